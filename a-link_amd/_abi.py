@@ -1,0 +1,113 @@
+"""ctypes binding of libalink_hip.so (include/alink_hip.h) — the only way this package computes.
+
+There is NO fallback: if the library is missing, or a call fails, an exception is raised.  The
+prototypes below are a 1:1 transcription of include/alink_hip.h; tests/test_abi.py checks that the
+built library exports every symbol the header declares.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libalink_hip.so")
+
+DT_BF16, DT_F16 = 0, 1
+LAYOUT_NHWC_F32, LAYOUT_NCHW_F32, LAYOUT_NHWC_U8 = 0, 1, 2
+SCORE_UNCERTAINTY, SCORE_MARGIN, SCORE_ENTROPY, SCORE_DISPARITY = 0, 1, 2, 3
+
+
+class AlinkError(RuntimeError):
+    pass
+
+
+class IRCfg(C.Structure):
+    _fields_ = [("units", C.c_int * 4), ("widths", C.c_int * 5), ("height", C.c_int), ("width", C.c_int),
+                ("emb", C.c_int), ("dtype", C.c_int), ("bn_eps", C.c_float)]
+
+
+_vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+_fp = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes)
+PROTOTYPES = {
+    "alink_last_error": (C.c_char_p, []),
+    "alink_init": (_i, [_i]),
+    "alink_version": (_i, []),
+    "alink_backbone_create": (_vp, [C.POINTER(IRCfg)]),
+    "alink_backbone_destroy": (None, [_vp]),
+    "alink_backbone_load": (_i, [_vp, C.c_char_p, _vp, _sz]),
+    "alink_backbone_num_tensors": (_i, [_vp]),
+    "alink_backbone_tensor_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_sz)]),
+    "alink_backbone_finalize": (_i, [_vp]),
+    "alink_backbone_workspace_bytes": (_sz, [_vp, _i]),
+    "alink_embed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "alink_embed_profile": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
+    "alink_conv_nhwc": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
+    "alink_head_create": (_vp, [_i, _i, _i, _f, _f, _f]),
+    "alink_head_destroy": (None, [_vp]),
+    "alink_head_num_params": (_sz, [_vp]),
+    "alink_head_set_params": (_i, [_vp, _vp, _sz]),
+    "alink_head_get_params": (_i, [_vp, _vp, _sz]),
+    "alink_head_reset_optimizer": (_i, [_vp]),
+    "alink_head_set_lr": (_i, [_vp, _f]),
+    "alink_head_get_lr": (_f, [_vp]),
+    "alink_head_params_dev": (_vp, [_vp]),
+    "alink_head_grads_dev": (_vp, [_vp]),
+    "alink_head_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "alink_committee_forward": (_i, [C.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "alink_head_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp]),
+    "alink_head_apply_update": (_i, [_vp, _vp]),
+    "alink_head_eval": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "alink_score": (_i, [_i, _vp, _vp, _i, _i64, _i, _vp, _vp]),
+    "alink_topk_scratch_bytes": (_sz, [_i64, _i]),
+    "alink_topk": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+_inited_devices = set()
+
+
+def load():
+    """dlopen the library and install prototypes.  Does not touch the GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AlinkError(
+            "libalink_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C a-link_amd/csrc`).  This package has no non-HIP fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().alink_last_error()
+        raise AlinkError("%s failed (%d): %s" % (what or "alink call", rc, msg.decode() if msg else "?"))
+
+
+def init(device=0):
+    """alink_init on `device` (once per device).  Raises if no GPU is visible."""
+    lib = load()
+    if device not in _inited_devices:
+        check(lib.alink_init(int(device)), "alink_init")
+        _inited_devices.add(device)
+    return lib
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    if hasattr(t, "data_ptr"):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)

@@ -1,0 +1,124 @@
+"""IRBackbone — host-side owner of one alink_backbone_t handle (include/alink_hip.h).
+
+Device memory (inputs, outputs, workspace) is allocated through torch; the arithmetic runs in
+libalink_hip.so.  Mirrors what face_model.get_model builds (reference code/face_model.py:28-41) but
+binds a *batched* executor: the reference binds batch = 1 (code/face_model.py:39).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from . import weights as W
+
+
+class IRBackbone(object):
+    def __init__(self, params, image_size=(112, 112), emb=512, dtype="bf16", device=0, max_batch=256,
+                 widths=W.WIDTHS):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _abi.AlinkError("no ROCm device visible: a-link_amd computes only on the GPU (no CPU fallback)")
+        self.device = device
+        self.lib = _abi.init(device)
+        self.units = W.infer_units(params)
+        self.emb = emb
+        self.image_size = tuple(image_size)
+        self.max_batch = int(max_batch)
+        cfg = _abi.IRCfg()
+        cfg.units[:] = list(self.units)
+        cfg.widths[:] = list(widths)
+        cfg.height, cfg.width = int(image_size[0]), int(image_size[1])
+        cfg.emb = emb
+        cfg.dtype = {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16}[dtype]
+        cfg.bn_eps = 2e-5
+        self.dtype = dtype
+        self.h = self.lib.alink_backbone_create(C.byref(cfg))
+        if not self.h:
+            raise _abi.AlinkError("alink_backbone_create: " + self.lib.alink_last_error().decode())
+        n = self.lib.alink_backbone_num_tensors(self.h)
+        name, cnt = C.c_char_p(), C.c_size_t()
+        for i in range(n):
+            _abi.check(self.lib.alink_backbone_tensor_info(self.h, i, C.byref(name), C.byref(cnt)))
+            key = name.value.decode()
+            if key not in params:
+                raise KeyError("checkpoint is missing tensor %s" % key)
+            a = np.ascontiguousarray(params[key], dtype=np.float32)
+            _abi.check(self.lib.alink_backbone_load(self.h, name.value, _abi.ptr(a), a.size), "load " + key)
+        _abi.check(self.lib.alink_backbone_finalize(self.h), "alink_backbone_finalize")
+        self._ws = None
+        self._ws_n = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.alink_backbone_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- workspace -------------------------------------------------------------------------------
+    def _workspace(self, n):
+        if self._ws is None or n > self._ws_n:
+            nbytes = self.lib.alink_backbone_workspace_bytes(self.h, n)
+            self._ws = self.torch.empty(nbytes + 256, dtype=self.torch.uint8, device="cuda:%d" % self.device)
+            self._ws_n = n
+        off = (-self._ws.data_ptr()) % 256
+        return self._ws.data_ptr() + off, self._ws.numel() - off
+
+    @staticmethod
+    def _layout_of(x, image_size):
+        if x.ndim != 4:
+            raise ValueError("expected a 4-d batch of images, got shape %s" % (tuple(x.shape),))
+        h, w = image_size
+        is_u8 = str(x.dtype) in ("uint8", "torch.uint8")
+        if tuple(x.shape[1:]) == (h, w, 3):
+            return _abi.LAYOUT_NHWC_U8 if is_u8 else _abi.LAYOUT_NHWC_F32
+        if tuple(x.shape[1:]) == (3, h, w) and not is_u8:
+            return _abi.LAYOUT_NCHW_F32
+        raise ValueError("images of shape %s do not match (N,%d,%d,3) / (N,3,%d,%d)" % (tuple(x.shape), h, w, h, w))
+
+    def embed_device(self, x, out=None):
+        """x: CUDA tensor (N,H,W,3) f32|u8 or (N,3,H,W) f32, contiguous.  Returns (N, emb) f32 CUDA."""
+        torch = self.torch
+        layout = self._layout_of(x, self.image_size)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        n = x.shape[0]
+        if out is None:
+            out = torch.empty((n, self.emb), dtype=torch.float32, device=x.device)
+        st = _abi.current_stream()
+        for i in range(0, n, self.max_batch):
+            m = min(self.max_batch, n - i)
+            ws, wsb = self._workspace(m)
+            _abi.check(self.lib.alink_embed(self.h, _abi.ptr(x[i:i + m]), layout, m, _abi.ptr(out[i:i + m]),
+                                            C.c_void_p(ws), wsb, st), "alink_embed")
+        return out
+
+    def embed(self, x):
+        """numpy in -> numpy out (the reference's calling convention: host arrays, code/siamese.py:234);
+        torch CUDA tensor in -> torch CUDA tensor out."""
+        torch = self.torch
+        if isinstance(x, np.ndarray):
+            if x.dtype != np.uint8:
+                x = np.ascontiguousarray(x, dtype=np.float32)
+            xd = torch.from_numpy(np.ascontiguousarray(x)).to("cuda:%d" % self.device)
+            return self.embed_device(xd).cpu().numpy()
+        return self.embed_device(x)
+
+    def profile(self, x):
+        """One profiled forward: list of (kind, ms, flops) per launch (HIP events on the stream)."""
+        torch = self.torch
+        layout = self._layout_of(x, self.image_size)
+        n = x.shape[0]
+        assert n <= self.max_batch
+        out = torch.empty((n, self.emb), dtype=torch.float32, device=x.device)
+        ws, wsb = self._workspace(n)
+        cap = 1024
+        ms = (C.c_float * cap)()
+        fl = (C.c_double * cap)()
+        kd = (C.c_int * cap)()
+        nl = C.c_int(cap)
+        _abi.check(self.lib.alink_embed_profile(self.h, _abi.ptr(x), layout, n, _abi.ptr(out), C.c_void_p(ws), wsb,
+                                                _abi.current_stream(), ms, fl, kd, C.byref(nl)), "alink_embed_profile")
+        return [(kd[i], ms[i], fl[i]) for i in range(nl.value)]

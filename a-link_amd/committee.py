@@ -1,0 +1,61 @@
+"""committee — drop-in for reference code/committee.py.
+
+Bagging.predict (code/committee.py:13-20) = sum of member predictions / number of members.  When every
+member is a device-resident DenseHead the mean is fused on the GPU (alink_committee_forward: member
+softmaxes accumulated in member order, one divide); any other duck-typed member falls back to the
+reference's own host arithmetic on the members' outputs.
+attackModel / resize (code/committee.py:22-37) drive the noise objects and need cv2-style bilinear
+resize; resize here is the identity when the size already matches and raises otherwise (noise stage =
+SURVEY.md §8f N1, not built yet).
+"""
+import numpy as np
+
+from . import head as _head
+
+
+class Bagging:
+    def __init__(self, models, attacks):
+        self.models = models
+        self.attacks = []
+        for attack in attacks:
+            self.attacks.append(attack)
+
+    def _device_heads(self):
+        hs = [getattr(m, "siamese_net", None) for m in self.models]
+        if all(isinstance(h, _head.DenseHead) for h in hs) and \
+                all(getattr(m, "_identity_preprocess", False) for m in self.models):
+            return hs
+        return None
+
+    def predict(self, predict_on):
+        hs = self._device_heads()
+        if hs is not None:
+            out = _head.committee_predict_device(hs, predict_on[0], predict_on[1])
+            return out if isinstance(predict_on[0], hs[0].torch.Tensor) else out.cpu().numpy()
+        predictions = []
+        for model in self.models:
+            predictions.append(model.predict(predict_on))
+        predicted = np.sum(np.array(predictions), axis=0) / len(self.models)
+        return np.array(predicted)
+
+    def predict_indexed(self, emb_left, emb_right, li, ri):
+        """Extension: score pairs (li[p], ri[p]) gathered from embedding matrices on device."""
+        hs = self._device_heads()
+        if hs is None:
+            raise TypeError("predict_indexed needs DenseHead members")
+        return _head.committee_predict_device(hs, emb_left, emb_right, li, ri)
+
+    def resize(self, images, new_size):
+        images = np.asarray(images)
+        if tuple(images.shape[1:3]) == (new_size[1], new_size[0]) or tuple(images.shape[1:3]) == tuple(new_size):
+            return np.array(images)
+        raise NotImplementedError("bilinear resize (cv2.resize, code/committee.py:22-26) is part of the noise "
+                                  "stage (SURVEY.md §8f N1), not built yet")
+
+    def attackModel(self, image_pairs, target_size, target_labels=None):
+        perturbed_l, perturbed_r = [], []
+        for attack in self.attacks:
+            preturbed = attack.addPairNoise(image_pairs, target_labels)
+            perturbed_l.append(self.resize(preturbed[0], target_size))
+            perturbed_r.append(self.resize(preturbed[1], target_size))
+        return [perturbed_l, perturbed_r]

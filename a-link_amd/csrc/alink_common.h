@@ -1,0 +1,89 @@
+// alink_common.h — shared host/device declarations for libalink_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+
+#include "../../include/alink_hip.h"
+
+namespace alink {
+
+// ---- error plumbing (never throw across the C ABI) ---------------------------------------------
+void set_error(const char* fmt, ...);
+int  hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define ALINK_HIP(call)                                                          \
+    do {                                                                         \
+        hipError_t e__ = (call);                                                 \
+        if (e__ != hipSuccess) return ::alink::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define ALINK_REQUIRE(cond, code, ...)          \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::alink::set_error(__VA_ARGS__);    \
+            return (code);                      \
+        }                                       \
+    } while (0)
+
+// ---- vector types -------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16   bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float    f32x4;
+typedef __attribute__((ext_vector_type(16))) float   f32x16;
+
+// ---- implicit-GEMM convolution launch descriptor -------------------------------------------------
+// Activations are NHWC in T (bf16 | f16); weights are [Cout][ksz*ksz*Cin] in T with the rows of
+// every 64-row block permuted by `perm64` (see conv_igemm.hip) so that a lane's 16 accumulator
+// values are 16 consecutive output channels.
+struct ConvParams {
+    const void*  in;      // [N][H][W][Cin]
+    const void*  wgt;     // [Cout][K]  (row-permuted)
+    const float* bias;    // [ncls][Cout] f32, natural channel order; ncls = border_cls ? 9 : 1
+    const float* alpha;   // [Cout] PReLU slopes, or nullptr
+    const void*  resid;   // [M][Cout] T, or nullptr
+    void*        out;     // [M][Cout] T;  split-K: f32 slabs [splitk][M][Cout]
+    const void*  zero;    // >= 256 B of zeros (source for padded taps / tail rows)
+    int N, H, W, Cin, Cout, Ho, Wo, stride, ksz, pad, M;
+    int border_cls;       // bias class chosen by output position (3x3, stride 1, pad 1 only)
+    int splitk;           // 1 = fused epilogue; >1 = f32 partial slabs
+    int ksteps_per_split;
+};
+
+// Launchers (host).  All enqueue on `stream` and return a HIP error.
+hipError_t launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t stream);
+double     conv_flops(const ConvParams& p);
+
+struct StemParams {
+    const void*  in;      // pixels, layout per `layout`
+    const void*  wgt;     // [64'][32] T: k = ky*9 + kx*3 + c (27 real, 5 zero), rows permuted
+    const float* bias;    // [C0]
+    const float* alpha;   // [C0]
+    void*        out;     // [N][H][W][C0] T
+    int N, H, W, C0, layout;
+};
+hipError_t launch_stem(int dtype, const StemParams& p, hipStream_t stream);
+
+struct FcFinishParams {
+    const float* slabs;   // [S][M][E]
+    const float* bias;    // [E]
+    float*       out;     // [M][E], L2-normalised rows
+    int S, M, E;
+};
+hipError_t launch_fc_finish(const FcFinishParams& p, hipStream_t stream);
+
+// position of natural channel c (0..63 within its 64-block) in the permuted weight rows
+static inline int perm64_row_of_channel(int c) {
+    // MFMA tile t (0..3), row 4q+j  <->  channel 16q + 4t + j
+    int q = c >> 4, t = (c >> 2) & 3, j = c & 3;
+    return 16 * t + 4 * q + j;
+}
+
+// host-side conversions
+uint16_t f32_to_bf16_rne(float f);
+uint16_t f32_to_f16_rne(float f);
+
+int init_kernels();   // function attributes (dynamic LDS sizes)
+
+}  // namespace alink

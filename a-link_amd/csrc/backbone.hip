@@ -1,0 +1,598 @@
+// backbone.hip — host side of the IR-ResNet ("ArcFace") feature extractor behind the C ABI.
+//
+// Replaces, for the hot path only:
+//   face_model.get_model            reference code/face_model.py:28-41  (load_checkpoint, slice at
+//                                   fc1_output, bind, set_params)
+//   FaceModel.get_feature           reference code/face_model.py:86-93  (forward + L2 normalise)
+// The network arithmetic itself is insightface's LResNet-E-IR symbol (fresnet.py, version_unit 3,
+// version_input 1, version_output 'E'), which the reference loads from a downloaded checkpoint
+// (code/arcface_prepreq.sh:18-19); SURVEY.md §8 row a5 is the spec followed here:
+//   data -> (x-127.5)*0.0078125 -> conv0 3x3 -> bn0 -> prelu
+//   4 stages of units:  bn1 -> conv1 3x3 s1 -> bn2 -> prelu -> conv2 3x3 s{2,1} -> bn3  (+ shortcut:
+//                       identity, or conv1sc 1x1 s2 -> bn 'sc' on the first unit of a stage)
+//   bn1 -> dropout(identity) -> flatten(C,H,W) -> pre_fc1 -> fc1 (BN, fix_gamma)
+//
+// Everything BN is folded at finalize() (inference only, like the reference's is_train=False):
+//   * post-conv BN scale -> weight rows, shift -> bias;
+//   * the pre-activation bn1 of a unit: scale -> weight input channels; its shift cannot be folded
+//     into a single bias because the conv zero-pads AFTER the BN, so border pixels miss some taps.
+//     We keep it exact with 9 bias classes (top/middle/bottom x left/middle/right): class bias =
+//     full bias minus the per-tap shift contributions of the taps that fall outside the image.
+//   * final bn1 + fc1 BN fold into the FC weights/bias (no padding there).
+#include "alink_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace alink {
+
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    set_error("HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return ALINK_EHIP;
+}
+
+uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+uint16_t f32_to_f16_rne(float f) {
+    _Float16 h = (_Float16)f;   // host clang: IEEE RNE conversion
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+static inline uint16_t cvt(int dtype, float f) {
+    return dtype == ALINK_DT_BF16 ? f32_to_bf16_rne(f) : f32_to_f16_rne(f);
+}
+
+hipError_t conv_set_attributes();
+int init_kernels() {
+    hipError_t e = conv_set_attributes();
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute", __FILE__, __LINE__);
+    return ALINK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct BN { std::vector<double> a, b; };   // y = a*x + b
+
+struct ConvLayer {
+    int Cin, Cout, ksz, stride, pad, Hin, Win, Hout, Wout;
+    bool border_cls, has_alpha;
+    int in_buf, out_buf, resid_buf;        // workspace buffer ids, -1 = none
+    void*  d_w = nullptr;                   // T [Cout][K] permuted
+    float* d_bias = nullptr;                // [ncls][Cout]
+    float* d_alpha = nullptr;               // [Cout]
+    std::string name;
+};
+
+}  // namespace alink
+
+using namespace alink;
+
+struct alink_backbone {
+    alink_ir_cfg cfg;
+    std::vector<std::pair<std::string, size_t>> expected;     // name, count (load order)
+    std::map<std::string, std::vector<float>> raw;
+    bool finalized = false;
+
+    // device side
+    void*  d_stem_w = nullptr;
+    float* d_stem_bias = nullptr;
+    float* d_stem_alpha = nullptr;
+    std::vector<ConvLayer> convs;
+    void*  d_fc_w = nullptr;
+    float* d_fc_bias = nullptr;
+    void*  d_zero = nullptr;
+    int fc_K = 0, fc_splitk = 1, fc_kps = 0;
+    int Hf = 0, Wf = 0;                                        // final feature map size
+    std::vector<void*> allocs;
+
+    ~alink_backbone() {
+        for (void* p : allocs) (void)hipFree(p);
+    }
+};
+
+namespace {
+
+void expect(alink_backbone* bb, const std::string& n, size_t c) { bb->expected.emplace_back(n, c); }
+void expect_bn(alink_backbone* bb, const std::string& n, size_t c) {
+    expect(bb, n + "_gamma", c);
+    expect(bb, n + "_beta", c);
+    expect(bb, n + "_moving_mean", c);
+    expect(bb, n + "_moving_var", c);
+}
+
+int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
+
+BN get_bn(const alink_backbone* bb, const std::string& n, bool fix_gamma) {
+    const auto& g = bb->raw.at(n + "_gamma");
+    const auto& be = bb->raw.at(n + "_beta");
+    const auto& mu = bb->raw.at(n + "_moving_mean");
+    const auto& var = bb->raw.at(n + "_moving_var");
+    BN r;
+    r.a.resize(g.size());
+    r.b.resize(g.size());
+    for (size_t i = 0; i < g.size(); ++i) {
+        const double gamma = fix_gamma ? 1.0 : (double)g[i];
+        r.a[i] = gamma / std::sqrt((double)var[i] + (double)bb->cfg.bn_eps);
+        r.b[i] = (double)be[i] - (double)mu[i] * r.a[i];
+    }
+    return r;
+}
+
+template <typename V>
+int upload(alink_backbone* bb, const std::vector<V>& h, void** d) {
+    ALINK_HIP(hipMalloc(d, h.size() * sizeof(V)));
+    bb->allocs.push_back(*d);
+    ALINK_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(V), hipMemcpyHostToDevice));
+    return ALINK_OK;
+}
+
+// Fold + upload one convolution.  w is MXNet (O, I, kh, kw).
+int build_conv(alink_backbone* bb, ConvLayer& L, const std::vector<float>& w, const BN* pre,
+               const BN& post, const std::vector<float>* prelu) {
+    const int O = L.Cout, I = L.Cin, k = L.ksz, K = k * k * I, dt = bb->cfg.dtype;
+    std::vector<uint16_t> wq((size_t)O * K);
+    std::vector<double> tapb((size_t)k * k * O, 0.0);          // [tap][co] shift contribution
+    for (int co = 0; co < O; ++co) {
+        const int blk = co & ~63, row = blk + perm64_row_of_channel(co & 63);
+        for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx) {
+                double tb = 0.0;
+                for (int ci = 0; ci < I; ++ci) {
+                    const double wv = (double)w[(((size_t)co * I + ci) * k + ky) * k + kx];
+                    const double ai = pre ? pre->a[ci] : 1.0;
+                    wq[(size_t)row * K + (size_t)(ky * k + kx) * I + ci] = cvt(dt, (float)(post.a[co] * wv * ai));
+                    if (pre) tb += wv * pre->b[ci];
+                }
+                tapb[(size_t)(ky * k + kx) * O + co] = post.a[co] * tb;
+            }
+    }
+    const int ncls = L.border_cls ? 9 : 1;
+    std::vector<float> bias((size_t)ncls * O);
+    for (int co = 0; co < O; ++co) {
+        double full = post.b[co];
+        for (int t = 0; t < k * k; ++t) full += tapb[(size_t)t * O + co];
+        if (!L.border_cls) { bias[co] = (float)full; continue; }
+        for (int rc = 0; rc < 3; ++rc)
+            for (int cc = 0; cc < 3; ++cc) {
+                double b = full;
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const bool miss = (rc == 0 && ky == 0) || (rc == 2 && ky == 2) ||
+                                          (cc == 0 && kx == 0) || (cc == 2 && kx == 2);
+                        if (miss) b -= tapb[(size_t)(ky * 3 + kx) * O + co];
+                    }
+                bias[(size_t)(rc * 3 + cc) * O + co] = (float)b;
+            }
+    }
+    int rc;
+    if ((rc = upload(bb, wq, &L.d_w))) return rc;
+    if ((rc = upload(bb, bias, (void**)&L.d_bias))) return rc;
+    if (prelu) {
+        if ((rc = upload(bb, *prelu, (void**)&L.d_alpha))) return rc;
+    }
+    return ALINK_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* alink_last_error(void) { return g_err; }
+int alink_version(void) { return 1; }
+
+int alink_init(int device) {
+    ALINK_HIP(hipSetDevice(device));
+    return init_kernels();
+}
+
+alink_backbone_t* alink_backbone_create(const alink_ir_cfg* cfg) {
+    if (!cfg) { set_error("cfg is NULL"); return nullptr; }
+    for (int i = 0; i < 5; ++i)
+        if (cfg->widths[i] <= 0 || cfg->widths[i] % 64) {
+            set_error("widths[%d]=%d must be a positive multiple of 64", i, cfg->widths[i]);
+            return nullptr;
+        }
+    if (cfg->widths[0] != 64) { set_error("stem width must be 64 (got %d)", cfg->widths[0]); return nullptr; }
+    for (int i = 0; i < 4; ++i)
+        if (cfg->units[i] < 1) { set_error("units[%d] must be >= 1", i); return nullptr; }
+    if (cfg->emb <= 0 || cfg->emb % 64) { set_error("emb must be a multiple of 64"); return nullptr; }
+    if (cfg->height < 16 || cfg->width < 16 || cfg->height % 16 || cfg->width % 16) {
+        set_error("input size %dx%d must be a multiple of 16 (four stride-2 stages)", cfg->height, cfg->width);
+        return nullptr;
+    }
+    if (cfg->dtype != ALINK_DT_BF16 && cfg->dtype != ALINK_DT_F16) { set_error("bad dtype"); return nullptr; }
+    alink_backbone* bb = new alink_backbone();
+    bb->cfg = *cfg;
+    if (!(bb->cfg.bn_eps > 0.f)) bb->cfg.bn_eps = 2e-5f;
+
+    // expected tensors, MXNet names
+    const int* w = cfg->widths;
+    expect(bb, "conv0_weight", (size_t)w[0] * 3 * 9);
+    expect_bn(bb, "bn0", w[0]);
+    expect(bb, "relu0_gamma", w[0]);
+    int H = cfg->height, W = cfg->width;
+    for (int s = 0; s < 4; ++s) {
+        const int cin_stage = w[s], c = w[s + 1];
+        for (int u = 0; u < cfg->units[s]; ++u) {
+            char pfx[64];
+            snprintf(pfx, sizeof(pfx), "stage%d_unit%d", s + 1, u + 1);
+            const std::string P(pfx);
+            const int cin = (u == 0) ? cin_stage : c;
+            expect_bn(bb, P + "_bn1", cin);
+            expect(bb, P + "_conv1_weight", (size_t)c * cin * 9);
+            expect_bn(bb, P + "_bn2", c);
+            expect(bb, P + "_relu1_gamma", c);
+            expect(bb, P + "_conv2_weight", (size_t)c * c * 9);
+            expect_bn(bb, P + "_bn3", c);
+            if (u == 0) {
+                expect(bb, P + "_conv1sc_weight", (size_t)c * cin);
+                expect_bn(bb, P + "_sc", c);
+            }
+        }
+        H = conv_out(H, 3, 2, 1);
+        W = conv_out(W, 3, 2, 1);
+    }
+    bb->Hf = H;
+    bb->Wf = W;
+    expect_bn(bb, "bn1", w[4]);
+    expect(bb, "pre_fc1_weight", (size_t)cfg->emb * w[4] * H * W);
+    expect(bb, "pre_fc1_bias", cfg->emb);
+    expect_bn(bb, "fc1", cfg->emb);
+    return bb;
+}
+
+void alink_backbone_destroy(alink_backbone_t* bb) { delete bb; }
+
+int alink_backbone_num_tensors(const alink_backbone_t* bb) { return bb ? (int)bb->expected.size() : 0; }
+
+int alink_backbone_tensor_info(const alink_backbone_t* bb, int i, const char** name, size_t* count) {
+    ALINK_REQUIRE(bb && i >= 0 && i < (int)bb->expected.size(), ALINK_EINVAL, "tensor index out of range");
+    if (name) *name = bb->expected[i].first.c_str();
+    if (count) *count = bb->expected[i].second;
+    return ALINK_OK;
+}
+
+int alink_backbone_load(alink_backbone_t* bb, const char* name, const float* host, size_t count) {
+    ALINK_REQUIRE(bb && name && host, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(!bb->finalized, ALINK_ESTATE, "backbone already finalized");
+    for (const auto& e : bb->expected)
+        if (e.first == name) {
+            ALINK_REQUIRE(e.second == count, ALINK_EINVAL, "tensor %s: expected %zu elements, got %zu", name,
+                          e.second, count);
+            bb->raw[name].assign(host, host + count);
+            return ALINK_OK;
+        }
+    set_error("tensor %s is not part of the configured network", name);
+    return ALINK_ENOTFOUND;
+}
+
+int alink_backbone_finalize(alink_backbone_t* bb) {
+    ALINK_REQUIRE(bb, ALINK_EINVAL, "NULL backbone");
+    ALINK_REQUIRE(!bb->finalized, ALINK_ESTATE, "backbone already finalized");
+    for (const auto& e : bb->expected)
+        ALINK_REQUIRE(bb->raw.count(e.first), ALINK_ESTATE, "tensor %s was never loaded", e.first.c_str());
+    int rc = init_kernels();
+    if (rc) return rc;
+    const alink_ir_cfg& cfg = bb->cfg;
+    const int dt = cfg.dtype;
+    const int* w = cfg.widths;
+
+    // zero page
+    ALINK_HIP(hipMalloc(&bb->d_zero, 4096));
+    bb->allocs.push_back(bb->d_zero);
+    ALINK_HIP(hipMemset(bb->d_zero, 0, 4096));
+
+    // ---- stem: W'[co][k=ky*9+kx*3+c] = a0[co] * W[co][c][ky][kx]; input normalisation happens in
+    // the kernel's loader so the zero frame is a true zero and no border classes are needed.
+    {
+        const auto& cw = bb->raw.at("conv0_weight");
+        const BN bn0 = get_bn(bb, "bn0", false);
+        std::vector<uint16_t> wq((size_t)64 * 32, cvt(dt, 0.f));
+        for (int co = 0; co < 64; ++co) {
+            const int row = perm64_row_of_channel(co);
+            for (int c = 0; c < 3; ++c)
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx)
+                        wq[(size_t)row * 32 + ky * 9 + kx * 3 + c] =
+                            cvt(dt, (float)(bn0.a[co] * (double)cw[(((size_t)co * 3 + c) * 3 + ky) * 3 + kx]));
+        }
+        std::vector<float> bias(64);
+        for (int co = 0; co < 64; ++co) bias[co] = (float)bn0.b[co];
+        if ((rc = upload(bb, wq, &bb->d_stem_w))) return rc;
+        if ((rc = upload(bb, bias, (void**)&bb->d_stem_bias))) return rc;
+        if ((rc = upload(bb, bb->raw.at("relu0_gamma"), (void**)&bb->d_stem_alpha))) return rc;
+    }
+
+    // ---- residual stages.  Workspace buffers: 0,1 = "big" (stem resolution), 2,3,4 = "small".
+    // x lives in `xb`; conv1 -> T, shortcut -> S, conv2(+resid) -> Y.
+    int H = cfg.height, W = cfg.width;
+    int xb = 0;                                  // stem writes buffer 0
+    for (int s = 0; s < 4; ++s) {
+        const int c = w[s + 1];
+        for (int u = 0; u < cfg.units[s]; ++u) {
+            char pfx[64];
+            snprintf(pfx, sizeof(pfx), "stage%d_unit%d", s + 1, u + 1);
+            const std::string P(pfx);
+            const int cin = (u == 0) ? w[s] : c;
+            const int stride = (u == 0) ? 2 : 1;
+            const int Ho = conv_out(H, 3, stride, 1), Wo = conv_out(W, 3, stride, 1);
+            // pick three buffers different from xb
+            int free_ids[4], nf = 0;
+            for (int b = 1; b <= 4 && nf < 4; ++b)
+                if (b != xb) free_ids[nf++] = b;
+            // the first unit of stage 1 produces a stem-resolution conv1 output: it must use a big
+            // buffer (0 or 1); xb is 0 there so T = 1.  Everything later fits the small buffers.
+            const int tb = free_ids[0], sb = free_ids[1], yb = free_ids[2];
+
+            const BN bn1 = get_bn(bb, P + "_bn1", false), bn2 = get_bn(bb, P + "_bn2", false),
+                     bn3 = get_bn(bb, P + "_bn3", false);
+            ConvLayer c1{};
+            c1.name = P + "_conv1";
+            c1.Cin = cin; c1.Cout = c; c1.ksz = 3; c1.stride = 1; c1.pad = 1;
+            c1.Hin = H; c1.Win = W; c1.Hout = H; c1.Wout = W;
+            c1.border_cls = true; c1.has_alpha = true;
+            c1.in_buf = xb; c1.out_buf = tb; c1.resid_buf = -1;
+            if ((rc = build_conv(bb, c1, bb->raw.at(P + "_conv1_weight"), &bn1, bn2, &bb->raw.at(P + "_relu1_gamma"))))
+                return rc;
+            bb->convs.push_back(c1);
+
+            int resid = xb;
+            if (u == 0) {
+                const BN bsc = get_bn(bb, P + "_sc", false);
+                ConvLayer sc{};
+                sc.name = P + "_conv1sc";
+                sc.Cin = cin; sc.Cout = c; sc.ksz = 1; sc.stride = stride; sc.pad = 0;
+                sc.Hin = H; sc.Win = W; sc.Hout = Ho; sc.Wout = Wo;
+                sc.border_cls = false; sc.has_alpha = false;
+                sc.in_buf = xb; sc.out_buf = sb; sc.resid_buf = -1;
+                if ((rc = build_conv(bb, sc, bb->raw.at(P + "_conv1sc_weight"), nullptr, bsc, nullptr))) return rc;
+                bb->convs.push_back(sc);
+                resid = sb;
+            }
+            ConvLayer c2{};
+            c2.name = P + "_conv2";
+            c2.Cin = c; c2.Cout = c; c2.ksz = 3; c2.stride = stride; c2.pad = 1;
+            c2.Hin = H; c2.Win = W; c2.Hout = Ho; c2.Wout = Wo;
+            c2.border_cls = false; c2.has_alpha = false;
+            c2.in_buf = tb; c2.out_buf = yb; c2.resid_buf = resid;
+            if ((rc = build_conv(bb, c2, bb->raw.at(P + "_conv2_weight"), nullptr, bn3, nullptr))) return rc;
+            bb->convs.push_back(c2);
+            xb = yb;
+            H = Ho;
+            W = Wo;
+        }
+    }
+
+    // ---- FC: flatten is (C,H,W) in the reference symbol; our activations are (H,W,C).
+    {
+        const int C = w[4], E = cfg.emb, HW = H * W, K = C * HW;
+        const auto& fw = bb->raw.at("pre_fc1_weight");
+        const auto& fb = bb->raw.at("pre_fc1_bias");
+        const BN bnl = get_bn(bb, "bn1", false), bfc = get_bn(bb, "fc1", true);
+        std::vector<uint16_t> wq((size_t)E * K);
+        std::vector<float> bias(E);
+        for (int o = 0; o < E; ++o) {
+            const int row = (o & ~63) + perm64_row_of_channel(o & 63);
+            double b = (double)fb[o];
+            for (int ch = 0; ch < C; ++ch)
+                for (int pos = 0; pos < HW; ++pos) {
+                    const double wv = (double)fw[(size_t)o * K + (size_t)ch * HW + pos];
+                    wq[(size_t)row * K + (size_t)pos * C + ch] = cvt(dt, (float)(bfc.a[o] * wv * bnl.a[ch]));
+                    b += wv * bnl.b[ch];
+                }
+            bias[o] = (float)(bfc.a[o] * b + bfc.b[o]);
+        }
+        if ((rc = upload(bb, wq, &bb->d_fc_w))) return rc;
+        if ((rc = upload(bb, bias, (void**)&bb->d_fc_bias))) return rc;
+        bb->fc_K = K;
+        const int nk = K / 64;
+        int S = nk / 14;                         // ~14 K-steps per split
+        if (S < 1) S = 1;
+        if (S > 64) S = 64;
+        bb->fc_kps = (nk + S - 1) / S;
+        bb->fc_splitk = (nk + bb->fc_kps - 1) / bb->fc_kps;
+        bb->Hf = H;
+        bb->Wf = W;
+    }
+    bb->raw.clear();
+    bb->finalized = true;
+    return ALINK_OK;
+}
+
+// workspace layout: [big0][big1][small2][small3][small4][fc slabs]
+static void ws_layout(const alink_backbone* bb, int N, size_t off[6], size_t* total) {
+    const alink_ir_cfg& c = bb->cfg;
+    const size_t big = (size_t)N * c.height * c.width * c.widths[0] * 2;
+    // small buffers hold shortcut and unit outputs (conv1 outputs always go to big buffer 1)
+    size_t small = 0;
+    int H = c.height, W = c.width;
+    for (int s = 0; s < 4; ++s) {
+        const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+        small = std::max(small, (size_t)N * Ho * Wo * c.widths[s + 1] * 2);
+        H = Ho;
+        W = Wo;
+    }
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o = 0;
+    off[0] = o; o += al(big);
+    off[1] = o; o += al(big);
+    for (int i = 2; i < 5; ++i) { off[i] = o; o += al(small); }
+    off[5] = o; o += al((size_t)bb->fc_splitk * N * c.emb * 4);
+    *total = o;
+}
+
+size_t alink_backbone_workspace_bytes(const alink_backbone_t* bb, int n_images) {
+    if (!bb || !bb->finalized || n_images <= 0) return 0;
+    size_t off[6], total;
+    ws_layout(bb, n_images, off, &total);
+    return total;
+}
+
+static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int N, float* dev_out,
+                      void* ws, size_t ws_bytes, hipStream_t stream, float* ms, double* flops, int* kind,
+                      int* n_launches) {
+    ALINK_REQUIRE(bb && dev_in && dev_out && ws, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(bb->finalized, ALINK_ESTATE, "alink_embed before alink_backbone_finalize");
+    ALINK_REQUIRE(N > 0, ALINK_EINVAL, "n_images must be positive");
+    ALINK_REQUIRE(layout >= 0 && layout <= 2, ALINK_EINVAL, "unknown pixel layout %d", layout);
+    const alink_ir_cfg& cfg = bb->cfg;
+    ALINK_REQUIRE((long long)N * cfg.height * cfg.width * 64 < (1ll << 31), ALINK_EINVAL,
+                  "batch of %d images exceeds the 2^31-element activation limit; split the batch", N);
+    size_t off[6], total;
+    ws_layout(bb, N, off, &total);
+    ALINK_REQUIRE(ws_bytes >= total, ALINK_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, total);
+    ALINK_REQUIRE(((uintptr_t)ws & 255) == 0, ALINK_EINVAL, "workspace must be 256-byte aligned");
+    char* base = (char*)ws;
+    auto buf = [&](int id) -> void* { return base + off[id]; };
+
+    const bool prof = ms != nullptr;
+    const int cap = prof ? *n_launches : 0;
+    int nl = 0;
+    std::vector<hipEvent_t> ev;
+    auto mark = [&]() -> int {
+        if (!prof) return ALINK_OK;
+        hipEvent_t e;
+        ALINK_HIP(hipEventCreate(&e));
+        ALINK_HIP(hipEventRecord(e, stream));
+        ev.push_back(e);
+        return ALINK_OK;
+    };
+    auto note = [&](double f, int k) {
+        if (prof && nl < cap) { flops[nl] = f; kind[nl] = k; }
+        ++nl;
+    };
+    int rc;
+    if ((rc = mark())) return rc;
+
+    StemParams sp{};
+    sp.in = dev_in; sp.wgt = bb->d_stem_w; sp.bias = bb->d_stem_bias; sp.alpha = bb->d_stem_alpha;
+    sp.out = buf(0); sp.N = N; sp.H = cfg.height; sp.W = cfg.width; sp.C0 = 64; sp.layout = layout;
+    ALINK_HIP(launch_stem(cfg.dtype, sp, stream));
+    note(2.0 * N * cfg.height * cfg.width * 64.0 * 27.0, 0);
+    if ((rc = mark())) return rc;
+
+    int last_out = 0;
+    for (const ConvLayer& L : bb->convs) {
+        ConvParams p{};
+        p.in = buf(L.in_buf); p.wgt = L.d_w; p.bias = L.d_bias; p.alpha = L.d_alpha;
+        p.resid = L.resid_buf >= 0 ? buf(L.resid_buf) : nullptr;
+        p.out = buf(L.out_buf); p.zero = bb->d_zero;
+        p.N = N; p.H = L.Hin; p.W = L.Win; p.Cin = L.Cin; p.Cout = L.Cout; p.Ho = L.Hout; p.Wo = L.Wout;
+        p.stride = L.stride; p.ksz = L.ksz; p.pad = L.pad; p.M = N * L.Hout * L.Wout;
+        p.border_cls = L.border_cls ? 1 : 0; p.splitk = 1;
+        p.ksteps_per_split = L.ksz * L.ksz * (L.Cin / 64);
+        ALINK_HIP(launch_conv_igemm(cfg.dtype, p, stream));
+        note(conv_flops(p), 1);
+        if ((rc = mark())) return rc;
+        last_out = L.out_buf;
+    }
+
+    // FC as a 1x1 "convolution" over N pixels with Cin = C*Hf*Wf, split-K into f32 slabs
+    {
+        ConvParams p{};
+        p.in = buf(last_out); p.wgt = bb->d_fc_w; p.bias = nullptr; p.alpha = nullptr; p.resid = nullptr;
+        p.out = buf(5); p.zero = bb->d_zero;
+        p.N = N; p.H = 1; p.W = 1; p.Cin = bb->fc_K; p.Cout = cfg.emb; p.Ho = 1; p.Wo = 1;
+        p.stride = 1; p.ksz = 1; p.pad = 0; p.M = N; p.border_cls = 0;
+        p.splitk = bb->fc_splitk; p.ksteps_per_split = bb->fc_kps;
+        ALINK_REQUIRE(p.splitk > 1, ALINK_EINVAL, "FC split-K must be > 1 (K=%d)", bb->fc_K);
+        ALINK_HIP(launch_conv_igemm(cfg.dtype, p, stream));
+        note(conv_flops(p), 2);
+        if ((rc = mark())) return rc;
+        FcFinishParams f{};
+        f.slabs = (const float*)buf(5); f.bias = bb->d_fc_bias; f.out = dev_out;
+        f.S = bb->fc_splitk; f.M = N; f.E = cfg.emb;
+        ALINK_HIP(launch_fc_finish(f, stream));
+        note(0.0, 3);
+        if ((rc = mark())) return rc;
+    }
+
+    if (prof) {
+        ALINK_HIP(hipStreamSynchronize(stream));
+        for (int i = 0; i + 1 < (int)ev.size() && i < cap; ++i) {
+            float t = 0.f;
+            ALINK_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+            ms[i] = t;
+        }
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        *n_launches = nl;
+    }
+    return ALINK_OK;
+}
+
+int alink_embed(alink_backbone_t* bb, const void* dev_in, int layout, int n_images, float* dev_out,
+                void* dev_workspace, size_t workspace_bytes, void* stream) {
+    return embed_impl(bb, dev_in, layout, n_images, dev_out, dev_workspace, workspace_bytes,
+                      (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
+}
+
+int alink_embed_profile(alink_backbone_t* bb, const void* dev_in, int layout, int n_images, float* dev_out,
+                        void* dev_workspace, size_t workspace_bytes, void* stream, float* ms, double* flops,
+                        int* kind, int* n_launches) {
+    ALINK_REQUIRE(ms && flops && kind && n_launches && *n_launches > 0, ALINK_EINVAL, "NULL profile buffers");
+    return embed_impl(bb, dev_in, layout, n_images, dev_out, dev_workspace, workspace_bytes,
+                      (hipStream_t)stream, ms, flops, kind, n_launches);
+}
+
+// ---- diagnostic single-convolution entry (unit tests) -------------------------------------------
+int alink_conv_nhwc(int dtype, const void* dev_in, const void* dev_w, const float* dev_bias,
+                    const float* dev_alpha, const void* dev_resid, void* dev_out, int N, int H, int W, int Cin,
+                    int Cout, int ksz, int stride, int pad, int border_cls, void* stream) {
+    ALINK_REQUIRE(dev_in && dev_w && dev_bias && dev_out, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, ALINK_EINVAL, "Cin/Cout must be multiples of 64");
+    ALINK_REQUIRE(ksz == 1 || ksz == 3, ALINK_EINVAL, "ksz must be 1 or 3");
+    ALINK_REQUIRE(!border_cls || (ksz == 3 && stride == 1 && pad == 1), ALINK_EINVAL,
+                  "border classes need a 3x3 stride-1 pad-1 convolution");
+    int rc = init_kernels();
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int K = ksz * ksz * Cin;
+    // permute weight rows into a private copy
+    std::vector<uint16_t> h((size_t)Cout * K), hp((size_t)Cout * K);
+    ALINK_HIP(hipStreamSynchronize(st));
+    ALINK_HIP(hipMemcpy(h.data(), dev_w, h.size() * 2, hipMemcpyDeviceToHost));
+    for (int co = 0; co < Cout; ++co) {
+        const int row = (co & ~63) + perm64_row_of_channel(co & 63);
+        memcpy(&hp[(size_t)row * K], &h[(size_t)co * K], (size_t)K * 2);
+    }
+    void *d_wp = nullptr, *d_zero = nullptr;
+    ALINK_HIP(hipMalloc(&d_wp, hp.size() * 2));
+    ALINK_HIP(hipMalloc(&d_zero, 4096));
+    ALINK_HIP(hipMemcpy(d_wp, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
+    ALINK_HIP(hipMemset(d_zero, 0, 4096));
+    ConvParams p{};
+    p.in = dev_in; p.wgt = d_wp; p.bias = dev_bias; p.alpha = dev_alpha; p.resid = dev_resid; p.out = dev_out;
+    p.zero = d_zero; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.Ho = conv_out(H, ksz, stride, pad); p.Wo = conv_out(W, ksz, stride, pad);
+    p.stride = stride; p.ksz = ksz; p.pad = pad; p.M = N * p.Ho * p.Wo; p.border_cls = border_cls;
+    p.splitk = 1; p.ksteps_per_split = ksz * ksz * (Cin / 64);
+    hipError_t e = launch_conv_igemm(dtype, p, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_wp);
+    (void)hipFree(d_zero);
+    if (e != hipSuccess) return hip_fail(e, "launch_conv_igemm", __FILE__, __LINE__);
+    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize", __FILE__, __LINE__);
+    return ALINK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,329 @@
+// conv_igemm.hip — NHWC implicit-GEMM convolution on the gfx950 matrix cores.
+//
+// This is the kernel that carries 99.8 % of the backbone FLOPs (the device
+// work behind `self.model.forward(db, is_train=False)` at reference code/face_model.py:90).
+//
+//   out[m][co] = epilogue( sum_{ky,kx,ci} in[n][oy*s+ky-pad][ox*s+kx-pad][ci] * w[co][ky][kx][ci] )
+//   m = (n*Ho + oy)*Wo + ox,   GEMM:  M = N*Ho*Wo pixels,  Ncols = Cout,  K = ksz*ksz*Cin
+//
+// Design (CDNA4):
+//   * 256-thread workgroup = 4 waves; every wave owns a 64-pixel x 64-channel output block as 4x4
+//     tiles of v_mfma_f32_16x16x32_{bf16,f16} (64 accumulator VGPRs).  WP x WC waves give a
+//     (64*WP)-pixel x (64*WC)-channel workgroup tile: 256x64 for 64-channel layers, 128x128 otherwise.
+//   * The weights are the MFMA *A* operand (rows = channels), the im2col pixels the *B* operand
+//     (cols = pixels), so an accumulator register holds 4 consecutive MFMA rows of ONE pixel.  The
+//     weight rows of each 64-block are stored permuted (perm64: tile t, row 4q+j  <->  channel
+//     16q+4t+j), which makes a lane's 16 accumulators 16 CONSECUTIVE channels: the epilogue writes
+//     32 contiguous bytes per lane and a full 128-B line per pixel with no LDS transpose.
+//   * K is walked tap-major in 64-channel steps.  One step stages a [pixels][64] and a [channels][64]
+//     tile (128-B rows) into LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip).  The
+//     DMA destination is lane-linear, so the bank-conflict swizzle (16-B chunk c of row r lives at
+//     chunk c ^ ((r>>1)&7)) is applied to the per-lane SOURCE address and again on the ds_read_b128
+//     side.  Padded taps and tail rows source a zero page instead of branching.
+//   * Two LDS buffers, one barrier per K-step: DMA for step k+1 is issued before the MFMAs of step
+//     k and retired by the vmcnt(0) that __syncthreads() carries.
+//   * blockIdx is remapped so that the workgroups sharing an XCD (blockIdx % 8) walk neighbouring
+//     pixel tiles: halo rows and weights are then shared in that XCD's L2.
+//   * Epilogue fuses: folded-BN bias (9 position classes when a pre-activation BN shift was folded
+//     through zero padding), PReLU, residual add, conversion to T.  Split-K mode (the 25088->512
+//     FC) writes f32 partial slabs instead (reduced in fixed order by fc_finish: deterministic).
+#include "alink_common.h"
+
+namespace alink {
+
+namespace {
+
+template <typename T> struct Vec8;
+template <> struct Vec8<__bf16>   { typedef bf16x8 type; };
+template <> struct Vec8<_Float16> { typedef f16x8 type; };
+
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16(typename Vec8<T>::type a, typename Vec8<T>::type b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mfma16<__bf16>(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mfma16<_Float16>(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// 16 bytes per lane, global -> LDS, no VGPR destination.  `lds_wave_base` must be wave-uniform:
+// lane l lands at lds_wave_base + 16*l.
+__device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gsrc,
+        (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Bijective XCD-aware remap (cdna_hip_programming.md §5 "XCD swizzle must be bijective"): blocks
+// with equal blockIdx % 8 share an XCD; give each such group one contiguous range of logical ids.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+template <typename T, int WP, int WC, bool DMA>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
+    typedef typename Vec8<T>::type vec8;
+    constexpr int BM = WP * 64, BN = WC * 64;
+    constexpr int PJ = BM / 32, WJ = BN / 32;
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave / WC, wc = wave % WC;
+
+    const int ntn = p.Cout / BN;
+    const int nwg = gridDim.x;
+    const int lid = xcd_remap(blockIdx.x, nwg);
+    const int tile_n = lid % ntn, tile_m = lid / ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+
+    const int Cin = p.Cin, W = p.W, ksz = p.ksz;
+    const int K = ksz * ksz * Cin;
+    const int cpt = Cin >> 6;                  // 64-channel steps per tap
+    const int nk = ksz * ksz * cpt;
+    const int kt0 = split * p.ksteps_per_split;
+    const int kt1 = min(kt0 + p.ksteps_per_split, nk);
+
+    const T* __restrict__ gin = (const T*)p.in;
+    const T* __restrict__ gw  = (const T*)p.wgt;
+    const T* __restrict__ gz  = (const T*)p.zero;
+
+    // ---- per-thread staging state: thread stages LDS chunk (tid&7) of rows (tid>>3) + 32*j ------
+    // swizzle: row r keeps logical chunk c at position c ^ ((r>>1)&7); (r>>1)&7 == (tid>>4)&7 for
+    // every j because rows advance by 32.
+    const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
+    int      poff[PJ];
+    unsigned pmask[PJ];
+    {
+        const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+            const int m = m0 + (tid >> 3) + 32 * j;
+            unsigned mask = 0;
+            int off = 0;
+            if (m < p.M) {
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                off = ((n * p.H + iy0) * W + ix0) * Cin + chunk * 8;
+                for (int ky = 0; ky < ksz; ++ky)
+                    for (int kx = 0; kx < ksz; ++kx)
+                        if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)W)
+                            mask |= 1u << (ky * ksz + kx);
+            }
+            poff[j] = off;
+            pmask[j] = mask;
+        }
+    }
+    int woff[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) woff[j] = (n0 + (tid >> 3) + 32 * j) * K + chunk * 8;
+
+    // K-step cursor (uniform): tap index, channel step inside the tap, tap coordinates
+    int s_tap = kt0 / cpt, s_cc = kt0 - s_tap * cpt;
+    int s_ky = s_tap / ksz, s_kx = s_tap - s_ky * ksz;
+
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * TILE_BYTES;
+        const int tap_off = (s_ky * W + s_kx) * Cin + s_cc * 64;
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+            const bool ok = (pmask[j] >> s_tap) & 1u;
+            const T* src = ok ? gin + (poff[j] + tap_off) : gz + (tid & 7) * 8;
+            if constexpr (DMA) {
+                dma16(src, base + (wave * 8 + 32 * j) * 128);
+            } else {
+                *(uint4*)(base + ((tid >> 3) + 32 * j) * 128 + (tid & 7) * 16) = *(const uint4*)src;
+            }
+        }
+        char* wbase = base + BM * 128;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const T* src = gw + (woff[j] + kt * 64);
+            if constexpr (DMA) {
+                dma16(src, wbase + (wave * 8 + 32 * j) * 128);
+            } else {
+                *(uint4*)(wbase + ((tid >> 3) + 32 * j) * 128 + (tid & 7) * 16) = *(const uint4*)src;
+            }
+        }
+        // advance the cursor to the next K-step
+        if (++s_cc == cpt) {
+            s_cc = 0;
+            ++s_tap;
+            if (++s_kx == ksz) { s_kx = 0; ++s_ky; }
+        }
+    };
+
+    // ---- fragment addressing: lane (q = lane>>4, lr = lane&15) reads row (tile*16 + lr), logical
+    // chunk 4*ksub + q, at position chunk ^ ((row>>1)&7) == chunk ^ (lr>>1)
+    const int q = lane >> 4, lr = lane & 15;
+    const int sw = lr >> 1;
+    const int foff0 = lr * 128 + (((0 | q) ^ sw) << 4);
+    const int foff1 = lr * 128 + (((4 | q) ^ sw) << 4);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (kt0 < kt1) {
+        stage(0, kt0);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
+            const char* pb = smem + cur * TILE_BYTES + (wp * 64) * 128;
+            const char* wb = smem + cur * TILE_BYTES + (BM + wc * 64) * 128;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int fo = ks ? foff1 : foff0;
+                vec8 wf[4], pf[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wf[t] = *(const vec8*)(wb + t * 2048 + fo);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pf[u] = *(const vec8*)(pb + u * 2048 + fo);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[t][u] = mfma16<T>(wf[t], pf[u], acc[t][u]);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane holds, for pixel (u*16 + lr), channels cbase + 4t + j  (16 consecutive) -
+    const int cbase = n0 + wc * 64 + 16 * q;
+    if (p.splitk > 1) {
+        float* slab = (float*)p.out + (size_t)split * p.M * p.Cout;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = m0 + wp * 64 + 16 * u + lr;
+            if (m < p.M) {
+                float* o = slab + (size_t)m * p.Cout + cbase;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) *(f32x4*)(o + 4 * t) = acc[t][u];
+            }
+        }
+        return;
+    }
+
+    float al[16];
+    if (p.alpha) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 a4 = *(const f32x4*)(p.alpha + cbase + 4 * t);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) al[4 * t + j] = a4[j];
+        }
+    }
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int m = m0 + wp * 64 + 16 * u + lr;
+        if (m >= p.M) continue;
+        int cls = 0;
+        if (p.border_cls) {
+            const int rem = m % HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int rc = (oy == 0) ? 0 : ((oy == p.Ho - 1) ? 2 : 1);
+            const int cc = (ox == 0) ? 0 : ((ox == p.Wo - 1) ? 2 : 1);
+            cls = rc * 3 + cc;
+        }
+        const float* bp = p.bias + cls * p.Cout + cbase;
+        float v[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 b4 = *(const f32x4*)(bp + 4 * t);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * t + j] = acc[t][u][j] + b4[j];
+        }
+        if (p.alpha) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * al[i];
+        }
+        const size_t o = (size_t)m * p.Cout + cbase;
+        if (p.resid) {
+            const vec8 r0 = *(const vec8*)((const T*)p.resid + o);
+            const vec8 r1 = *(const vec8*)((const T*)p.resid + o + 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] += (float)r0[i];
+                v[8 + i] += (float)r1[i];
+            }
+        }
+        vec8 o0, o1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            o0[i] = (T)v[i];
+            o1[i] = (T)v[8 + i];
+        }
+        *(vec8*)((T*)p.out + o) = o0;
+        *(vec8*)((T*)p.out + o + 8) = o1;
+    }
+}
+
+template <typename T, int WP, int WC, bool DMA>
+hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
+    constexpr int BM = WP * 64, BN = WC * 64;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+    const int ntm = (p.M + BM - 1) / BM, ntn = p.Cout / BN;
+    dim3 grid(ntm * ntn, p.splitk, 1), block(256, 1, 1);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WP, WC, DMA>), grid, block, lds, stream, p);
+    return hipGetLastError();
+}
+
+template <typename T, int WP, int WC, bool DMA>
+hipError_t set_attr_one() {
+    constexpr size_t lds = 2 * (size_t)(WP * 64 + WC * 64) * 128;
+    return hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WP, WC, DMA>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+bool g_use_dma = true;
+
+}  // namespace
+
+// test hook: 0 = register staging (global_load -> ds_write), 1 = LDS-DMA (default)
+extern "C" void alink_debug_set_dma(int on) { g_use_dma = on != 0; }
+
+hipError_t conv_set_attributes() {
+    hipError_t e;
+#define A(T, WP, WC)                                                    \
+    if ((e = set_attr_one<T, WP, WC, true>()) != hipSuccess) return e;  \
+    if ((e = set_attr_one<T, WP, WC, false>()) != hipSuccess) return e;
+    A(__bf16, 4, 1) A(__bf16, 2, 2) A(_Float16, 4, 1) A(_Float16, 2, 2)
+#undef A
+    return hipSuccess;
+}
+
+double conv_flops(const ConvParams& p) {
+    return 2.0 * (double)p.M * (double)p.Cout * (double)(p.ksz * p.ksz * p.Cin);
+}
+
+hipError_t launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t stream) {
+    // host-side shape contract of the kernel (checked by callers too; never launch out of contract)
+    if (p.Cin % 64 || p.Cout % 64 || p.M <= 0 || p.splitk < 1) return hipErrorInvalidValue;
+    if (p.ksz * p.ksz > 32) return hipErrorInvalidValue;  // tap mask is 32 bits
+    if ((long long)p.N * p.H * p.W * p.Cin >= (1ll << 31)) return hipErrorInvalidValue;
+    if ((long long)p.Cout * p.ksz * p.ksz * p.Cin >= (1ll << 31)) return hipErrorInvalidValue;
+    const bool wide = (p.Cout % 128) == 0;
+#define L(T)                                                                          \
+    (wide ? (g_use_dma ? launch_one<T, 2, 2, true>(p, stream)                         \
+                       : launch_one<T, 2, 2, false>(p, stream))                       \
+          : (g_use_dma ? launch_one<T, 4, 1, true>(p, stream)                         \
+                       : launch_one<T, 4, 1, false>(p, stream)))
+    if (dtype == ALINK_DT_BF16) return L(__bf16);
+    if (dtype == ALINK_DT_F16) return L(_Float16);
+#undef L
+    return hipErrorInvalidValue;
+}
+
+}  // namespace alink

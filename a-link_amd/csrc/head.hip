@@ -1,0 +1,567 @@
+// head.hip — the siamese pair scorer and its fine-tune step.
+//
+// Replaces the Keras graph built at reference code/siamese.py:24-35
+//     L1 = abs(left - right); Dense(h1, relu); Dense(h2, relu); Dense(2); softmax
+//     compile(loss="binary_crossentropy", optimizer=Adadelta(lr), metrics=['accuracy'])
+// and the calls made on it: predict (code/siamese.py:130-131), fit/train_on_batch/test_on_batch
+// (code/siamese.py:57,103,107) and the committee mean (code/committee.py:13-20).
+//
+// Everything is f32.  The large-P forward runs on the f32-input matrix cores
+// (v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fmaf chain, so results match a CPU f32 matmul
+// to rounding).  Pairs are gathered by index straight from the embedding matrices (row = 2 KB at
+// D = 512, fully coalesced), so the N^2 score-matrix workload (utilities/generateMatrixDFW.py:25-36)
+// never materialises pair tensors.  The fine-tune step works on Keras-sized batches (16 rows):
+// latency-bound, so it is a short chain of plain VALU kernels, gradients kept in one flat buffer
+// for the data-parallel all-reduce.
+//
+// Keras 2.1.2 semantics restated (SURVEY.md §8c "files a CPU restatement must follow"):
+//   binary_crossentropy: p clipped to [1e-7, 1-1e-7], converted to a logit, sigmoid CE on it, mean
+//   over the 2 outputs; sample-weighted batch loss = mean(w*l) / mean(w != 0); 'accuracy' resolves
+//   to binary_accuracy = mean(round(p) == y) (round half to even), not weighted;
+//   Adadelta: a = rho*a + (1-rho)*g^2; u = g*sqrt(d+eps)/sqrt(a+eps); p -= lr*u; d = rho*d+(1-rho)*u^2.
+#include "alink_common.h"
+
+#include <vector>
+
+using namespace alink;
+
+struct alink_head {
+    int D, h1, h2;
+    float lr, rho, eps;
+    size_t nparams;
+    size_t oW1, ob1, oW2, ob2, oW3, ob3;
+    float* d_params = nullptr;   // Keras layout: kernel (in,out) row-major, bias; per layer
+    float* d_grads = nullptr;
+    float* d_acc = nullptr;      // Adadelta accumulators
+    float* d_dacc = nullptr;     // Adadelta delta accumulators
+    float* d_w1p = nullptr;      // W1 packed for the MFMA forward: [D/8][h1][2][4]
+    float* d_w2p = nullptr;      // W2 packed: [h1/8][h2][2][4]
+    bool packed_dirty = true;
+    // train/eval scratch for up to `cap` rows
+    int cap = 4096;
+    float *d_dm = nullptr, *d_z1 = nullptr, *d_z2 = nullptr, *d_dz1 = nullptr, *d_dz2 = nullptr,
+          *d_dz3 = nullptr, *d_p = nullptr;
+    std::vector<void*> allocs;
+    ~alink_head() { for (void* p : allocs) (void)hipFree(p); }
+};
+
+namespace {
+
+constexpr int TP = 32;          // pairs per workgroup in the MFMA forward
+constexpr int ROWP = TP * 8 + 4;  // floats per k8 block in LDS (pad 4: conflict-free b128 writes)
+constexpr int KC = 512;         // K chunk staged per pass
+
+struct HeadFwd {
+    const float *L, *R;
+    const int32_t *li, *ri;
+    long long P;
+    const float *w1p, *b1, *w2p, *b2, *w3, *b3;
+    float* probs;
+    int D, h1, h2;
+    int accumulate;     // add to probs already there (committee member > 0)
+    float final_div;    // > 0: divide by it after adding (last committee member)
+};
+
+// out-of-place repack W (in,out) row-major -> [in/8][out][2][4]:  k = 8*k8 + 2*s + h
+__global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int in, int out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)in * out) return;
+    const int k = (int)(i / out), c = (int)(i - (long long)k * out);
+    const int k8 = k >> 3, kk = k & 7, h = kk & 1, s = kk >> 1;
+    wp[((size_t)k8 * out + c) * 8 + h * 4 + s] = w[i];
+}
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void head_fwd_kernel(const HeadFwd p) {
+    extern __shared__ __attribute__((aligned(16))) float buf[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long p0 = (long long)blockIdx.x * TP;
+    const int D = p.D, h1 = p.h1, h2 = p.h2;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int colbase = wave * (32 * CT);
+
+    f32x16 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+
+    for (int k0 = 0; k0 < D; k0 += KC) {
+        const int kc = min(KC, D - k0), nk8 = kc >> 3;
+        __syncthreads();
+        for (int idx = tid; idx < TP * nk8; idx += 256) {
+            const int row = idx / nk8, k8 = idx - row * nk8;
+            long long pp = p0 + row;
+            if (pp >= p.P) pp = p.P - 1;
+            const long long lrow = p.li ? (long long)p.li[pp] : pp;
+            const long long rrow = p.ri ? (long long)p.ri[pp] : pp;
+            const float* lp = p.L + lrow * D + k0 + k8 * 8;
+            const float* rp = p.R + rrow * D + k0 + k8 * 8;
+            const f32x4 l0 = *(const f32x4*)lp, l1 = *(const f32x4*)(lp + 4);
+            const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+            f32x4 e, o;   // even k (h = 0) and odd k (h = 1), s = 0..3
+            e[0] = fabsf(l0[0] - r0[0]); o[0] = fabsf(l0[1] - r0[1]);
+            e[1] = fabsf(l0[2] - r0[2]); o[1] = fabsf(l0[3] - r0[3]);
+            e[2] = fabsf(l1[0] - r1[0]); o[2] = fabsf(l1[1] - r1[1]);
+            e[3] = fabsf(l1[2] - r1[2]); o[3] = fabsf(l1[3] - r1[3]);
+            float* d = buf + k8 * ROWP + row * 8;
+            *(f32x4*)d = e;
+            *(f32x4*)(d + 4) = o;
+        }
+        __syncthreads();
+        const float* wbase = p.w1p + ((size_t)(k0 >> 3) * h1 + colbase + l31) * 8 + hh * 4;
+        for (int k8 = 0; k8 < nk8; ++k8) {
+            const f32x4 a = *(const f32x4*)(buf + k8 * ROWP + l31 * 8 + hh * 4);
+            f32x4 b[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) b[c] = *(const f32x4*)(wbase + ((size_t)k8 * h1 + c * 32) * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[c][s], acc[c], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // A1 = relu(Z1 + b1) -> LDS in the packed A-operand layout of layer 2
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int col = colbase + c * 32 + l31;
+        const float bb = p.b1[col];
+        float* d = buf + (col >> 3) * ROWP + (col & 1) * 4 + ((col & 7) >> 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            d[row * 8] = fmaxf(acc[c][r] + bb, 0.f);
+        }
+    }
+    __syncthreads();
+    // layer 2: wave = (column tile, K split)
+    const int nt2 = h2 >> 5, tile = wave % nt2, ks = wave / nt2, nsplit = 4 / nt2;
+    const int nk8_2 = h1 >> 3, kper = nk8_2 / nsplit;
+    f32x16 acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+    {
+        const float* w2b = p.w2p + ((size_t)tile * 32 + l31) * 8 + hh * 4;
+        for (int k8 = ks * kper; k8 < (ks + 1) * kper; ++k8) {
+            const f32x4 a = *(const f32x4*)(buf + k8 * ROWP + l31 * 8 + hh * 4);
+            const f32x4 b = *(const f32x4*)(w2b + (size_t)k8 * h2 * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc2, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // partials [ks][row][col]
+    {
+        float* part = buf + ks * (TP * h2);
+        const int col = tile * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            part[row * h2 + col] = acc2[r];
+        }
+    }
+    __syncthreads();
+    float* a2 = buf + 4 * TP * 64;      // after the (at most 4 x 32 x 64) partials
+    for (int i = tid; i < TP * h2; i += 256) {
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += buf[z * (TP * h2) + i];
+        a2[i] = fmaxf(s + p.b2[i % h2], 0.f);
+    }
+    __syncthreads();
+    if (tid < 2 * TP) {
+        const int row = tid >> 1, cls = tid & 1;
+        float z = 0.f;
+        for (int c = 0; c < h2; ++c) z = fmaf(a2[row * h2 + c], p.w3[c * 2 + cls], z);
+        z += p.b3[cls];
+        const float zo = __shfl_xor(z, 1, 64);
+        const float m = fmaxf(z, zo);
+        const float e = expf(z - m), eo = expf(zo - m);
+        float pr = e / (e + eo);
+        const long long pp = p0 + row;
+        if (pp < p.P) {
+            float* o = p.probs + pp * 2 + cls;
+            if (p.accumulate) pr += *o;
+            if (p.final_div > 0.f) pr = pr / p.final_div;
+            *o = pr;
+        }
+    }
+}
+
+// ------------------------------- small-batch train / eval kernels --------------------------------
+__global__ void absdiff_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                               float* __restrict__ dm, int n, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n * D) dm[i] = fabsf(L[i] - R[i]);
+}
+
+// z[r][c] = sum_k a[r][k] * w[k][c] + b[c];  one thread per (r, c), c fastest
+__global__ void dense_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                 const float* __restrict__ b, float* __restrict__ z, int n, int K, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * C) return;
+    const int r = i / C, c = i - r * C;
+    const float* ar = a + (size_t)r * K;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) s = fmaf(ar[k], w[(size_t)k * C + c], s);
+    z[i] = s + b[c];
+}
+// same but the input is relu(zin) (the stored pre-activation of the previous layer)
+__global__ void dense_fwd_relu_in_kernel(const float* __restrict__ zin, const float* __restrict__ w,
+                                         const float* __restrict__ b, float* __restrict__ z, int n, int K,
+                                         int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * C) return;
+    const int r = i / C, c = i - r * C;
+    const float* ar = zin + (size_t)r * K;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) s = fmaf(fmaxf(ar[k], 0.f), w[(size_t)k * C + c], s);
+    z[i] = s + b[c];
+}
+
+struct HeadLoss {
+    const float *z2, *w3, *b3, *y, *sw;
+    float *probs, *dz3, *dz2, *gw3, *gb3, *metrics;
+    int n, h2, want_grads;
+    float grad_scale;   // <= 0: 1 / count(sw != 0)
+};
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// One workgroup: layer 3, softmax, Keras BCE + metrics, and (if want_grads) dZ3, dW3, db3, dZ2.
+__global__ __launch_bounds__(256) void head_loss_kernel(const HeadLoss p) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, n = p.n, h2 = p.h2;
+    float cnt = 0.f;
+    for (int i = tid; i < n; i += 256) cnt += (p.sw ? (p.sw[i] != 0.f) : 1.f);
+    cnt = block_sum(cnt, red);
+    const float scale = p.grad_scale > 0.f ? p.grad_scale : 1.f / cnt;
+
+    float lsum = 0.f, asum = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float* a = p.z2 + (size_t)i * h2;
+        float z0 = 0.f, z1 = 0.f;
+        for (int c = 0; c < h2; ++c) {
+            const float v = fmaxf(a[c], 0.f);
+            z0 = fmaf(v, p.w3[c * 2 + 0], z0);
+            z1 = fmaf(v, p.w3[c * 2 + 1], z1);
+        }
+        z0 += p.b3[0];
+        z1 += p.b3[1];
+        const float m = fmaxf(z0, z1);
+        const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+        const float pr[2] = {e0 / (e0 + e1), e1 / (e0 + e1)};
+        p.probs[i * 2 + 0] = pr[0];
+        p.probs[i * 2 + 1] = pr[1];
+        const float w = p.sw ? p.sw[i] : 1.f;
+        float li = 0.f, acc = 0.f, dp[2];
+        for (int c = 0; c < 2; ++c) {
+            const float y = p.y[i * 2 + c];
+            const float pc = fminf(fmaxf(pr[c], 1e-7f), 1.f - 1e-7f);
+            const float x = logf(pc / (1.f - pc));
+            li += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+            acc += (rintf(pr[c]) == y) ? 1.f : 0.f;
+            const bool inside = pr[c] >= 1e-7f && pr[c] <= 1.f - 1e-7f;
+            // d/dp of BCE(y, clip(p)) through logit + sigmoid CE = (pc - y) / (pc (1 - pc))
+            dp[c] = inside ? 0.5f * w * scale * (pc - y) / (pc * (1.f - pc)) : 0.f;
+        }
+        lsum += 0.5f * li * w;
+        asum += 0.5f * acc;
+        if (p.want_grads) {
+            // through softmax: dz_j = p_j * (dp_j - sum_c dp_c p_c)
+            const float dot = dp[0] * pr[0] + dp[1] * pr[1];
+            p.dz3[i * 2 + 0] = pr[0] * (dp[0] - dot);
+            p.dz3[i * 2 + 1] = pr[1] * (dp[1] - dot);
+        }
+    }
+    lsum = block_sum(lsum, red);
+    asum = block_sum(asum, red);
+    if (tid == 0) {
+        p.metrics[0] = lsum * (p.grad_scale > 0.f ? p.grad_scale : 1.f / cnt);
+        p.metrics[1] = asum / (float)n;
+    }
+    if (!p.want_grads) return;
+    __syncthreads();   // dz3 written by this block (global, same block -> visible after barrier)
+    // dW3[c][j] = sum_i relu(z2[i][c]) * dz3[i][j];  db3[j] = sum_i dz3[i][j]
+    for (int t = tid; t < h2 * 2 + 2; t += 256) {
+        float s = 0.f;
+        if (t < h2 * 2) {
+            const int c = t >> 1, j = t & 1;
+            for (int i = 0; i < n; ++i) s = fmaf(fmaxf(p.z2[(size_t)i * h2 + c], 0.f), p.dz3[i * 2 + j], s);
+            p.gw3[t] = s;
+        } else {
+            const int j = t - h2 * 2;
+            for (int i = 0; i < n; ++i) s += p.dz3[i * 2 + j];
+            p.gb3[j] = s;
+        }
+    }
+    // dZ2[i][c] = (z2 > 0) * sum_j dz3[i][j] * w3[c][j]
+    for (int t = tid; t < n * h2; t += 256) {
+        const int i = t / h2, c = t - i * h2;
+        const float g = p.dz3[i * 2] * p.w3[c * 2] + p.dz3[i * 2 + 1] * p.w3[c * 2 + 1];
+        p.dz2[t] = p.z2[t] > 0.f ? g : 0.f;
+    }
+}
+
+// gw[k][c] = sum_i act(a[i][k]) * dz[i][c];  gb[c] = sum_i dz[i][c]   (blockIdx.y == 0 part)
+// relu_a: a holds pre-activations, use relu(a)
+__global__ void dense_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ dz,
+                                   float* __restrict__ gw, float* __restrict__ gb, int n, int K, int C,
+                                   int relu_a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < K * C) {
+        const int k = i / C, c = i - k * C;
+        float s = 0.f;
+        for (int r = 0; r < n; ++r) {
+            float av = a[(size_t)r * K + k];
+            if (relu_a) av = fmaxf(av, 0.f);
+            s = fmaf(av, dz[(size_t)r * C + c], s);
+        }
+        gw[i] = s;
+    } else if (i < K * C + C) {
+        const int c = i - K * C;
+        float s = 0.f;
+        for (int r = 0; r < n; ++r) s += dz[(size_t)r * C + c];
+        gb[c] = s;
+    }
+}
+// dzin[r][k] = (zin[r][k] > 0) * sum_c dz[r][c] * w[k][c]
+__global__ void dense_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                   const float* __restrict__ zin, float* __restrict__ dzin, int n, int K,
+                                   int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * K) return;
+    const int r = i / K, k = i - r * K;
+    const float* wr = w + (size_t)k * C;
+    const float* dr = dz + (size_t)r * C;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(dr[c], wr[c], s);
+    dzin[i] = zin[i] > 0.f ? s : 0.f;
+}
+
+__global__ void adadelta_kernel(float* __restrict__ prm, const float* __restrict__ g, float* __restrict__ a,
+                                float* __restrict__ d, size_t n, float lr, float rho, float eps) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float na = rho * a[i] + (1.f - rho) * gi * gi;
+    const float u = gi * sqrtf(d[i] + eps) / sqrtf(na + eps);
+    prm[i] = prm[i] - lr * u;
+    d[i] = rho * d[i] + (1.f - rho) * u * u;
+    a[i] = na;
+}
+
+inline dim3 g1(long long n) { return dim3((unsigned)((n + 255) / 256), 1, 1); }
+
+int head_alloc(alink_head* h, float** p, size_t count) {
+    ALINK_HIP(hipMalloc((void**)p, count * sizeof(float)));
+    h->allocs.push_back(*p);
+    ALINK_HIP(hipMemset(*p, 0, count * sizeof(float)));
+    return ALINK_OK;
+}
+
+int ensure_packed(alink_head* h, hipStream_t st) {
+    if (!h->packed_dirty) return ALINK_OK;
+    hipLaunchKernelGGL(pack_kernel, g1((long long)h->D * h->h1), dim3(256), 0, st, h->d_params + h->oW1,
+                       h->d_w1p, h->D, h->h1);
+    hipLaunchKernelGGL(pack_kernel, g1((long long)h->h1 * h->h2), dim3(256), 0, st, h->d_params + h->oW2,
+                       h->d_w2p, h->h1, h->h2);
+    ALINK_HIP(hipGetLastError());
+    h->packed_dirty = false;
+    return ALINK_OK;
+}
+
+size_t fwd_lds_bytes(int h1) {
+    const size_t a = (size_t)(KC / 8) * ROWP, b = (size_t)(h1 / 8) * ROWP, c = 4 * TP * 64 + TP * 64;
+    size_t m = a > b ? a : b;
+    if (c > m) m = c;
+    return m * sizeof(float);
+}
+
+int launch_fwd(alink_head* h, const float* L, const float* R, const int32_t* li, const int32_t* ri,
+               long long P, float* probs, int accumulate, float final_div, hipStream_t st) {
+    int rc = ensure_packed(h, st);
+    if (rc) return rc;
+    HeadFwd p{};
+    p.L = L; p.R = R; p.li = li; p.ri = ri; p.P = P;
+    p.w1p = h->d_w1p; p.b1 = h->d_params + h->ob1; p.w2p = h->d_w2p; p.b2 = h->d_params + h->ob2;
+    p.w3 = h->d_params + h->oW3; p.b3 = h->d_params + h->ob3; p.probs = probs;
+    p.D = h->D; p.h1 = h->h1; p.h2 = h->h2; p.accumulate = accumulate; p.final_div = final_div;
+    const size_t lds = fwd_lds_bytes(h->h1);
+    const dim3 grid((unsigned)((P + TP - 1) / TP)), block(256);
+    switch (h->h1 / 128) {
+        case 1: hipLaunchKernelGGL(head_fwd_kernel<1>, grid, block, lds, st, p); break;
+        case 2: hipLaunchKernelGGL(head_fwd_kernel<2>, grid, block, lds, st, p); break;
+        case 3: hipLaunchKernelGGL(head_fwd_kernel<3>, grid, block, lds, st, p); break;
+        case 4: hipLaunchKernelGGL(head_fwd_kernel<4>, grid, block, lds, st, p); break;
+        default: set_error("h1=%d unsupported", h->h1); return ALINK_EINVAL;
+    }
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+// forward (+ optional backward) on a small batch with the VALU kernels
+int small_pass(alink_head* h, const float* L, const float* R, const float* y, const float* sw, int n,
+               float grad_scale, bool want_grads, float* metrics, hipStream_t st) {
+    ALINK_REQUIRE(n > 0 && n <= h->cap, ALINK_EINVAL, "batch of %d rows outside 1..%d", n, h->cap);
+    const int D = h->D, h1 = h->h1, h2 = h->h2;
+    float* P = h->d_params;
+    float* G = h->d_grads;
+    hipLaunchKernelGGL(absdiff_kernel, g1((long long)n * D), dim3(256), 0, st, L, R, h->d_dm, n, D);
+    hipLaunchKernelGGL(dense_fwd_kernel, g1((long long)n * h1), dim3(256), 0, st, h->d_dm, P + h->oW1,
+                       P + h->ob1, h->d_z1, n, D, h1);
+    hipLaunchKernelGGL(dense_fwd_relu_in_kernel, g1((long long)n * h2), dim3(256), 0, st, h->d_z1, P + h->oW2,
+                       P + h->ob2, h->d_z2, n, h1, h2);
+    HeadLoss lp{};
+    lp.z2 = h->d_z2; lp.w3 = P + h->oW3; lp.b3 = P + h->ob3; lp.y = y; lp.sw = sw; lp.probs = h->d_p;
+    lp.dz3 = h->d_dz3; lp.dz2 = h->d_dz2; lp.gw3 = G + h->oW3; lp.gb3 = G + h->ob3; lp.metrics = metrics;
+    lp.n = n; lp.h2 = h2; lp.want_grads = want_grads ? 1 : 0; lp.grad_scale = grad_scale;
+    hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(256), 0, st, lp);
+    if (want_grads) {
+        hipLaunchKernelGGL(dense_wgrad_kernel, g1((long long)h1 * h2 + h2), dim3(256), 0, st, h->d_z1, h->d_dz2,
+                           G + h->oW2, G + h->ob2, n, h1, h2, 1);
+        hipLaunchKernelGGL(dense_dgrad_kernel, g1((long long)n * h1), dim3(256), 0, st, h->d_dz2, P + h->oW2,
+                           h->d_z1, h->d_dz1, n, h1, h2);
+        hipLaunchKernelGGL(dense_wgrad_kernel, g1((long long)D * h1 + h1), dim3(256), 0, st, h->d_dm, h->d_dz1,
+                           G + h->oW1, G + h->ob1, n, D, h1, 0);
+    }
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+bool g_head_attr_done = false;
+int head_init_attrs() {
+    if (g_head_attr_done) return ALINK_OK;
+    const int lds = (int)fwd_lds_bytes(512);
+    ALINK_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    ALINK_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    ALINK_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    ALINK_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    g_head_attr_done = true;
+    return ALINK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+alink_head_t* alink_head_create(int d_in, int h1, int h2, float lr, float rho, float eps) {
+    if (d_in <= 0 || d_in % 8) { set_error("d_in=%d must be a positive multiple of 8", d_in); return nullptr; }
+    if (h1 < 128 || h1 > 512 || h1 % 128) { set_error("h1=%d must be 128, 256, 384 or 512", h1); return nullptr; }
+    if (h2 != 32 && h2 != 64) { set_error("h2=%d must be 32 or 64", h2); return nullptr; }
+    if (head_init_attrs()) return nullptr;
+    alink_head* h = new alink_head();
+    h->D = d_in; h->h1 = h1; h->h2 = h2; h->lr = lr; h->rho = rho; h->eps = eps;
+    h->oW1 = 0; h->ob1 = (size_t)d_in * h1; h->oW2 = h->ob1 + h1; h->ob2 = h->oW2 + (size_t)h1 * h2;
+    h->oW3 = h->ob2 + h2; h->ob3 = h->oW3 + (size_t)h2 * 2; h->nparams = h->ob3 + 2;
+    int rc = 0;
+    rc |= head_alloc(h, &h->d_params, h->nparams);
+    rc |= head_alloc(h, &h->d_grads, h->nparams);
+    rc |= head_alloc(h, &h->d_acc, h->nparams);
+    rc |= head_alloc(h, &h->d_dacc, h->nparams);
+    rc |= head_alloc(h, &h->d_w1p, (size_t)d_in * h1);
+    rc |= head_alloc(h, &h->d_w2p, (size_t)h1 * h2);
+    rc |= head_alloc(h, &h->d_dm, (size_t)h->cap * d_in);
+    rc |= head_alloc(h, &h->d_z1, (size_t)h->cap * h1);
+    rc |= head_alloc(h, &h->d_dz1, (size_t)h->cap * h1);
+    rc |= head_alloc(h, &h->d_z2, (size_t)h->cap * h2);
+    rc |= head_alloc(h, &h->d_dz2, (size_t)h->cap * h2);
+    rc |= head_alloc(h, &h->d_dz3, (size_t)h->cap * 2);
+    rc |= head_alloc(h, &h->d_p, (size_t)h->cap * 2);
+    if (rc) { delete h; return nullptr; }
+    return h;
+}
+
+void alink_head_destroy(alink_head_t* h) { delete h; }
+size_t alink_head_num_params(const alink_head_t* h) { return h ? h->nparams : 0; }
+
+int alink_head_set_params(alink_head_t* h, const float* host_params, size_t count) {
+    ALINK_REQUIRE(h && host_params, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(count == h->nparams, ALINK_EINVAL, "expected %zu parameters, got %zu", h->nparams, count);
+    ALINK_HIP(hipMemcpy(h->d_params, host_params, count * sizeof(float), hipMemcpyHostToDevice));
+    h->packed_dirty = true;
+    return ALINK_OK;
+}
+int alink_head_get_params(const alink_head_t* h, float* host_params, size_t count) {
+    ALINK_REQUIRE(h && host_params, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(count == h->nparams, ALINK_EINVAL, "expected %zu parameters, got %zu", h->nparams, count);
+    ALINK_HIP(hipDeviceSynchronize());
+    ALINK_HIP(hipMemcpy(host_params, h->d_params, count * sizeof(float), hipMemcpyDeviceToHost));
+    return ALINK_OK;
+}
+int alink_head_reset_optimizer(alink_head_t* h) {
+    ALINK_REQUIRE(h, ALINK_EINVAL, "NULL head");
+    ALINK_HIP(hipMemset(h->d_acc, 0, h->nparams * sizeof(float)));
+    ALINK_HIP(hipMemset(h->d_dacc, 0, h->nparams * sizeof(float)));
+    return ALINK_OK;
+}
+int alink_head_set_lr(alink_head_t* h, float lr) {
+    ALINK_REQUIRE(h && lr >= 0.f, ALINK_EINVAL, "bad lr");
+    h->lr = lr;
+    return ALINK_OK;
+}
+float alink_head_get_lr(const alink_head_t* h) { return h ? h->lr : 0.f; }
+float* alink_head_params_dev(alink_head_t* h) { return h ? h->d_params : nullptr; }
+float* alink_head_grads_dev(alink_head_t* h) { return h ? h->d_grads : nullptr; }
+
+int alink_head_forward(alink_head_t* h, const float* dev_L, const float* dev_R, const int32_t* dev_li,
+                       const int32_t* dev_ri, int64_t P, float* dev_probs, void* stream) {
+    ALINK_REQUIRE(h && dev_L && dev_R && dev_probs, ALINK_EINVAL, "NULL argument");
+    if (P == 0) return ALINK_OK;
+    ALINK_REQUIRE(P > 0, ALINK_EINVAL, "negative pair count");
+    return launch_fwd(h, dev_L, dev_R, dev_li, dev_ri, P, dev_probs, 0, 0.f, (hipStream_t)stream);
+}
+
+int alink_committee_forward(alink_head_t* const* heads, int n_heads, const float* dev_L, const float* dev_R,
+                            const int32_t* dev_li, const int32_t* dev_ri, int64_t P, float* dev_probs,
+                            void* dev_scratch, void* stream) {
+    (void)dev_scratch;
+    ALINK_REQUIRE(heads && n_heads > 0 && dev_L && dev_R && dev_probs, ALINK_EINVAL, "bad argument");
+    if (P == 0) return ALINK_OK;
+    for (int m = 0; m < n_heads; ++m) {
+        ALINK_REQUIRE(heads[m], ALINK_EINVAL, "NULL committee member %d", m);
+        // np.sum over members then / len(models) (code/committee.py:18): sequential f32 adds, one divide
+        const int rc = launch_fwd(heads[m], dev_L, dev_R, dev_li, dev_ri, P, dev_probs, m > 0,
+                                  m == n_heads - 1 ? (float)n_heads : 0.f, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return ALINK_OK;
+}
+
+int alink_head_train_step(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
+                          const float* dev_sw, int n, float grad_scale, int apply, float* dev_metrics,
+                          void* stream) {
+    ALINK_REQUIRE(h && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
+    int rc = small_pass(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, true, dev_metrics, (hipStream_t)stream);
+    if (rc) return rc;
+    if (apply) return alink_head_apply_update(h, stream);
+    return ALINK_OK;
+}
+
+int alink_head_apply_update(alink_head_t* h, void* stream) {
+    ALINK_REQUIRE(h, ALINK_EINVAL, "NULL head");
+    hipLaunchKernelGGL(adadelta_kernel, g1((long long)h->nparams), dim3(256), 0, (hipStream_t)stream,
+                       h->d_params, h->d_grads, h->d_acc, h->d_dacc, h->nparams, h->lr, h->rho, h->eps);
+    ALINK_HIP(hipGetLastError());
+    h->packed_dirty = true;
+    return ALINK_OK;
+}
+
+int alink_head_eval(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y, int n,
+                    float* dev_metrics, void* stream) {
+    ALINK_REQUIRE(h && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
+    return small_pass(h, dev_L, dev_R, dev_y, nullptr, n, 0.f, false, dev_metrics, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+// stem_tail.hip — the two ends of the IR-ResNet backbone that are not plain implicit GEMMs.
+//
+//  stem   : (x - 127.5) * 0.0078125 -> conv3x3(3->C0, pad 1, no bias) -> BN -> PReLU
+//           (insightface fresnet `conv0/bn0/relu0`; executed inside model.forward at reference
+//           code/face_model.py:90).  Pixels arrive as the reference holds them: float32 RGB
+//           0..255, HWC (code/readDFW.py:82) or CHW after FaceModel.get_input (code/face_model.py:83).
+//  finish : fixed-order reduction of the FC split-K slabs + folded bias, then the L2 row normalise
+//           that the reference does on the host with sklearn (code/face_model.py:92).
+#include "alink_common.h"
+
+namespace alink {
+namespace {
+
+template <typename T> struct Vec8;
+template <> struct Vec8<__bf16>   { typedef bf16x8 type; };
+template <> struct Vec8<_Float16> { typedef f16x8 type; };
+
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16(typename Vec8<T>::type a, typename Vec8<T>::type b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mfma16<__bf16>(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mfma16<_Float16>(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+constexpr int STEM_ROWS = 8;   // output rows per workgroup
+
+// One workgroup = one band of STEM_ROWS output rows of one image.  The (STEM_ROWS+2) input rows are
+// normalised, converted to T and parked in LDS with a zero frame (x = -1, x = W, rows outside the
+// image), so the 3x3x3 patch of a pixel is three runs of 9 consecutive LDS elements.  K = 27 is
+// padded to 32: one MFMA K-step per 16 pixels x 16 channels.  Only C0 = 64 is supported.
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
+    typedef typename Vec8<T>::type vec8;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* tile = (T*)smem_raw;
+
+    const int H = p.H, W = p.W;
+    const int RP = ((W + 2) * 3 + 7) & ~7;          // LDS row pitch in elements
+    const int n = blockIdx.y, y0 = blockIdx.x * STEM_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- stage + normalise the input band ------------------------------------------------------
+    const int row_elems = (W + 2) * 3;
+    const int total = (STEM_ROWS + 2) * row_elems;
+    for (int i = tid; i < total; i += 256) {
+        const int r = i / row_elems, e = i - r * row_elems;
+        int ixp, c;
+        if (LAYOUT == ALINK_LAYOUT_NCHW_F32) { c = e / (W + 2); ixp = e - c * (W + 2); }
+        else                                 { ixp = e / 3;     c = e - ixp * 3; }
+        const int iy = y0 - 1 + r, ix = ixp - 1;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            float px;
+            if (LAYOUT == ALINK_LAYOUT_NHWC_F32)
+                px = ((const float*)p.in)[(((size_t)n * H + iy) * W + ix) * 3 + c];
+            else if (LAYOUT == ALINK_LAYOUT_NCHW_F32)
+                px = ((const float*)p.in)[(((size_t)n * 3 + c) * H + iy) * W + ix];
+            else
+                px = (float)((const uint8_t*)p.in)[(((size_t)n * H + iy) * W + ix) * 3 + c];
+            v = (px - 127.5f) * 0.0078125f;
+        }
+        tile[r * RP + ixp * 3 + c] = (T)v;
+    }
+
+    // ---- per-lane constants ----------------------------------------------------------------------
+    const int q = lane >> 4, lr = lane & 15;
+    // A fragments (weights): tile t, row lr, k = 8q..8q+7  (rows already perm64-permuted on host)
+    vec8 wf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wf[t] = *(const vec8*)((const T*)p.wgt + (16 * t + lr) * 32 + 8 * q);
+    // B fragment gather offsets: k = 8q + j -> (ky = k/9, e = k%9) -> ky*RP + e ; k >= 27 -> zero
+    int koff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * q + j;
+        const int ky = (k * 57) >> 9;               // k / 9 for k < 32
+        koff[j] = (k < 27) ? ky * RP + (k - 9 * ky) : -1;
+    }
+    const int cbase = 16 * q;                       // lane's 16 consecutive channels
+    float bi[16], al[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { bi[i] = p.bias[cbase + i]; al[i] = p.alpha[cbase + i]; }
+
+    __syncthreads();
+
+    const int tpr = (W + 15) >> 4;                  // 16-pixel tiles per row
+    const int ntiles = STEM_ROWS * tpr;
+    for (int tl = wave; tl < ntiles; tl += 4) {
+        const int ry = tl / tpr, xt = tl - ry * tpr;
+        const int y = y0 + ry;
+        const int x = xt * 16 + lr;
+        const int xc = x < W ? x : W - 1;           // clamp: keep LDS reads in bounds, skip the store
+        const T* base = tile + ry * RP + xc * 3;
+        vec8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = koff[j] >= 0 ? base[koff[j]] : (T)0.f;
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16<T>(wf[t], pf, f32x4{0.f, 0.f, 0.f, 0.f});
+        if (y < H && x < W) {
+            vec8 o0, o1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * t + j;
+                    float v = acc[t][j] + bi[i];
+                    v = v > 0.f ? v : v * al[i];
+                    if (i < 8) o0[i] = (T)v; else o1[i - 8] = (T)v;
+                }
+            T* o = (T*)p.out + (((size_t)n * H + y) * W + x) * 64 + cbase;
+            *(vec8*)o = o0;
+            *(vec8*)(o + 8) = o1;
+        }
+    }
+}
+
+// One wave per embedding row: sum the split-K slabs in slab order (bit-reproducible), add the folded
+// bias, L2-normalise with sklearn.preprocessing.normalize semantics (zero norm -> divide by 1).
+__global__ __launch_bounds__(256) void fc_finish_kernel(const FcFinishParams p) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= p.M) return;
+    const int E = p.E;
+    float ss = 0.f;
+    // E is a multiple of 64: lane owns columns lane*4 + 256*i .. +3
+    for (int c0 = lane * 4; c0 < E; c0 += 256) {
+        f32x4 s = *(const f32x4*)(p.bias + c0);
+        // bias first then slabs would change rounding vs "sum then bias"; keep sum-then-bias
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < p.S; ++z) a += *(const f32x4*)(p.slabs + ((size_t)z * p.M + m) * E + c0);
+        a += s;
+        *(f32x4*)(p.out + (size_t)m * E + c0) = a;
+        ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    float nrm = sqrtf(ss);
+    if (nrm == 0.f) nrm = 1.f;
+    for (int c0 = lane * 4; c0 < E; c0 += 256) {
+        f32x4 a = *(f32x4*)(p.out + (size_t)m * E + c0);
+        a[0] /= nrm; a[1] /= nrm; a[2] /= nrm; a[3] /= nrm;
+        *(f32x4*)(p.out + (size_t)m * E + c0) = a;
+    }
+}
+
+template <typename T>
+hipError_t launch_stem_t(const StemParams& p, hipStream_t stream) {
+    const int RP = ((p.W + 2) * 3 + 7) & ~7;
+    const size_t lds = (size_t)(STEM_ROWS + 2) * RP * sizeof(T);
+    dim3 grid((p.H + STEM_ROWS - 1) / STEM_ROWS, p.N, 1), block(256, 1, 1);
+    switch (p.layout) {
+        case ALINK_LAYOUT_NHWC_F32:
+            hipLaunchKernelGGL((stem_kernel<T, ALINK_LAYOUT_NHWC_F32>), grid, block, lds, stream, p); break;
+        case ALINK_LAYOUT_NCHW_F32:
+            hipLaunchKernelGGL((stem_kernel<T, ALINK_LAYOUT_NCHW_F32>), grid, block, lds, stream, p); break;
+        case ALINK_LAYOUT_NHWC_U8:
+            hipLaunchKernelGGL((stem_kernel<T, ALINK_LAYOUT_NHWC_U8>), grid, block, lds, stream, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_stem(int dtype, const StemParams& p, hipStream_t stream) {
+    if (p.C0 != 64 || p.N <= 0 || p.W < 2 || p.H < 1) return hipErrorInvalidValue;
+    if ((size_t)(STEM_ROWS + 2) * (((p.W + 2) * 3 + 7) & ~7) * 2 > 60000) return hipErrorInvalidValue;
+    if (dtype == ALINK_DT_BF16) return launch_stem_t<__bf16>(p, stream);
+    if (dtype == ALINK_DT_F16) return launch_stem_t<_Float16>(p, stream);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_fc_finish(const FcFinishParams& p, hipStream_t stream) {
+    if (p.E % 64 || p.M <= 0 || p.S < 1) return hipErrorInvalidValue;
+    dim3 grid((p.M + 3) / 4, 1, 1), block(256, 1, 1);
+    hipLaunchKernelGGL(fc_finish_kernel, grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace alink

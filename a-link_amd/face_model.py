@@ -1,0 +1,52 @@
+"""face_model — drop-in for reference code/face_model.py (hot path only).
+
+    get_model(ctx, image_size, model_str, layer)   code/face_model.py:28-41
+    FaceModel(args)                                code/face_model.py:43-57
+    FaceModel.get_input(face_img)                  code/face_model.py:70-84  (HWC -> CHW only)
+    FaceModel.get_feature(aligned)                 code/face_model.py:86-93  (forward + L2 normalise)
+
+Differences, all deliberate: the executor is batched (`get_features`), the checkpoint is an .npz
+with MXNet tensor names (or `synthetic:<arch>`), and the MTCNN detector / gender-age model that the
+reference constructs but never uses (code/face_model.py:52-67,95-107) are not built.
+"""
+import numpy as np
+
+from . import weights as W
+from .backbone import IRBackbone
+
+
+def get_model(ctx, image_size, model_str, layer, dtype="bf16", max_batch=256):
+    assert layer == "fc1", "the reference slices the symbol at fc1_output (code/face_model.py:36,53)"
+    params = W.resolve_model(model_str, image_size)
+    device = ctx if isinstance(ctx, int) else 0
+    return IRBackbone(params, image_size=image_size, dtype=dtype, device=device, max_batch=max_batch)
+
+
+class FaceModel(object):
+    def __init__(self, args):
+        self.args = args
+        _vec = args.image_size.split(',')
+        assert len(_vec) == 2
+        image_size = (int(_vec[0]), int(_vec[1]))
+        self.model = None
+        self.ga_model = None
+        if len(args.model) > 0:
+            self.model = get_model(getattr(args, "gpu", 0), image_size, args.model, 'fc1',
+                                   dtype=getattr(args, "dtype", "bf16"),
+                                   max_batch=getattr(args, "max_batch", 256))
+        self.threshold = args.threshold
+        self.det_minsize = 50
+        self.det_threshold = [0.6, 0.7, 0.8]
+        self.image_size = image_size
+
+    def get_input(self, face_img):
+        return np.transpose(face_img, (2, 0, 1))
+
+    def get_feature(self, aligned):
+        """(3,H,W) float RGB 0..255 -> (emb,) float32, unit L2 norm."""
+        blob = np.expand_dims(np.asarray(aligned, dtype=np.float32), axis=0)
+        return self.model.embed(blob).flatten()
+
+    def get_features(self, images):
+        """Batched extension: (N,H,W,3) or (N,3,H,W) -> (N, emb).  Same arithmetic per image."""
+        return self.model.embed(images)

@@ -1,0 +1,301 @@
+"""DenseHead — the siamese pair scorer on the GPU, with the slice of the Keras `Model` API the
+reference calls on `SiameseNetwork.siamese_net` (reference code/siamese.py:33-35,57,103,107,116,123,131):
+predict / fit / train_on_batch / test_on_batch / get_weights / set_weights / save_weights / load_weights.
+
+All arithmetic happens in libalink_hip.so (head.hip); this file is the Keras-2.1.2 control flow:
+validation_split (last 20 % held out BEFORE shuffling), np.random.shuffle of the index array per
+epoch, batch-size-weighted epoch means, class_weight -> sample weights, EarlyStopping /
+ReduceLROnPlateau bookkeeping.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+def glorot_uniform(rng, fan_in, fan_out):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, (fan_in, fan_out)).astype(np.float32)
+
+
+def to_categorical(y, num_classes=2):
+    """keras.utils.to_categorical (reference code/siamese.py:56,100-101)."""
+    y = np.asarray(y, dtype="int").ravel()
+    out = np.zeros((y.shape[0], num_classes), dtype=np.float32)
+    out[np.arange(y.shape[0]), y] = 1.0
+    return out
+
+
+class EarlyStopping(object):
+    """keras.callbacks.EarlyStopping (2.1.2) for a monitored quantity that should decrease."""
+
+    def __init__(self, monitor="val_loss", min_delta=0.0, patience=0, verbose=0):
+        self.monitor, self.patience, self.verbose = monitor, patience, verbose
+        self.min_delta = -abs(min_delta)
+        self.wait, self.best, self.stopped_epoch = 0, np.inf, 0
+
+    def on_epoch_end(self, epoch, logs, model):
+        current = logs.get(self.monitor)
+        if current is None:
+            return
+        if np.less(current - self.min_delta, self.best):
+            self.best, self.wait = current, 0
+        else:
+            self.wait += 1
+            if self.wait >= self.patience:
+                self.stopped_epoch = epoch
+                model.stop_training = True
+
+
+class ReduceLROnPlateau(object):
+    """keras.callbacks.ReduceLROnPlateau (2.1.2), mode min."""
+
+    def __init__(self, monitor="val_loss", factor=0.1, patience=10, min_lr=0.0, epsilon=1e-4, cooldown=0,
+                 verbose=0):
+        self.monitor, self.factor, self.patience = monitor, factor, patience
+        self.min_lr, self.epsilon, self.cooldown, self.verbose = min_lr, epsilon, cooldown, verbose
+        self.wait, self.best, self.cooldown_counter = 0, np.inf, 0
+
+    def on_epoch_end(self, epoch, logs, model):
+        logs["lr"] = model.get_lr()
+        current = logs.get(self.monitor)
+        if current is None:
+            return
+        if self.cooldown_counter > 0:
+            self.cooldown_counter -= 1
+            self.wait = 0
+        if np.less(current, self.best - self.epsilon):
+            self.best, self.wait = current, 0
+        elif not self.cooldown_counter > 0:
+            if self.wait >= self.patience:
+                old_lr = float(model.get_lr())
+                if old_lr > self.min_lr:
+                    model.set_lr(max(old_lr * self.factor, self.min_lr))
+                    self.cooldown_counter = self.cooldown
+                    self.wait = 0
+            self.wait += 1
+
+
+class DenseHead(object):
+    """abs(l - r) -> Dense(h1, relu) -> Dense(h2, relu) -> Dense(2) -> softmax; BCE + Adadelta."""
+
+    def __init__(self, d_in, h1=512, h2=64, lr=1.0, rho=0.95, eps=1e-8, seed=None, device=0):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _abi.AlinkError("no ROCm device visible: a-link_amd computes only on the GPU (no CPU fallback)")
+        self.device = "cuda:%d" % device
+        self.lib = _abi.init(device)
+        self.d_in, self.h1, self.h2 = int(d_in), int(h1), int(h2)
+        self.h = self.lib.alink_head_create(self.d_in, self.h1, self.h2, lr, rho, eps)
+        if not self.h:
+            raise _abi.AlinkError("alink_head_create: " + self.lib.alink_last_error().decode())
+        self.stop_training = False
+        rng = np.random.RandomState(seed) if seed is not None else np.random
+        # Keras Dense default init: glorot_uniform kernel, zero bias
+        self.set_weights([glorot_uniform(rng, d_in, h1), np.zeros(h1, np.float32),
+                          glorot_uniform(rng, h1, h2), np.zeros(h2, np.float32),
+                          glorot_uniform(rng, h2, 2), np.zeros(2, np.float32)])
+        self._metrics = torch.zeros(2, dtype=torch.float32, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.alink_head_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- parameters --------------------------------------------------------------------------------
+    def _shapes(self):
+        return [(self.d_in, self.h1), (self.h1,), (self.h1, self.h2), (self.h2,), (self.h2, 2), (2,)]
+
+    def set_weights(self, ws):
+        shapes = self._shapes()
+        assert len(ws) == 6, "expected [W1,b1,W2,b2,W3,b3]"
+        flat = np.concatenate([np.asarray(w, np.float32).reshape(s).ravel() for w, s in zip(ws, shapes)])
+        flat = np.ascontiguousarray(flat, dtype=np.float32)
+        _abi.check(self.lib.alink_head_set_params(self.h, _abi.ptr(flat), flat.size), "alink_head_set_params")
+
+    def get_weights(self):
+        n = self.lib.alink_head_num_params(self.h)
+        flat = np.empty(n, dtype=np.float32)
+        _abi.check(self.lib.alink_head_get_params(self.h, _abi.ptr(flat), n), "alink_head_get_params")
+        out, o = [], 0
+        for s in self._shapes():
+            k = int(np.prod(s))
+            out.append(flat[o:o + k].reshape(s).copy())
+            o += k
+        return out
+
+    def get_lr(self):
+        return float(self.lib.alink_head_get_lr(self.h))
+
+    def set_lr(self, lr):
+        _abi.check(self.lib.alink_head_set_lr(self.h, float(lr)))
+
+    def save_weights(self, path):
+        """Side format: <path>.npz with Keras' layer/weight names (no h5py in this environment)."""
+        ws = self.get_weights()
+        names = ["dense_1/kernel", "dense_1/bias", "dense_2/kernel", "dense_2/bias", "dense_3/kernel", "dense_3/bias"]
+        np.savez(path + ".npz" if not path.endswith(".npz") else path, **dict(zip(names, ws)))
+
+    def load_weights(self, path):
+        p = path if path.endswith(".npz") else path + ".npz"
+        with np.load(p) as z:
+            names = ["dense_1/kernel", "dense_1/bias", "dense_2/kernel", "dense_2/bias", "dense_3/kernel",
+                     "dense_3/bias"]
+            self.set_weights([z[n] for n in names])
+
+    # -- device helpers ----------------------------------------------------------------------------
+    def _dev(self, a, dtype=None):
+        torch = self.torch
+        if isinstance(a, torch.Tensor):
+            t = a.to(self.device)
+            if dtype is not None and t.dtype != dtype:
+                t = t.to(dtype)
+            return t.contiguous()
+        a = np.ascontiguousarray(a, dtype=np.float32 if dtype in (None, torch.float32) else np.int32)
+        return torch.from_numpy(a).to(self.device)
+
+    def grads_tensor(self):
+        """torch view-less alias of the flat gradient buffer (for torch.distributed.all_reduce)."""
+        return self._alias(self.lib.alink_head_grads_dev(self.h))
+
+    def params_tensor(self):
+        return self._alias(self.lib.alink_head_params_dev(self.h))
+
+    def _alias(self, devptr):
+        torch = self.torch
+        n = self.lib.alink_head_num_params(self.h)
+
+        class _CAI(object):  # __cuda_array_interface__ holder
+            pass
+        holder = _CAI()
+        holder.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(devptr), False),
+                                           "version": 2, "strides": None}
+        t = torch.as_tensor(holder, device=self.device)
+        t._alink_owner = self
+        return t
+
+    # -- inference ---------------------------------------------------------------------------------
+    def predict_device(self, L, R, li=None, ri=None, out=None):
+        torch = self.torch
+        L, R = self._dev(L), self._dev(R)
+        if li is not None:
+            li, ri = self._dev(li, torch.int32), self._dev(ri, torch.int32)
+            P = li.numel()
+        else:
+            assert L.shape == R.shape
+            P = L.shape[0]
+        assert L.shape[1] == self.d_in and R.shape[1] == self.d_in
+        if out is None:
+            out = torch.empty((P, 2), dtype=torch.float32, device=self.device)
+        _abi.check(self.lib.alink_head_forward(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(li), _abi.ptr(ri), P,
+                                               _abi.ptr(out), _abi.current_stream()), "alink_head_forward")
+        return out
+
+    def predict(self, X, batch_size=1024, verbose=0):
+        """Keras Model.predict([L, R]) (reference code/siamese.py:131).  batch_size is accepted for
+        API compatibility; the kernel tiles the pairs itself."""
+        L, R = X
+        as_torch = isinstance(L, self.torch.Tensor)
+        out = self.predict_device(L, R)
+        return out if as_torch else out.cpu().numpy()
+
+    # -- training ----------------------------------------------------------------------------------
+    @staticmethod
+    def _sample_weights(y, class_weight, sample_weight):
+        if sample_weight is not None:
+            return np.asarray(sample_weight, np.float32)
+        if class_weight is not None:
+            cls = np.asarray(y).argmax(axis=1)
+            return np.asarray([class_weight[c] for c in cls if c in class_weight], dtype=np.float32)
+        return None
+
+    def train_on_batch(self, x, y, class_weight=None, sample_weight=None):
+        L, R = self._dev(x[0]), self._dev(x[1])
+        yd = self._dev(y)
+        sw = self._sample_weights(y, class_weight, sample_weight)
+        swd = self._dev(sw) if sw is not None else None
+        n = L.shape[0]
+        _abi.check(self.lib.alink_head_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
+                                                  0.0, 1, _abi.ptr(self._metrics), _abi.current_stream()),
+                   "alink_head_train_step")
+        m = self._metrics.cpu().numpy()
+        return [float(m[0]), float(m[1])]
+
+    def test_on_batch(self, x, y):
+        L, R = self._dev(x[0]), self._dev(x[1])
+        yd = self._dev(y)
+        _abi.check(self.lib.alink_head_eval(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), L.shape[0],
+                                            _abi.ptr(self._metrics), _abi.current_stream()), "alink_head_eval")
+        m = self._metrics.cpu().numpy()
+        return [float(m[0]), float(m[1])]
+
+    def fit(self, x, y, batch_size=32, epochs=1, verbose=1, callbacks=None, validation_split=0.0, shuffle=True):
+        """Keras 2.1.2 Model.fit for in-memory arrays (reference code/siamese.py:57)."""
+        L = np.asarray(x[0], dtype=np.float32)
+        R = np.asarray(x[1], dtype=np.float32)
+        y = np.asarray(y, dtype=np.float32)
+        n_all = L.shape[0]
+        if 0.0 < validation_split < 1.0:
+            split_at = int(n_all * (1.0 - validation_split))
+            vL, vR, vy = L[split_at:], R[split_at:], y[split_at:]
+            L, R, y = L[:split_at], R[:split_at], y[:split_at]
+        else:
+            vL = vR = vy = None
+        n = L.shape[0]
+        Ld, Rd, yd = self._dev(L), self._dev(R), self._dev(y)
+        torch = self.torch
+        history = {"loss": [], "acc": []}
+        if vL is not None:
+            history["val_loss"], history["val_acc"] = [], []
+        self.stop_training = False
+        index_array = np.arange(n)
+        for epoch in range(epochs):
+            if shuffle:
+                np.random.shuffle(index_array)
+            tot, seen = np.zeros(2), 0
+            for s in range(0, n, batch_size):
+                ids = index_array[s:s + batch_size]
+                idt = torch.from_numpy(ids.astype(np.int64)).to(self.device)
+                out = self.train_on_batch([Ld[idt], Rd[idt]], yd[idt])
+                tot += np.asarray(out) * len(ids)
+                seen += len(ids)
+            logs = {"loss": tot[0] / seen, "acc": tot[1] / seen}
+            if vL is not None and len(vy) > 0:
+                vt, vs = np.zeros(2), 0
+                for s in range(0, len(vy), batch_size):
+                    out = self.test_on_batch([vL[s:s + batch_size], vR[s:s + batch_size]], vy[s:s + batch_size])
+                    k = len(vy[s:s + batch_size])
+                    vt += np.asarray(out) * k
+                    vs += k
+                logs["val_loss"], logs["val_acc"] = vt[0] / vs, vt[1] / vs
+            for cb in (callbacks or []):
+                cb.on_epoch_end(epoch, logs, self)
+            for k, v in logs.items():
+                history.setdefault(k, []).append(v)
+            if verbose:
+                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in sorted(logs.items())))
+            if self.stop_training:
+                break
+        return history
+
+
+def committee_predict_device(heads, L, R, li=None, ri=None):
+    """Bagging.predict on device: sum of member softmaxes / M (reference code/committee.py:13-20)."""
+    h0 = heads[0]
+    torch = h0.torch
+    L, R = h0._dev(L), h0._dev(R)
+    if li is not None:
+        li, ri = h0._dev(li, torch.int32), h0._dev(ri, torch.int32)
+        P = li.numel()
+    else:
+        P = L.shape[0]
+    out = torch.empty((P, 2), dtype=torch.float32, device=h0.device)
+    arr = (C.c_void_p * len(heads))(*[h.h for h in heads])
+    _abi.check(h0.lib.alink_committee_forward(arr, len(heads), _abi.ptr(L), _abi.ptr(R), _abi.ptr(li), _abi.ptr(ri),
+                                              P, _abi.ptr(out), None, _abi.current_stream()), "alink_committee_forward")
+    return out

@@ -1,0 +1,142 @@
+"""siamese — drop-in for the hot-path classes of reference code/siamese.py.
+
+    SiameseNetwork(shape, modelName, learningRate=1.0)      code/siamese.py:19-131
+    ArcFace(shape, model_path)                              code/siamese.py:219-234
+    SmallRes(imageShape, featureShape, name, learningRate)  code/siamese.py:134-184  (see smallres.py)
+
+Same constructor signatures, attributes (`siamese_net`, `modelName`, `shape`, `learningRate`) and
+methods.  `siamese_net` is a DenseHead (GPU) exposing the Keras Model calls the reference makes.
+"""
+import sys
+
+import numpy as np
+
+from . import face_model
+from .head import DenseHead, EarlyStopping, ReduceLROnPlateau, to_categorical
+
+
+class _Args(dict):
+    """easydict.EasyDict stand-in for the 4 keys the reference passes (code/siamese.py:221-226)."""
+    __getattr__ = dict.__getitem__
+
+
+class SiameseNetwork:
+    _identity_preprocess = True
+
+    def __init__(self, shape, modelName, learningRate=1.0, seed=None, adadelta_epsilon=1e-8):
+        self.learningRate = learningRate
+        self.modelName = modelName
+        self.shape = shape
+        # abs(l - r) -> Dense(512, relu) -> Dense(64, relu) -> Dense(2) -> softmax,
+        # loss binary_crossentropy, optimizer Adadelta(learningRate) (code/siamese.py:24-35)
+        self.siamese_net = DenseHead(shape[0], 512, 64, lr=learningRate, rho=0.95, eps=adadelta_epsilon, seed=seed)
+
+    def getDenseBarebones(self):
+        """(code/siamese.py:37-42) layer specs as (units, activation) — there is no Keras here."""
+        return [(512, 'relu'), (64, 'relu'), (2, None)]
+
+    def finetune(self, X, Y, epochs, batch_size, verbose=1):
+        early_stop = EarlyStopping(monitor='val_loss', min_delta=0.1, patience=5, verbose=1)
+        reduce_lr = ReduceLROnPlateau(monitor='val_loss', factor=0.2, patience=5, min_lr=0.01, verbose=verbose)
+        Y_encoded = to_categorical(Y, num_classes=2)
+        return self.siamese_net.fit(self.preprocess(X), Y_encoded, batch_size=batch_size, epochs=epochs,
+                                    validation_split=0.2, verbose=verbose, callbacks=[early_stop, reduce_lr])
+
+    def testAccuracy(self, X, Y, batch_size=512):
+        """(code/siamese.py:60-79) all-pairs accuracy; pairs gathered on device instead of stacked."""
+        X = np.asarray(X, dtype=np.float32)
+        Y = np.asarray(Y).ravel()
+        n = len(X)
+        li = np.repeat(np.arange(n, dtype=np.int32), n)
+        ri = np.tile(np.arange(n, dtype=np.int32), n)
+        probs = self.siamese_net.predict_device(X, X, li, ri).cpu().numpy()
+        pred = np.argmax(probs, axis=1)
+        truth = 1 * (Y[li] == Y[ri])
+        return np.sum(pred == truth) / float(len(li))
+
+    def customTrainModel(self, dataGen, epochs, batch_size, valRatio=0.2, n_steps=320000, preprocess=False,
+                         verbose=1):
+        steps_per_epoch = int(n_steps / batch_size)
+        logs = []
+        for eno in range(epochs):
+            train_loss, val_loss = 0, 0
+            train_acc, val_acc = 0, 0
+            for i in range(steps_per_epoch):
+                x, y = next(dataGen)
+                if preprocess:
+                    x = self.preprocess(x)
+                indices = np.random.permutation(len(y))
+                splitPoint = int(len(y) * valRatio)
+                x_train, y_train = [pp[indices[splitPoint:]] for pp in x], y[indices[splitPoint:]]
+                x_test, y_test = [pp[indices[:splitPoint]] for pp in x], y[indices[:splitPoint]]
+                # Python-2 integer division in the reference (no `from __future__ import division`
+                # in code/siamese.py): len / count floors.
+                with np.errstate(divide='ignore'):
+                    class_1_weight = np.int64(len(y_train)) // np.sum(y_train == 1)
+                    class_0_weight = np.int64(len(y_train)) // np.sum(y_train == 0)
+                scaling_factor = float(class_1_weight + class_0_weight)
+                class_weight = {0: class_0_weight / scaling_factor, 1: class_1_weight / scaling_factor}
+                y_train = to_categorical(y_train, num_classes=2)
+                y_test = to_categorical(y_test, num_classes=2)
+                train_metrics = self.siamese_net.train_on_batch(x_train, y_train, class_weight=class_weight)
+                train_loss += train_metrics[0]
+                train_acc += train_metrics[1]
+                if len(y_test) > 0:
+                    val_metrics = self.siamese_net.test_on_batch(x_test, y_test)
+                    val_loss += val_metrics[0]
+                    val_acc += val_metrics[1]
+                if verbose:
+                    sys.stdout.write("Epoch %d : %d / %d : Tr loss: %.4f, Tr acc: %.4f, Vl loss: %.4f, Vl acc: %.4f  \r" % (
+                        eno + 1, i + 1, steps_per_epoch, train_loss / (i + 1), train_acc / (i + 1),
+                        val_loss / (i + 1), val_acc / (i + 1)))
+                    sys.stdout.flush()
+            if verbose:
+                print("\n")
+            logs.append((train_loss / steps_per_epoch, train_acc / steps_per_epoch,
+                         val_loss / steps_per_epoch, val_acc / steps_per_epoch))
+        return logs
+
+    def maybeLoadFromMemory(self):
+        try:
+            self.siamese_net.load_weights(self.modelName + ".h5")
+            return True
+        except Exception:
+            return False
+
+    def save(self, customName=None):
+        if not customName:
+            self.siamese_net.save_weights(self.modelName + ".h5")
+        else:
+            self.siamese_net.save_weights(customName + ".h5")
+
+    def preprocess(self, X):
+        return X
+
+    def predict(self, X):
+        return self.siamese_net.predict(self.preprocess(X), batch_size=1024)
+
+
+class ArcFace:
+    def __init__(self, shape, model_path, dtype="bf16", max_batch=256):
+        args = _Args({
+            "image_size": "%d,%d" % (shape[0], shape[1]),
+            "model": model_path + ",0",
+            "gpu": 0,
+            "threshold": 1.24,
+            "dtype": dtype,
+            "max_batch": max_batch,
+        })
+        self.model = face_model.FaceModel(args)
+
+    def preprocess(self, X):
+        return X
+
+    def process(self, X):
+        """(N,H,W,3) float RGB 0..255 -> (N,512).  The reference loops get_input/get_feature per
+        image at batch 1 (code/siamese.py:234); here the whole array is one batched launch chain."""
+        X = self.preprocess(X)
+        if isinstance(X, (list, tuple)):
+            X = np.stack(X)
+        if len(X) == 0:
+            return np.zeros((0, 512), dtype=np.float32)
+        return self.model.get_features(X)

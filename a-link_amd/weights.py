@@ -1,0 +1,117 @@
+"""Backbone checkpoints: tensor name table (MXNet / insightface naming), synthetic initialisation and
+the .npz side format.
+
+The reference loads `model-r100-ii/model-symbol.json` + `model-0000.params` downloaded from Dropbox
+(reference code/arcface_prepreq.sh:13-20, code/face_model.py:34).  Neither file is available offline,
+so bench/tests use synthetic weights of the same architecture:
+conv He-normal, BN gamma~U(.5,1.5) beta~N(0,.1) mean~N(0,.1) var~U(.5,1.5), PReLU 0.25, FC Xavier.
+A real checkpoint converted to an .npz with the same tensor names loads through `load_npz`.
+"""
+import numpy as np
+
+R100_UNITS = (3, 13, 30, 3)
+R50_UNITS = (3, 4, 14, 3)
+WIDTHS = (64, 64, 128, 256, 512)
+ARCH_UNITS = {"r100": R100_UNITS, "r50": R50_UNITS, "r34": (3, 4, 6, 3), "r18": (2, 2, 2, 2)}
+
+
+def tensor_shapes(units, widths=WIDTHS, size=(112, 112), emb=512):
+    """Ordered {name: shape} of every tensor the LResNet-E-IR checkpoint holds (MXNet layouts)."""
+    t = {}
+
+    def bn(name, c):
+        for s in ("_gamma", "_beta", "_moving_mean", "_moving_var"):
+            t[name + s] = (c,)
+
+    t["conv0_weight"] = (widths[0], 3, 3, 3)
+    bn("bn0", widths[0])
+    t["relu0_gamma"] = (widths[0],)
+    h, w = size
+    for s in range(4):
+        c = widths[s + 1]
+        for u in range(units[s]):
+            p = "stage%d_unit%d" % (s + 1, u + 1)
+            cin = widths[s] if u == 0 else c
+            bn(p + "_bn1", cin)
+            t[p + "_conv1_weight"] = (c, cin, 3, 3)
+            bn(p + "_bn2", c)
+            t[p + "_relu1_gamma"] = (c,)
+            t[p + "_conv2_weight"] = (c, c, 3, 3)
+            bn(p + "_bn3", c)
+            if u == 0:
+                t[p + "_conv1sc_weight"] = (c, cin, 1, 1)
+                bn(p + "_sc", c)
+        h, w = (h + 1) // 2, (w + 1) // 2
+    bn("bn1", widths[4])
+    t["pre_fc1_weight"] = (emb, widths[4] * h * w)
+    t["pre_fc1_bias"] = (emb,)
+    bn("fc1", emb)
+    return t
+
+
+def synthetic_ir_params(units=R100_UNITS, widths=WIDTHS, size=(112, 112), emb=512, seed=1):
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, shape in tensor_shapes(units, widths, size, emb).items():
+        if name.endswith("_weight") and len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            v = rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+        elif name == "pre_fc1_weight":
+            lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+            v = rng.uniform(-lim, lim, shape)
+        elif name == "pre_fc1_bias":
+            v = rng.standard_normal(shape) * 0.01
+        elif name.endswith("_gamma") and ("relu" in name):
+            v = np.full(shape, 0.25)
+        elif name.endswith("_gamma"):
+            v = rng.uniform(0.5, 1.5, shape)
+        elif name.endswith("_beta") or name.endswith("_moving_mean"):
+            v = rng.standard_normal(shape) * 0.1
+        elif name.endswith("_moving_var"):
+            v = rng.uniform(0.5, 1.5, shape)
+        else:
+            raise AssertionError(name)
+        p[name] = np.ascontiguousarray(v, dtype=np.float32)
+    return p
+
+
+def infer_units(params):
+    units = []
+    for s in range(1, 5):
+        u = 0
+        while ("stage%d_unit%d_conv1_weight" % (s, u + 1)) in params:
+            u += 1
+        units.append(u)
+    return tuple(units)
+
+
+def save_npz(path, params):
+    np.savez(path, **params)
+
+
+def load_npz(path):
+    with np.load(path) as z:
+        out = {}
+        for k in z.files:
+            # accept MXNet's "arg:" / "aux:" prefixes as written by mx.nd.save of a checkpoint dict
+            name = k.split(":", 1)[1] if (k.startswith("arg:") or k.startswith("aux:")) else k
+            out[name] = np.ascontiguousarray(z[k], dtype=np.float32)
+        return out
+
+
+def resolve_model(model_str, image_size=(112, 112)):
+    """`args.model` of FaceModel ("prefix,epoch", reference code/face_model.py:29-33) -> params dict.
+
+    prefix forms:  synthetic:<arch>[:seed]   synthetic weights (bench / tests)
+                   <path>                    <path>-%04d.npz (epoch) holding MXNet-named tensors
+    """
+    vec = model_str.split(",")
+    assert len(vec) == 2, "model must be 'prefix,epoch' (reference code/face_model.py:29-30)"
+    prefix, epoch = vec[0], int(vec[1])
+    if prefix.startswith("synthetic:"):
+        parts = prefix.split(":")
+        arch = parts[1]
+        seed = int(parts[2]) if len(parts) > 2 else 1
+        return synthetic_ir_params(ARCH_UNITS[arch], size=image_size, seed=seed)
+    path = "%s-%04d.npz" % (prefix, epoch)
+    return load_npz(path)

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: 112x112 face embeddings/s (IR-ResNet-100 "ArcFace") on MI355X.
+
+A "step" embeds one batch of synthetic 112x112x3 faces (uniform integer pixels 0..255, seed 0;
+synthetic weights seed 1 — SURVEY.md §8d) already resident in HBM: stem -> 49 residual units -> FC ->
+L2 normalise, exactly the launch chain ArcFace.process runs.  N GPUs = N independent shards of the
+pool (weak scaling, no data-path collective: images are independent).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (implicit-GEMM conv
+kernel: algorithmic FLOPs / HIP-event kernel time, vs the 2.5 PFLOP/s dense bf16 MFMA peak) and
+`cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2516.6    # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU dense bf16/f16 (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="r100", choices=["r100", "r50", "r34", "r18"])
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--input", default="f32", choices=["f32", "u8"], help="pixel type resident in HBM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline profile / fine-tune timing")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import a_link_amd  # noqa: F401
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    units = W.ARCH_UNITS[args.model]
+    params = W.synthetic_ir_params(units, seed=1)
+    bb = IRBackbone(params, image_size=(112, 112), dtype=args.dtype, device=local_rank, max_batch=args.batch)
+    del params
+    B = args.batch
+    g = torch.Generator(device="cpu").manual_seed(rank)           # rank 0 == seed 0
+    px = torch.randint(0, 256, (B, 112, 112, 3), generator=g, dtype=torch.uint8)
+    x = (px if args.input == "u8" else px.to(torch.float32)).cuda()
+    out = torch.empty((B, 512), dtype=torch.float32, device="cuda")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        bb.embed_device(x, out)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bb.embed_device(x, out)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all()
+
+    from oracle import ir_resnet     # FLOP count + cpu_baseline leg only
+    gflop_per_emb = ir_resnet.flops_per_image(units) / 1e9
+    emb_per_s = world * args.steps * B / dt
+    line = {
+        "metric": "112x112 face embeddings/sec (IR-ResNet-%s ArcFace, 512-d, L2-normalised)" % args.model[1:],
+        "value": emb_per_s, "unit": "embeddings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "LResNet%sE-IR embed, batch %d x 3x112x112 per GPU, %s pixels resident in HBM"
+                               % (args.model[1:], B, args.input),
+                   "arch": args.model, "units": list(units), "batch_per_gpu": B, "global_batch": B * world,
+                   "gflop_per_embedding": gflop_per_emb, "sharding": "images (dp%d), no collective" % world},
+        "tflops_end_to_end": emb_per_s * gflop_per_emb / 1e3,
+        "frac_mfma_peak_end_to_end": emb_per_s * gflop_per_emb / 1e3 / (MFMA_PEAK_TFLOPS * world),
+    }
+
+    if rank == 0 and not args.no_extras:
+        # ---- roofline of the dominant kernel (conv_igemm_kernel): HIP events around every launch
+        conv_ms, conv_fl, other_ms = [], [], []
+        for _ in range(3):
+            prof = bb.profile(x)
+            conv_ms.append(sum(ms for k, ms, f in prof if k == 1))
+            conv_fl.append(sum(f for k, ms, f in prof if k == 1))
+            other_ms.append(sum(ms for k, ms, f in prof if k != 1))
+        n_conv = sum(1 for k, _, _ in prof if k == 1)
+        cms = float(np.median(conv_ms))
+        achieved = conv_fl[0] / (cms * 1e-3) / 1e12
+        line["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (all %d launches of one forward)" % n_conv,
+                            "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                            "flops_per_forward": conv_fl[0], "kernel_ms_per_forward": cms,
+                            "avg_launch_ms": cms / n_conv, "non_conv_ms_per_forward": float(np.median(other_ms))}
+        # ---- fine-tune step (second half of BASELINE.json's metric): head-512, batch 16
+        from a_link_amd.head import DenseHead
+        hd = DenseHead(512, lr=0.1, seed=0)
+        rng = np.random.RandomState(0)
+        L = torch.from_numpy(rng.randn(16, 512).astype(np.float32)).cuda()
+        R = torch.from_numpy(rng.randn(16, 512).astype(np.float32)).cuda()
+        y = np.zeros((16, 2), np.float32)
+        y[np.arange(16), rng.randint(0, 2, 16)] = 1
+        yd = torch.from_numpy(y).cuda()
+        for _ in range(20):
+            hd.train_on_batch([L, R], yd)
+        ts = []
+        for _ in range(200):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hd.train_on_batch([L, R], yd)      # fwd + BCE + bwd + Adadelta + metrics read-back
+            ts.append(time.perf_counter() - t1)
+        line["finetune_step_ms"] = 1e3 * float(np.median(ts))
+        # pair scoring throughput (K6): 1M pairs gathered from a 100k x 512 embedding matrix
+        E = torch.randn(100000, 512, device="cuda")
+        E = E / E.norm(dim=1, keepdim=True)
+        li = torch.randint(0, 100000, (1 << 20,), device="cuda", dtype=torch.int32)
+        ri = torch.randint(0, 100000, (1 << 20,), device="cuda", dtype=torch.int32)
+        po = torch.empty((1 << 20, 2), device="cuda")
+        hd.predict_device(E, E, li, ri, out=po)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            hd.predict_device(E, E, li, ri, out=po)
+        torch.cuda.synchronize()
+        line["pair_scores_per_s"] = 3 * (1 << 20) / (time.perf_counter() - t1)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- CPU baseline: the oracle (kind "port": our CPU restatement; the reference's MXNet path
+        # cannot be installed) on a bounded sample of the same workload
+        params = W.synthetic_ir_params(units, seed=1)
+        cores = torch.get_num_threads()
+        xs = x[:8].float().cpu().numpy()
+        t1 = time.perf_counter()
+        ir_resnet.embed(params, xs, batch=8)
+        one = time.perf_counter() - t1
+        reps = max(1, min(8, int(15.0 / max(one, 1e-3))))
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ir_resnet.embed(params, xs, batch=8)
+        cpu_dt = time.perf_counter() - t1
+        line["cpu_baseline"] = {"value": reps * 8 / cpu_dt, "unit": "embeddings/s", "cores": cores, "kind": "port",
+                                "sample": "%d x batch-8 forwards of the same %s network (torch-CPU f32 oracle)"
+                                          % (reps, args.model)}
+
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

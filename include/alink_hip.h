@@ -1,0 +1,170 @@
+/*
+ * alink_hip.h — C-ABI of libalink_hip.so, the MI355X (gfx950) implementation of A-LINK's
+ * face-recognition hot path.
+ *
+ * The reference (iamgroot42/A-LINK) has NO native boundary: its hot path is Python duck typing on
+ * top of MXNet / Keras.  Every entry point below therefore cites the reference *call site* it
+ * replaces (paths relative to the reference checkout).  A maintainer binds these with ctypes (see
+ * INTEGRATION.md); this repo's own host side (a-link_amd/_abi.py) does exactly that.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative ALINK_E* code; nothing throws across the ABI;
+ *     alink_last_error() returns a thread-local human-readable message for the last failure.
+ *   - all `dev_*` pointers are device (HBM) pointers owned by the caller (PyTorch-ROCm in this repo);
+ *     `stream` is a hipStream_t passed as void* (NULL = default stream).  No entry point allocates,
+ *     frees or synchronises inside the launch path (graph-capture safe), except *_create / *_finalize
+ *     / *_destroy / *_profile which are documented as synchronous.
+ *   - handles are opaque, one per (process, GPU); a handle is not thread-safe (the reference is
+ *     single-threaded: code/ALINK_arc.py:22-25).
+ *   - pixels are what the reference feeds its models: float32, RGB, 0..255
+ *     (code/readDFW.py:82,124); 512-d embeddings and all head tensors are float32.
+ */
+#ifndef ALINK_HIP_H
+#define ALINK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALINK_OK          0
+#define ALINK_EINVAL     -1   /* bad argument / shape the kernels do not support            */
+#define ALINK_ENOMEM     -2   /* hipMalloc failed or caller workspace too small              */
+#define ALINK_EHIP       -3   /* a HIP runtime call failed (message has hipGetErrorString)   */
+#define ALINK_ESTATE     -4   /* call order violated (e.g. embed before finalize)            */
+#define ALINK_ENOTFOUND  -5   /* unknown tensor name                                         */
+
+/* activation / weight storage type of the backbone GEMMs (accumulation is always f32) */
+#define ALINK_DT_BF16 0
+#define ALINK_DT_F16  1
+
+/* input pixel layouts accepted by alink_embed */
+#define ALINK_LAYOUT_NHWC_F32 0   /* what siamese.ArcFace.process receives (code/siamese.py:232-234) */
+#define ALINK_LAYOUT_NCHW_F32 1   /* what FaceModel.get_feature receives  (code/face_model.py:83-88)  */
+#define ALINK_LAYOUT_NHWC_U8  2   /* extension: raw 8-bit pixels, 4x less input traffic              */
+
+const char* alink_last_error(void);
+int  alink_init(int device);                 /* hipSetDevice + function attributes; idempotent */
+int  alink_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backbone: insightface LResNet-E-IR ("ArcFace") feature extractor.
+ * Replaces face_model.get_model (code/face_model.py:28-41: mx.model.load_checkpoint + bind) and
+ * FaceModel.get_feature (code/face_model.py:86-93: forward + sklearn normalize).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct alink_backbone alink_backbone_t;
+
+typedef struct {
+    int units[4];      /* residual units per stage: r100 = {3,13,30,3}, r50 = {3,4,14,3}   */
+    int widths[5];     /* {64,64,128,256,512}: stem width then one per stage (multiples of 64) */
+    int height, width; /* input size; "112,112" in code/siamese.py:222                       */
+    int emb;           /* embedding size (512), multiple of 64                               */
+    int dtype;         /* ALINK_DT_BF16 | ALINK_DT_F16                                       */
+    float bn_eps;      /* 2e-5 in the insightface symbol                                     */
+} alink_ir_cfg;
+
+alink_backbone_t* alink_backbone_create(const alink_ir_cfg* cfg);
+void alink_backbone_destroy(alink_backbone_t* bb);
+
+/* Hand over one raw checkpoint tensor (host float32, MXNet layout and MXNet names:
+ * conv (O,I,kh,kw); FC (O, C*H*W); BN gamma/beta/moving_mean/moving_var; PReLU gamma).
+ * This is the per-tensor body of arg_params/aux_params in code/face_model.py:34,40. */
+int alink_backbone_load(alink_backbone_t* bb, const char* name, const float* host, size_t count);
+/* number of tensors the configured network expects, and the i-th expected name / element count */
+int alink_backbone_num_tensors(const alink_backbone_t* bb);
+int alink_backbone_tensor_info(const alink_backbone_t* bb, int i, const char** name, size_t* count);
+/* fold BN into weights/biases, convert, upload.  Synchronous; allocates device memory. */
+int alink_backbone_finalize(alink_backbone_t* bb);
+
+size_t alink_backbone_workspace_bytes(const alink_backbone_t* bb, int n_images);
+
+/* N images -> N L2-normalised embeddings (code/face_model.py:86-93, batched).
+ * dev_in: pixels in `layout`; dev_out: N x emb float32. */
+int alink_embed(alink_backbone_t* bb, const void* dev_in, int layout, int n_images,
+                float* dev_out, void* dev_workspace, size_t workspace_bytes, void* stream);
+
+/* Per-launch timing of one alink_embed with HIP events on `stream` (synchronous; for bench.py's
+ * roofline).  ms[i]/flops[i]/kind[i] describe launch i; kind: 0 stem, 1 implicit-GEMM conv,
+ * 2 FC split-K GEMM, 3 FC finish.  *n_launches in: capacity, out: count. */
+int alink_embed_profile(alink_backbone_t* bb, const void* dev_in, int layout, int n_images,
+                        float* dev_out, void* dev_workspace, size_t workspace_bytes, void* stream,
+                        float* ms, double* flops, int* kind, int* n_launches);
+
+/* Diagnostic / unit-test entry: one fused NHWC convolution launch of the implicit-GEMM kernel
+ *   out = [prelu_alpha]( conv(in, w) + bias[class] ) [+ resid]
+ * dev_w is (Cout, ksz, ksz, Cin) in `dtype` in NATURAL cout order (the call permutes a private
+ * copy — synchronous, test use only); dev_bias is (ncls, Cout) f32 with ncls = 9 if border_cls. */
+int alink_conv_nhwc(int dtype, const void* dev_in, const void* dev_w, const float* dev_bias,
+                    const float* dev_alpha, const void* dev_resid, void* dev_out,
+                    int N, int H, int W, int Cin, int Cout, int ksz, int stride, int pad,
+                    int border_cls, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Siamese pair head: |l - r| -> Dense(h1) ReLU -> Dense(h2) ReLU -> Dense(2) -> softmax.
+ * Replaces SiameseNetwork.__init__/predict/finetune/customTrainModel's Keras calls
+ * (code/siamese.py:19-35, 52-58, 81-112, 130-131) and committee.Bagging.predict
+ * (code/committee.py:13-20).  All f32 (exact-f32 MFMA), Keras-2.1.2 semantics.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct alink_head alink_head_t;
+
+alink_head_t* alink_head_create(int d_in, int h1, int h2, float lr, float rho, float eps);
+void alink_head_destroy(alink_head_t* h);
+size_t alink_head_num_params(const alink_head_t* h);   /* W1,b1,W2,b2,W3,b3 flattened */
+/* Parameters in Keras order and layout: kernel (in,out) row-major then bias, per layer. */
+int alink_head_set_params(alink_head_t* h, const float* host_params, size_t count);
+int alink_head_get_params(const alink_head_t* h, float* host_params, size_t count);
+int alink_head_reset_optimizer(alink_head_t* h);
+/* keras.callbacks.ReduceLROnPlateau hook (code/siamese.py:54): change Adadelta's lr */
+int alink_head_set_lr(alink_head_t* h, float lr);
+float alink_head_get_lr(const alink_head_t* h);
+/* device pointers of the flat parameter / gradient buffers (for RCCL all-reduce by the caller) */
+float* alink_head_params_dev(alink_head_t* h);
+float* alink_head_grads_dev(alink_head_t* h);
+
+/* probs[p] = softmax(head(|L[li[p]] - R[ri[p]]|)) for p < P.  li/ri may be NULL (= identity):
+ * that is SiameseNetwork.predict([L,R]) (code/siamese.py:130-131); with index lists the pairs are
+ * gathered from embedding matrices instead of being materialised (utilities/generateMatrixDFW.py:25-36). */
+int alink_head_forward(alink_head_t* h, const float* dev_L, const float* dev_R,
+                       const int32_t* dev_li, const int32_t* dev_ri, int64_t P,
+                       float* dev_probs, void* stream);
+/* Bagging.predict: mean over n_heads members of alink_head_forward (code/committee.py:13-20). */
+int alink_committee_forward(alink_head_t* const* heads, int n_heads, const float* dev_L,
+                            const float* dev_R, const int32_t* dev_li, const int32_t* dev_ri,
+                            int64_t P, float* dev_probs, void* dev_scratch, void* stream);
+
+/* One Keras train_on_batch: forward, binary_crossentropy (clip 1e-7, mean over the 2 outputs,
+ * sample-weighted mean over the batch), backward, [grads left in alink_head_grads_dev],
+ * then Adadelta.  dev_y is (n,2) one-hot, dev_sw (n) sample weights or NULL.
+ * dev_metrics receives {loss, binary_accuracy}.  `apply` = 0 computes gradients only (the caller
+ * all-reduces them, then calls alink_head_apply_update) — the data-parallel fine-tune step. */
+int alink_head_train_step(alink_head_t* h, const float* dev_L, const float* dev_R,
+                          const float* dev_y, const float* dev_sw, int n, float grad_scale,
+                          int apply, float* dev_metrics, void* stream);
+int alink_head_apply_update(alink_head_t* h, void* stream);
+/* Keras test_on_batch: {loss, binary_accuracy} without touching parameters. */
+int alink_head_eval(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
+                    int n, float* dev_metrics, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pool scoring helpers (HBM-bound): uncertainty measures (code/uncertainty.py:15-60) and top-k
+ * (modAL multi_argmax as used at code/uncertainty.py:155,183,213; disparity top-k at
+ * code/ALINK_arc.py:181).
+ * ---------------------------------------------------------------------------------------------- */
+#define ALINK_SCORE_UNCERTAINTY 0   /* 1 - max_c p                                  */
+#define ALINK_SCORE_MARGIN      1   /* p_(1) - p_(2)                                */
+#define ALINK_SCORE_ENTROPY     2   /* -sum p ln p (p renormalised)                 */
+#define ALINK_SCORE_DISPARITY   3   /* -|a[:,col] - b[:,col]| (needs dev_b)         */
+int alink_score(int kind, const float* dev_probs, const float* dev_b, int col, int64_t P, int C,
+                float* dev_scores, void* stream);
+/* indices of the k smallest (largest=0) or largest scores, ties broken by lower index, returned
+ * sorted by (score, index).  dev_scratch >= alink_topk_scratch_bytes(P, k). */
+size_t alink_topk_scratch_bytes(int64_t P, int k);
+int alink_topk(const float* dev_scores, int64_t P, int k, int largest, int32_t* dev_idx,
+               float* dev_vals, void* dev_scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALINK_HIP_H */

@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library is built, loads, and exports every symbol include/alink_hip.h declares."""
+import os
+import re
+
+import a_link_amd  # noqa: F401
+from a_link_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "alink_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(alink_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exists_and_loads():
+    assert os.path.exists(_abi.LIB_PATH), "run __graft_entry__.build() first"
+    lib = _abi.load()
+    assert lib.alink_version() >= 1
+
+
+def test_every_header_symbol_is_exported_and_bound():
+    lib = _abi.load()
+    syms = _header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), "library does not export %s" % s
+        assert s in _abi.PROTOTYPES, "_abi.py has no prototype for %s" % s
+    for s in _abi.PROTOTYPES:
+        assert s in syms, "_abi.py binds %s which the header does not declare" % s
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        return
+    import pytest
+    with pytest.raises(_abi.AlinkError):
+        _abi.init(0)
+    from a_link_amd.head import DenseHead
+    with pytest.raises(_abi.AlinkError):
+        DenseHead(512)
+    from a_link_amd import siamese
+    with pytest.raises(_abi.AlinkError):
+        siamese.ArcFace((112, 112), "synthetic:r18")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "a-link_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py") or f.endswith(".hip") or f.endswith(".h"):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f

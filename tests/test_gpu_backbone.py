@@ -1,0 +1,126 @@
+"""GPU parity of the whole IR-ResNet feature extractor (stem -> residual stages -> FC -> L2 norm)
+against the unfused CPU oracle (oracle/ir_resnet.py), through the reference's own API surface
+(siamese.ArcFace.process / FaceModel.get_feature).
+
+Tolerance: north_star — 512-d embeddings within 1e-3 cosine of the reference arithmetic (f32 on
+CPU); the HIP path stores activations in bf16 (f16 optional) and accumulates in f32.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-3
+
+
+def _cos_dist(a, b):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+def _pixels(n, size, seed=0):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (n, size[0], size[1], 3)).astype(np.float32)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_small_net_all_layouts(gpu, dtype):
+    """units (2,2,2,2) at 32x32: every layer type, every input layout, ragged tiles everywhere."""
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import ir_resnet
+    size = (32, 32)
+    params = W.synthetic_ir_params((2, 2, 2, 2), size=size, seed=3)
+    bb = IRBackbone(params, image_size=size, dtype=dtype, max_batch=8)
+    x = _pixels(5, size, seed=1)
+    ref = ir_resnet.embed(params, x)
+    got = bb.embed(x)
+    assert got.shape == (5, 512) and got.dtype == np.float32
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    d = _cos_dist(got, ref)
+    assert d.max() < COS_TOL, d
+    # NCHW (FaceModel.get_feature's layout) and u8 inputs give the same result bit for bit
+    got_nchw = bb.embed(np.ascontiguousarray(np.transpose(x, (0, 3, 1, 2))))
+    got_u8 = bb.embed(x.astype(np.uint8))
+    assert np.array_equal(got, got_nchw)
+    assert np.array_equal(got, got_u8)
+    # batch invariance: an image embeds identically alone and inside a batch (no cross-image reduction)
+    single = bb.embed(x[2:3])
+    assert np.array_equal(single[0], got[2])
+    # chunking (max_batch = 8): 19 images in 3 chunks equals per-image results
+    x19 = _pixels(19, size, seed=7)
+    g19 = bb.embed(x19)
+    assert np.array_equal(g19[9], bb.embed(x19[9:10])[0])
+
+
+def test_non_integer_and_out_of_range_pixels(gpu):
+    """Noisy images are not clipped back to 0..255 before embedding (reference code/noise.py:44,
+    code/ALINK_arc.py:161-164): negative / >255 / fractional pixels must flow through."""
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import ir_resnet
+    size = (32, 32)
+    params = W.synthetic_ir_params((1, 1, 1, 1), size=size, seed=5)
+    bb = IRBackbone(params, image_size=size, max_batch=4)
+    rng = np.random.default_rng(2)
+    x = (_pixels(3, size, 4) + rng.normal(10, np.sqrt(10), (3, 32, 32, 3))).astype(np.float32)
+    x[0, :2] = -20.0
+    x[1, -2:] = 300.0
+    d = _cos_dist(bb.embed(x), ir_resnet.embed(params, x))
+    assert d.max() < COS_TOL, d
+
+
+def test_r50_112_api_surface(gpu):
+    """ResNet-50-IR at the reference's 112x112 through ArcFace.process / FaceModel.get_feature."""
+    from a_link_amd import siamese, weights as W
+    from oracle import ir_resnet
+    fm = siamese.ArcFace((112, 112), "synthetic:r50:1", max_batch=4)
+    params = W.synthetic_ir_params(W.R50_UNITS, seed=1)
+    x = _pixels(3, (112, 112), seed=0)
+    got = fm.process(x)
+    ref = ir_resnet.embed(params, x, batch=3)
+    d = _cos_dist(got, ref)
+    assert d.max() < COS_TOL, d
+    # the reference's per-image path: get_input (HWC->CHW) + get_feature, batch 1
+    one = fm.model.get_feature(fm.model.get_input(x[1]))
+    assert one.shape == (512,)
+    assert np.array_equal(one, got[1])
+    assert fm.process(np.zeros((0, 112, 112, 3), np.float32)).shape == (0, 512)
+
+
+def test_profile_reports_every_launch(gpu):
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import ir_resnet
+    size = (32, 32)
+    units = (1, 2, 1, 1)
+    params = W.synthetic_ir_params(units, size=size, seed=3)
+    bb = IRBackbone(params, image_size=size, max_batch=4)
+    x = torch.from_numpy(_pixels(4, size)).cuda()
+    prof = bb.profile(x)
+    kinds = [k for k, _, _ in prof]
+    assert kinds[0] == 0 and kinds[-1] == 3 and kinds[-2] == 2
+    assert kinds.count(1) == sum(units) * 2 + 4
+    total = sum(f for _, _, f in prof)
+    assert abs(total / 4 - ir_resnet.flops_per_image(units, size=32)) < 1e-6 * total
+    assert all(ms >= 0 for _, ms, _ in prof)
+
+
+def test_error_paths(gpu):
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    size = (32, 32)
+    params = W.synthetic_ir_params((1, 1, 1, 1), size=size)
+    bad = dict(params)
+    del bad["stage2_unit1_sc_beta"]
+    with pytest.raises(KeyError):
+        IRBackbone(bad, image_size=size)
+    bad = dict(params)
+    bad["bn0_gamma"] = np.zeros(63, np.float32)
+    with pytest.raises(gpu.AlinkError):
+        IRBackbone(bad, image_size=size)
+    bb = IRBackbone(params, image_size=size)
+    with pytest.raises(ValueError):
+        bb.embed(np.zeros((2, 31, 32, 3), np.float32))

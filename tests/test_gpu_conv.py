@@ -1,0 +1,83 @@
+"""GPU parity of the implicit-GEMM convolution kernel (conv_igemm.hip) through the C ABI
+(alink_conv_nhwc) against a CPU f32 convolution of the same (bf16/f16-rounded) operands."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, H, W, Cin, Cout, ksz, stride, pad, border, alpha, resid
+    (2, 14, 14, 64, 64, 3, 1, 1, 1, 1, 0),      # unit conv1: border classes + PReLU, 256x64 tile
+    (2, 14, 14, 64, 64, 3, 2, 1, 0, 0, 1),      # unit conv2 stride 2 + residual
+    (1, 12, 10, 128, 128, 3, 1, 1, 1, 1, 0),    # 128x128 tile, ragged M (120 pixels)
+    (3, 8, 8, 64, 128, 1, 2, 0, 0, 0, 0),       # 1x1 stride-2 shortcut
+    (2, 7, 7, 256, 256, 3, 1, 1, 0, 0, 1),      # stage-4 like, K = 2304
+    (1, 9, 9, 128, 64, 3, 2, 1, 0, 0, 0),       # odd size, stride 2
+    (5, 16, 16, 64, 192, 3, 1, 1, 1, 1, 1),     # Cout not a multiple of 128 -> 256x64 tile path
+]
+
+
+def _ref(x, w, bias, alpha, resid, stride, pad, border):
+    y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    N, Ho, Wo, Co = y.shape
+    if border:
+        rc = torch.ones(Ho, dtype=torch.long); rc[0] = 0; rc[-1] = 2
+        cc = torch.ones(Wo, dtype=torch.long); cc[0] = 0; cc[-1] = 2
+        cls = rc[:, None] * 3 + cc[None, :]
+        y = y + bias[cls]                      # (Ho,Wo,Co) broadcast over N
+    else:
+        y = y + bias[0]
+    if alpha is not None:
+        y = torch.where(y > 0, y, y * alpha)
+    if resid is not None:
+        y = y + resid
+    return y
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("dma", [1, 0])
+def test_conv_matches_cpu(gpu, dt, dma):
+    lib = gpu.load()
+    lib.alink_debug_set_dma(dma)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    code = gpu.DT_BF16 if dt == "bf16" else gpu.DT_F16
+    g = torch.Generator().manual_seed(1234)
+    try:
+        for (N, H, W, Ci, Co, k, s, p, border, use_alpha, use_resid) in CASES:
+            x = (torch.randn(N, H, W, Ci, generator=g)).to(tdt)
+            w = (torch.randn(Co, k, k, Ci, generator=g) * (1.0 / np.sqrt(k * k * Ci))).to(tdt)
+            ncls = 9 if border else 1
+            bias = torch.randn(ncls, Co, generator=g)
+            alpha = torch.rand(Co, generator=g) * 0.5 if use_alpha else None
+            Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+            resid = torch.randn(N, Ho, Wo, Co, generator=g).to(tdt) if use_resid else None
+            ref = _ref(x.float(), w.float(), bias, alpha, resid.float() if use_resid else None, s, p, border)
+            xd, wd, bd = x.cuda(), w.cuda(), bias.cuda()
+            ad = alpha.cuda() if use_alpha else None
+            rd = resid.cuda() if use_resid else None
+            out = torch.full((N, Ho, Wo, Co), float("nan"), dtype=tdt, device="cuda")
+            rc = lib.alink_conv_nhwc(code, gpu.ptr(xd), gpu.ptr(wd), gpu.ptr(bd), gpu.ptr(ad), gpu.ptr(rd),
+                                     gpu.ptr(out), N, H, W, Ci, Co, k, s, p, border, None)
+            gpu.check(rc, "alink_conv_nhwc")
+            got = out.float().cpu()
+            assert torch.isfinite(got).all(), (N, H, W, Ci, Co, k, s)
+            # output rounding of T (2^-9 bf16 / 2^-12 f16 relative) + accumulation-order noise
+            rel = 2.0 ** -8 if dt == "bf16" else 2.0 ** -10
+            err = (got - ref).abs()
+            tol = rel * ref.abs() + 2e-3
+            assert (err <= tol).all(), "case %s dt=%s dma=%d: max err %.4g" % (
+                (N, H, W, Ci, Co, k, s, p, border), dt, dma, float((err - tol).max()))
+    finally:
+        lib.alink_debug_set_dma(1)
+
+
+def test_conv_rejects_bad_shapes(gpu):
+    lib = gpu.load()
+    x = torch.zeros(1, 4, 4, 32, dtype=torch.bfloat16, device="cuda")
+    rc = lib.alink_conv_nhwc(0, gpu.ptr(x), gpu.ptr(x), gpu.ptr(x), None, None, gpu.ptr(x),
+                             1, 4, 4, 32, 64, 3, 1, 1, 0, None)
+    assert rc == -1 and b"multiples of 64" in lib.alink_last_error()

@@ -1,0 +1,130 @@
+"""GPU parity of the siamese head (head.hip) against the NumPy oracle (oracle/siamese_head.py):
+forward (f32 MFMA), pair gather, committee mean, train_on_batch / test_on_batch, fit()."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(n, d, seed):
+    rng = np.random.RandomState(seed)
+    L = rng.randn(n, d).astype(np.float32)
+    R = rng.randn(n, d).astype(np.float32)
+    L /= np.linalg.norm(L, axis=1, keepdims=True)
+    R /= np.linalg.norm(R, axis=1, keepdims=True)
+    return L, R
+
+
+def _pair(d=512, h1=512, h2=64, seed=11, lr=0.1):
+    from a_link_amd.head import DenseHead
+    from oracle import siamese_head as O
+    o = O.HeadModel(d, h1, h2, lr=lr, seed=seed)
+    # make the biases non-zero so the bias path is exercised
+    rng = np.random.RandomState(seed + 1)
+    ws = o.get_weights()
+    for i in (1, 3, 5):
+        ws[i] = (rng.randn(*ws[i].shape) * 0.1).astype(np.float32)
+    o.set_weights(ws)
+    g = DenseHead(d, h1, h2, lr=lr, seed=seed)
+    g.set_weights(ws)
+    return g, o
+
+
+@pytest.mark.parametrize("d,h1,h2", [(512, 512, 64), (2048, 512, 64), (2048, 128, 32), (64, 256, 64)])
+def test_forward_matches_oracle(gpu, d, h1, h2):
+    g, o = _pair(d, h1, h2)
+    for n in (1, 31, 32, 33, 1000):
+        L, R = _data(n, d, n)
+        got = g.predict([L, R])
+        ref = o.predict([L, R])
+        assert got.shape == (n, 2)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(got.sum(1), 1.0, atol=1e-6)
+
+
+def test_get_set_weights_roundtrip(gpu):
+    g, o = _pair()
+    for a, b in zip(g.get_weights(), o.get_weights()):
+        assert np.array_equal(a, b)
+
+
+def test_indexed_gather_equals_materialised_pairs(gpu):
+    g, o = _pair()
+    E, _ = _data(300, 512, 5)
+    rng = np.random.RandomState(0)
+    li = rng.randint(0, 300, 5000).astype(np.int32)
+    ri = rng.randint(0, 300, 5000).astype(np.int32)
+    a = g.predict_device(E, E, li, ri).cpu().numpy()
+    b = g.predict([E[li], E[ri]])
+    assert np.array_equal(a, b)
+    np.testing.assert_allclose(a, o.predict([E[li], E[ri]]), atol=2e-6)
+
+
+def test_committee_mean(gpu):
+    from a_link_amd import committee, siamese
+    from oracle import siamese_head as O
+    members = [siamese.SiameseNetwork((512,), "m%d" % i, 0.1, seed=i) for i in range(3)]
+    L, R = _data(777, 512, 3)
+    bag = committee.Bagging(members, [])
+    got = bag.predict([L, R])
+    each = [m.predict([L, R]) for m in members]
+    ref = O.bagging_predict(each)           # the reference's own host arithmetic on member outputs
+    np.testing.assert_allclose(got, ref, atol=1e-7)
+    oracle_members = []
+    for m in members:
+        om = O.HeadModel(512)
+        om.set_weights(m.siamese_net.get_weights())
+        oracle_members.append(om.predict([L, R]))
+    np.testing.assert_allclose(got, O.bagging_predict(oracle_members), atol=2e-6)
+
+
+def test_train_on_batch_and_eval(gpu):
+    from oracle import siamese_head as O
+    g, o = _pair(lr=0.1)
+    rng = np.random.RandomState(4)
+    for step in range(5):
+        n = [16, 13, 16, 7, 1][step]
+        L, R = _data(n, 512, 100 + step)
+        y = O.to_categorical(rng.randint(0, 2, n))
+        cw = None if step % 2 == 0 else {0: 1.0 / 3, 1: 2.0 / 3}
+        mg = g.train_on_batch([L, R], y, class_weight=cw)
+        mo = o.train_on_batch([L, R], y, class_weight=cw)
+        np.testing.assert_allclose(mg, mo, rtol=2e-5, atol=1e-6)
+        for a, b in zip(g.get_weights(), o.get_weights()):
+            np.testing.assert_allclose(a, b, rtol=0, atol=3e-6)
+        tg = g.test_on_batch([L, R], y)
+        to = o.test_on_batch([L, R], y)
+        np.testing.assert_allclose(tg, to, rtol=2e-5, atol=1e-6)
+
+
+def test_finetune_matches_keras_semantics(gpu):
+    """SiameseNetwork.finetune (reference code/siamese.py:52-58): to_categorical, fit(bs=16, epochs=3,
+    validation_split=.2): same np.random stream -> same shuffles -> same weights as the oracle."""
+    from a_link_amd import siamese
+    from oracle import siamese_head as O
+    net = siamese.SiameseNetwork((512,), "ft", 0.1, seed=21)
+    o = O.HeadModel(512, lr=0.1, seed=21)
+    o.set_weights(net.siamese_net.get_weights())
+    L, R = _data(150, 512, 9)
+    Y = (np.random.RandomState(1).rand(150, 1) > 0.5).astype(int)
+    np.random.seed(77)
+    hg = net.finetune([L, R], Y, 3, 16, verbose=0)
+    np.random.seed(77)
+    ho = O.finetune(o, [L, R], Y, 3, 16)
+    for k in ("loss", "acc", "val_loss", "val_acc"):
+        np.testing.assert_allclose(hg[k], ho[k], rtol=1e-4, atol=1e-5)
+    for a, b in zip(net.siamese_net.get_weights(), o.get_weights()):
+        np.testing.assert_allclose(a, b, atol=2e-5)
+    np.testing.assert_allclose(net.predict([L, R]), o.predict([L, R]), atol=1e-5)
+
+
+def test_save_load_roundtrip(gpu, tmp_path):
+    from a_link_amd import siamese
+    a = siamese.SiameseNetwork((512,), str(tmp_path / "model_a"), 0.1, seed=1)
+    b = siamese.SiameseNetwork((512,), str(tmp_path / "model_a"), 0.1, seed=2)
+    assert not b.maybeLoadFromMemory()          # nothing saved yet -> False, like the reference
+    a.save()
+    assert b.maybeLoadFromMemory()
+    L, R = _data(10, 512, 0)
+    assert np.array_equal(a.predict([L, R]), b.predict([L, R]))
