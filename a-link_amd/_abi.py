@@ -71,6 +71,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported first: it ships its own libamdhip64, and the library has to bind to
+    # THAT runtime instance (we are handed torch's streams and device pointers).  Loading ours first
+    # pulls in the system runtime as a second copy, which then sees no device.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise AlinkError(
             "libalink_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "

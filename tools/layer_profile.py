@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Per-launch timing table of one backbone forward (HIP events through alink_embed_profile)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import a_link_amd  # noqa
+from a_link_amd import weights as W
+from a_link_amd.backbone import IRBackbone
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="r100")
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+units = W.ARCH_UNITS[a.model]
+bb = IRBackbone(W.synthetic_ir_params(units, seed=1), dtype=a.dtype, max_batch=a.batch)
+x = torch.randint(0, 256, (a.batch, 112, 112, 3), dtype=torch.uint8).float().cuda()
+for _ in range(2):
+    bb.embed_device(x)
+profs = [bb.profile(x) for _ in range(a.reps)]
+ms = np.median(np.array([[m for _, m, _ in p] for p in profs]), axis=0)
+kinds = [k for k, _, _ in profs[0]]
+fl = [f for _, _, f in profs[0]]
+# group identical (kind, flops) launches
+names = ["stem"]
+for s in range(4):
+    for u in range(units[s]):
+        names.append("s%du%d_conv1" % (s + 1, u + 1))
+        if u == 0:
+            names.append("s%du%d_sc" % (s + 1, u + 1))
+        names.append("s%du%d_conv2" % (s + 1, u + 1))
+names += ["fc_splitk", "fc_finish"]
+tot = ms.sum()
+print("total %.3f ms  -> %.0f emb/s ; conv %.3f ms %.1f TF/s" % (
+    tot, a.batch / tot * 1e3, sum(m for m, k in zip(ms, kinds) if k == 1),
+    sum(f for f, k in zip(fl, kinds) if k == 1) / sum(m for m, k in zip(ms, kinds) if k == 1) / 1e9))
+agg = {}
+for n, m, f in zip(names, ms, fl):
+    key = n if ("u1_" in n or n in ("stem", "fc_splitk", "fc_finish")) else n.split("u")[0] + "uN_" + n.split("_")[1]
+    d = agg.setdefault(key, [0, 0.0, 0.0])
+    d[0] += 1; d[1] += m; d[2] += f
+print("%-14s %4s %9s %7s %9s %6s" % ("layer", "n", "ms_total", "ms_each", "TF/s", "%time"))
+for k, (n, m, f) in agg.items():
+    print("%-14s %4d %9.3f %7.3f %9.1f %6.1f" % (k, n, m, m / n, f / m / 1e9 if m > 0 else 0, 100 * m / tot))
