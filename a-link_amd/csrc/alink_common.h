@@ -49,6 +49,8 @@ struct ConvParams {
     int border_cls;       // bias class chosen by output position (3x3, stride 1, pad 1 only)
     int splitk;           // 1 = fused epilogue; >1 = f32 partial slabs
     int ksteps_per_split;
+    int ablate;           // diagnostic timing-only modes of conv3x3_direct (0 = normal)
+    void* stamps;         // diagnostic: 4 x u64 s_memtime stamps per workgroup, or nullptr
 };
 
 // Launchers (host).  All enqueue on `stream` and return a HIP error.
@@ -79,6 +81,21 @@ static inline int perm64_row_of_channel(int c) {
     int q = c >> 4, t = (c >> 2) & 3, j = c & 3;
     return 16 * t + 4 * q + j;
 }
+// same for kernels whose waves own 32 channels (2 MFMA tiles): tile t (0..1), row 4q+j <-> 8q + 4t + j
+static inline int perm32_row_of_channel(int c) {
+    int q = c >> 3, t = (c >> 2) & 1, j = c & 3;
+    return 16 * t + 4 * q + j;
+}
+// weight row of output channel co for a kernel whose lanes hold `cpl` (16 | 8) consecutive channels
+static inline int permuted_row(int co, int cpl) {
+    return cpl == 16 ? (co & ~63) + perm64_row_of_channel(co & 63) : (co & ~31) + perm32_row_of_channel(co & 31);
+}
+
+// conv3x3_direct.hip
+int        direct_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout);
+int        direct_variant_cpl(int v);
+hipError_t direct_set_attributes();
+hipError_t launch_conv3x3_direct(int variant, int dtype, const ConvParams& p, hipStream_t st);
 
 // host-side conversions
 uint16_t f32_to_bf16_rne(float f);

@@ -66,6 +66,8 @@ hipError_t conv_set_attributes();
 int init_kernels() {
     hipError_t e = conv_set_attributes();
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute", __FILE__, __LINE__);
+    e = direct_set_attributes();
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(direct)", __FILE__, __LINE__);
     return ALINK_OK;
 }
 
@@ -75,6 +77,7 @@ struct BN { std::vector<double> a, b; };   // y = a*x + b
 struct ConvLayer {
     int Cin, Cout, ksz, stride, pad, Hin, Win, Hout, Wout;
     bool border_cls, has_alpha;
+    int variant = 0;                       // conv3x3_direct variant (0 = conv_igemm)
     int in_buf, out_buf, resid_buf;        // workspace buffer ids, -1 = none
     void*  d_w = nullptr;                   // T [Cout][K] permuted
     float* d_bias = nullptr;                // [ncls][Cout]
@@ -149,17 +152,23 @@ int upload(alink_backbone* bb, const std::vector<V>& h, void** d) {
 int build_conv(alink_backbone* bb, ConvLayer& L, const std::vector<float>& w, const BN* pre,
                const BN& post, const std::vector<float>* prelu) {
     const int O = L.Cout, I = L.Cin, k = L.ksz, K = k * k * I, dt = bb->cfg.dtype;
+    L.variant = direct_variant(L.ksz, L.stride, L.pad, L.Hin, L.Win, L.Cin, L.Cout);
+    const int cpl = L.variant ? direct_variant_cpl(L.variant) : 16;
     std::vector<uint16_t> wq((size_t)O * K);
     std::vector<double> tapb((size_t)k * k * O, 0.0);          // [tap][co] shift contribution
     for (int co = 0; co < O; ++co) {
-        const int blk = co & ~63, row = blk + perm64_row_of_channel(co & 63);
+        const int row = permuted_row(co, cpl);
         for (int ky = 0; ky < k; ++ky)
             for (int kx = 0; kx < k; ++kx) {
                 double tb = 0.0;
                 for (int ci = 0; ci < I; ++ci) {
                     const double wv = (double)w[(((size_t)co * I + ci) * k + ky) * k + kx];
                     const double ai = pre ? pre->a[ci] : 1.0;
-                    wq[(size_t)row * K + (size_t)(ky * k + kx) * I + ci] = cvt(dt, (float)(post.a[co] * wv * ai));
+                    // K order: conv_igemm walks tap-major [tap][ci]; conv3x3_direct walks 64-channel
+                    // chunks outermost [ci/64][tap][ci%64]
+                    const size_t kidx = L.variant ? ((size_t)(ci >> 6) * 9 + (ky * 3 + kx)) * 64 + (ci & 63)
+                                                  : (size_t)(ky * k + kx) * I + ci;
+                    wq[(size_t)row * K + kidx] = cvt(dt, (float)(post.a[co] * wv * ai));
                     if (pre) tb += wv * pre->b[ci];
                 }
                 tapb[(size_t)(ky * k + kx) * O + co] = post.a[co] * tb;
@@ -448,6 +457,11 @@ size_t alink_backbone_workspace_bytes(const alink_backbone_t* bb, int n_images) 
     return total;
 }
 
+int g_ablate = 0;
+void* g_stamps = nullptr;
+extern "C" void alink_debug_set_ablate(int a) { g_ablate = a; }
+extern "C" void alink_debug_set_stamps(void* p) { g_stamps = p; }
+
 static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int N, float* dev_out,
                       void* ws, size_t ws_bytes, hipStream_t stream, float* ms, double* flops, int* kind,
                       int* n_launches) {
@@ -501,7 +515,9 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         p.stride = L.stride; p.ksz = L.ksz; p.pad = L.pad; p.M = N * L.Hout * L.Wout;
         p.border_cls = L.border_cls ? 1 : 0; p.splitk = 1;
         p.ksteps_per_split = L.ksz * L.ksz * (L.Cin / 64);
-        ALINK_HIP(launch_conv_igemm(cfg.dtype, p, stream));
+        p.ablate = g_ablate;
+        if (L.variant) ALINK_HIP(launch_conv3x3_direct(L.variant, cfg.dtype, p, stream));
+        else           ALINK_HIP(launch_conv_igemm(cfg.dtype, p, stream));
         note(conv_flops(p), 1);
         if ((rc = mark())) return rc;
         last_out = L.out_buf;
@@ -571,9 +587,14 @@ int alink_conv_nhwc(int dtype, const void* dev_in, const void* dev_w, const floa
     std::vector<uint16_t> h((size_t)Cout * K), hp((size_t)Cout * K);
     ALINK_HIP(hipStreamSynchronize(st));
     ALINK_HIP(hipMemcpy(h.data(), dev_w, h.size() * 2, hipMemcpyDeviceToHost));
+    const int variant = direct_variant(ksz, stride, pad, H, W, Cin, Cout);
+    const int cpl = variant ? direct_variant_cpl(variant) : 16;
     for (int co = 0; co < Cout; ++co) {
-        const int row = (co & ~63) + perm64_row_of_channel(co & 63);
-        memcpy(&hp[(size_t)row * K], &h[(size_t)co * K], (size_t)K * 2);
+        const size_t r = (size_t)permuted_row(co, cpl) * K;
+        if (!variant) { memcpy(&hp[r], &h[(size_t)co * K], (size_t)K * 2); continue; }
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ci = 0; ci < Cin; ++ci)
+                hp[r + ((size_t)(ci >> 6) * 9 + tap) * 64 + (ci & 63)] = h[(size_t)co * K + (size_t)tap * Cin + ci];
     }
     void *d_wp = nullptr, *d_zero = nullptr;
     ALINK_HIP(hipMalloc(&d_wp, hp.size() * 2));
@@ -586,7 +607,8 @@ int alink_conv_nhwc(int dtype, const void* dev_in, const void* dev_w, const floa
     p.Ho = conv_out(H, ksz, stride, pad); p.Wo = conv_out(W, ksz, stride, pad);
     p.stride = stride; p.ksz = ksz; p.pad = pad; p.M = N * p.Ho * p.Wo; p.border_cls = border_cls;
     p.splitk = 1; p.ksteps_per_split = ksz * ksz * (Cin / 64);
-    hipError_t e = launch_conv_igemm(dtype, p, st);
+    p.ablate = g_ablate; p.stamps = g_stamps;
+    hipError_t e = variant ? launch_conv3x3_direct(variant, dtype, p, st) : launch_conv_igemm(dtype, p, st);
     hipError_t e2 = hipStreamSynchronize(st);
     (void)hipFree(d_wp);
     (void)hipFree(d_zero);

@@ -215,6 +215,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         return;
     }
 
+    // All residual loads first (independent: one exposed latency instead of one per pixel tile), then
+    // bias (by border class) / PReLU / add / store.
+    const int HoWo = p.Ho * p.Wo;
+    size_t off[4];
+    bool ok[4];
+    int cls[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int m = m0 + wp * 64 + 16 * u + lr;
+        ok[u] = m < p.M;
+        const int mc = ok[u] ? m : p.M - 1;
+        off[u] = (size_t)mc * p.Cout + cbase;
+        cls[u] = 0;
+        if (p.border_cls) {
+            const int rem = mc % HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int rc = (oy == 0) ? 0 : ((oy == p.Ho - 1) ? 2 : 1);
+            const int cc = (ox == 0) ? 0 : ((ox == p.Wo - 1) ? 2 : 1);
+            cls[u] = rc * 3 + cc;
+        }
+    }
+    vec8 res[4][2];
+    if (p.resid) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            res[u][0] = *(const vec8*)((const T*)p.resid + off[u]);
+            res[u][1] = *(const vec8*)((const T*)p.resid + off[u] + 8);
+        }
+    }
+    f32x4 bia[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bia[u][t] = *(const f32x4*)(p.bias + cls[u] * p.Cout + cbase + 4 * t);
     float al[16];
     if (p.alpha) {
 #pragma unroll
@@ -224,49 +258,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             for (int j = 0; j < 4; ++j) al[4 * t + j] = a4[j];
         }
     }
-    const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int m = m0 + wp * 64 + 16 * u + lr;
-        if (m >= p.M) continue;
-        int cls = 0;
-        if (p.border_cls) {
-            const int rem = m % HoWo;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            const int rc = (oy == 0) ? 0 : ((oy == p.Ho - 1) ? 2 : 1);
-            const int cc = (ox == 0) ? 0 : ((ox == p.Wo - 1) ? 2 : 1);
-            cls = rc * 3 + cc;
-        }
-        const float* bp = p.bias + cls * p.Cout + cbase;
         float v[16];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f32x4 b4 = *(const f32x4*)(bp + 4 * t);
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * t + j] = acc[t][u][j] + b4[j];
-        }
+            for (int j = 0; j < 4; ++j) v[4 * t + j] = acc[t][u][j] + bia[u][t][j];
         if (p.alpha) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * al[i];
         }
-        const size_t o = (size_t)m * p.Cout + cbase;
         if (p.resid) {
-            const vec8 r0 = *(const vec8*)((const T*)p.resid + o);
-            const vec8 r1 = *(const vec8*)((const T*)p.resid + o + 8);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                v[i] += (float)r0[i];
-                v[8 + i] += (float)r1[i];
+                v[i] += (float)res[u][0][i];
+                v[8 + i] += (float)res[u][1][i];
             }
         }
-        vec8 o0, o1;
+        if (ok[u]) {
+            vec8 o0, o1;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            o0[i] = (T)v[i];
-            o1[i] = (T)v[8 + i];
+            for (int i = 0; i < 8; ++i) {
+                o0[i] = (T)v[i];
+                o1[i] = (T)v[8 + i];
+            }
+            *(vec8*)((T*)p.out + off[u]) = o0;
+            *(vec8*)((T*)p.out + off[u] + 8) = o1;
         }
-        *(vec8*)((T*)p.out + o) = o0;
-        *(vec8*)((T*)p.out + o + 8) = o1;
     }
 }
 

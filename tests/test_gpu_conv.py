@@ -18,6 +18,17 @@ CASES = [
     (2, 7, 7, 256, 256, 3, 1, 1, 0, 0, 1),      # stage-4 like, K = 2304
     (1, 9, 9, 128, 64, 3, 2, 1, 0, 0, 0),       # odd size, stride 2
     (5, 16, 16, 64, 192, 3, 1, 1, 1, 1, 1),     # Cout not a multiple of 128 -> 256x64 tile path
+    # shapes served by conv3x3_direct.hip (input tile resident in LDS), one per variant D1..D6
+    (3, 14, 14, 256, 256, 3, 1, 1, 1, 1, 0),    # D1: stage-3 conv1 (border classes + PReLU)
+    (2, 14, 14, 128, 512, 3, 1, 1, 0, 0, 1),    # D1: two channel tiles, residual, Cin = 2 chunks
+    (2, 28, 28, 128, 256, 3, 1, 1, 1, 1, 0),    # D2
+    (2, 28, 28, 128, 128, 3, 1, 1, 0, 0, 1),    # D3: stage-2 conv2-like
+    (1, 28, 28, 64, 128, 3, 1, 1, 1, 1, 1),     # D3 with a single input chunk
+    (2, 56, 56, 64, 128, 3, 1, 1, 1, 1, 0),     # D4
+    (2, 56, 56, 64, 64, 3, 1, 1, 1, 1, 1),      # D5: stage 1
+    (1, 112, 112, 64, 64, 3, 1, 1, 1, 1, 0),    # D6: stage-1 unit-1 conv1
+    (2, 13, 14, 64, 256, 3, 1, 1, 1, 0, 0),     # D1 with a ragged row count (H not a multiple of R)
+    (1, 30, 28, 64, 128, 3, 1, 1, 0, 1, 0),     # D3 ragged rows
 ]
 
 
