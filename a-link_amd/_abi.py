@@ -57,6 +57,19 @@ PROTOTYPES = {
     "alink_head_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp]),
     "alink_head_apply_update": (_i, [_vp, _vp]),
     "alink_head_eval": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "alink_head_input_grads": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "alink_smallres_create": (_vp, [_i, _i, _i, _f, _f, _f]),
+    "alink_smallres_destroy": (None, [_vp]),
+    "alink_smallres_num_params": (_sz, [_vp]),
+    "alink_smallres_set_params": (_i, [_vp, _vp, _sz]),
+    "alink_smallres_get_params": (_i, [_vp, _vp, _sz]),
+    "alink_smallres_set_lr": (_i, [_vp, _f]),
+    "alink_smallres_grads_dev": (_vp, [_vp]),
+    "alink_smallres_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "alink_smallres_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _f, _i, _vp, _vp]),
+    "alink_smallres_apply_update": (_i, [_vp, _vp]),
+    "alink_smallres_eval": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "alink_smallres_mask_sizes": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "alink_score": (_i, [_i, _vp, _vp, _i, _i64, _i, _vp, _vp]),
     "alink_topk_scratch_bytes": (_sz, [_i64, _i]),
     "alink_topk": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),

@@ -350,6 +350,23 @@ __global__ void dense_dgrad_kernel(const float* __restrict__ dz, const float* __
     dzin[i] = zin[i] > 0.f ? s : 0.f;
 }
 
+// d|l-r|/dl: dL[r][k] = sgn(L-R) * sum_c dz1[r][c] * W1[k][c];  dR = -dL   (tf.abs gradient: sign, 0 at 0)
+__global__ void head_input_grad_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                                       const float* __restrict__ dz1, const float* __restrict__ w1,
+                                       float* __restrict__ dL, float* __restrict__ dR, int n, int D, int h1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * D) return;
+    const int r = i / D, k = i - r * D;
+    const float* wr = w1 + (size_t)k * h1;
+    const float* dr = dz1 + (size_t)r * h1;
+    float s = 0.f;
+    for (int c = 0; c < h1; ++c) s = fmaf(dr[c], wr[c], s);
+    const float d = L[i] - R[i];
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    dL[i] = s * sg;
+    dR[i] = -s * sg;
+}
+
 __global__ void adadelta_kernel(float* __restrict__ prm, const float* __restrict__ g, float* __restrict__ a,
                                 float* __restrict__ d, size_t n, float lr, float rho, float eps) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -555,6 +572,16 @@ int alink_head_apply_update(alink_head_t* h, void* stream) {
                        h->d_params, h->d_grads, h->d_acc, h->d_dacc, h->nparams, h->lr, h->rho, h->eps);
     ALINK_HIP(hipGetLastError());
     h->packed_dirty = true;
+    return ALINK_OK;
+}
+
+int alink_head_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, int n, float* dev_dL,
+                           float* dev_dR, void* stream) {
+    ALINK_REQUIRE(h && dev_L && dev_R && dev_dL && dev_dR, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(n > 0 && n <= h->cap, ALINK_EINVAL, "batch of %d rows outside 1..%d", n, h->cap);
+    hipLaunchKernelGGL(head_input_grad_kernel, g1((long long)n * h->D), dim3(256), 0, (hipStream_t)stream, dev_L,
+                       dev_R, h->d_dz1, h->d_params + h->oW1, dev_dL, dev_dR, n, h->D, h->h1);
+    ALINK_HIP(hipGetLastError());
     return ALINK_OK;
 }
 

@@ -1,0 +1,486 @@
+// smallres.hip — SmallRes: the low-resolution siamese CNN that the Multi-PIE driver trains end to end.
+//
+// Replaces the Keras graph at reference code/siamese.py:134-170 and the calls made on it
+// (predict code/siamese.py:183-184; train_on_batch / test_on_batch via customTrainModel
+// code/siamese.py:81-112, called from code/ALINK_MTP.py:121; finetune code/siamese.py:52-58).
+// Keras semantics restated: Conv2D default padding 'valid' unless 'same'; MaxPooling2D 2x2 stride 2
+// (floor); Dropout(rate) in training multiplies kept units by 1/(1-rate); Flatten of NHWC is
+// (h, w, c)-major; Dense kernel (in,out).
+//
+// Sizes are tiny (32x32 or 48x48 inputs, batch 16 pairs = 32 tower passes, 24 MMAC each), the step is
+// latency-bound: plain f32 VALU kernels, one thread per output element, coalesced along channels.
+// The pair head (|l-r| -> 128 -> 32 -> 2) is an alink_head handle (head.hip); this file adds the
+// tower forward/backward and ties the two Adadelta states together.
+#include "alink_common.h"
+
+#include <vector>
+
+using namespace alink;
+
+extern "C" {
+int alink_head_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, int n, float* dev_dL,
+                           float* dev_dR, void* stream);
+}
+
+namespace {
+
+constexpr int MAXN = 256;           // pairs per call (host code chunks larger requests)
+
+inline dim3 g1(long long n) { return dim3((unsigned)((n + 255) / 256), 1, 1); }
+
+// out[n][oy][ox][co] = relu( b[co] + sum in[n][oy+ky-pad][ox+kx-pad][ci] * w[ky][kx][ci][co] )
+__global__ void conv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                const float* __restrict__ b, float* __restrict__ out, int N, int H, int W, int Ci,
+                                int Co, int pad, int prescale) {
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * Ho * Wo * Co) return;
+    const int co = (int)(i % Co);
+    long long r = i / Co;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float s = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy + ky - pad;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox + kx - pad;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const float* ip = in + (((size_t)n * H + iy) * W + ix) * Ci;
+            const float* wp = w + ((size_t)(ky * 3 + kx) * Ci) * Co + co;
+            for (int ci = 0; ci < Ci; ++ci) {
+                float x = ip[ci];
+                if (prescale) x = (x - 128.f) / 128.f;
+                s = fmaf(x, wp[(size_t)ci * Co], s);
+            }
+        }
+    }
+    out[i] = fmaxf(s + b[co], 0.f);
+}
+
+// 2x2/2 max pool (+ optional dropout: keep-mask u8, scale 1/(1-rate)); records the argmax (0..3)
+__global__ void pool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, uint8_t* __restrict__ arg,
+                                const uint8_t* __restrict__ mask, float scale, int N, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * Ho * Wo * C) return;
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float best = -INFINITY;
+    int bi = 0;
+    for (int k = 0; k < 4; ++k) {
+        const float v = in[(((size_t)n * H + 2 * oy + (k >> 1)) * W + 2 * ox + (k & 1)) * C + c];
+        if (v > best) { best = v; bi = k; }
+    }
+    if (arg) arg[i] = (uint8_t)bi;
+    if (mask) best = mask[i] ? best * scale : 0.f;
+    out[i] = best;
+}
+
+// din (pre-pool, post-relu tensor `act`) = relu'(act) * [argmax] * dropout * dpooled
+__global__ void pool_bwd_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ arg,
+                                const uint8_t* __restrict__ mask, float scale, const float* __restrict__ act,
+                                float* __restrict__ dact, int N, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * H * W * C) return;
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    float g = 0.f;
+    const int oy = y >> 1, ox = x >> 1;
+    if (oy < Ho && ox < Wo) {
+        const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + c;
+        if (arg[o] == ((y & 1) * 2 + (x & 1))) {
+            g = dpool[o];
+            if (mask) g = mask[o] ? g * scale : 0.f;
+        }
+    }
+    dact[i] = act[i] > 0.f ? g : 0.f;          // relu of the conv that produced `act`
+}
+
+// din[n][iy][ix][ci] = sum_{ky,kx,co} dz[n][iy-ky+pad][ix-kx+pad][co] * w[ky][kx][ci][co];
+// if act != nullptr the result is additionally masked by relu'(act) (act = din's own forward value)
+__global__ void conv_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                     const float* __restrict__ act, float* __restrict__ din, int N, int H, int W,
+                                     int Ci, int Co, int pad) {
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * H * W * Ci) return;
+    const int ci = (int)(i % Ci);
+    long long r = i / Ci;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const int n = (int)(r / H);
+    float s = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int oy = iy - ky + pad;
+        if ((unsigned)oy >= (unsigned)Ho) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ox = ix - kx + pad;
+            if ((unsigned)ox >= (unsigned)Wo) continue;
+            const float* dp = dz + (((size_t)n * Ho + oy) * Wo + ox) * Co;
+            const float* wp = w + ((size_t)(ky * 3 + kx) * Ci + ci) * Co;
+            for (int co = 0; co < Co; ++co) s = fmaf(dp[co], wp[co], s);
+        }
+    }
+    if (act) s = act[i] > 0.f ? s : 0.f;
+    din[i] = s;
+}
+
+// dw[ky][kx][ci][co] += sum over a chunk of (n,oy,ox);  db[co] likewise.  grid.y = pixel chunks,
+// partial sums combined with float atomics (dw/db zeroed before the launch).
+__global__ void conv_bwd_weight_kernel(const float* __restrict__ in, const float* __restrict__ dz,
+                                       float* __restrict__ dw, float* __restrict__ db, int N, int H, int W,
+                                       int Ci, int Co, int pad, int prescale, int chunk) {
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int total = 9 * Ci * Co;
+    const long long P = (long long)N * Ho * Wo;
+    const long long p0 = (long long)blockIdx.y * chunk, p1 = min(P, p0 + chunk);
+    if (i < total) {
+        const int co = i % Co;
+        int r = i / Co;
+        const int ci = r % Ci; r /= Ci;
+        const int kx = r % 3, ky = r / 3;
+        float s = 0.f;
+        for (long long pp = p0; pp < p1; ++pp) {
+            const int ox = (int)(pp % Wo);
+            const long long q = pp / Wo;
+            const int oy = (int)(q % Ho), n = (int)(q / Ho);
+            const int iy = oy + ky - pad, ix = ox + kx - pad;
+            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+            float x = in[(((size_t)n * H + iy) * W + ix) * Ci + ci];
+            if (prescale) x = (x - 128.f) / 128.f;
+            s = fmaf(x, dz[(size_t)pp * Co + co], s);
+        }
+        atomicAdd(dw + i, s);
+    } else if (i < total + Co) {
+        const int co = i - total;
+        float s = 0.f;
+        for (long long pp = p0; pp < p1; ++pp) s += dz[(size_t)pp * Co + co];
+        atomicAdd(db + co, s);
+    }
+}
+
+// z[r][c] = relu(sum_k a[r][k] w[k][c] + b[c])
+__global__ void dense_relu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                      const float* __restrict__ b, float* __restrict__ z, int n, int K, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * C) return;
+    const int r = i / C, c = i - r * C;
+    const float* ar = a + (size_t)r * K;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) s = fmaf(ar[k], w[(size_t)k * C + c], s);
+    z[i] = fmaxf(s + b[c], 0.f);
+}
+// dz = dout * relu'(z);  gw[k][c] = sum_r a[r][k] dz[r][c];  gb[c] = sum_r dz[r][c]
+__global__ void relu_mask_kernel(const float* __restrict__ z, const float* __restrict__ d, float* __restrict__ dz,
+                                 long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dz[i] = z[i] > 0.f ? d[i] : 0.f;
+}
+__global__ void dense_wgrad2_kernel(const float* __restrict__ a, const float* __restrict__ dz,
+                                    float* __restrict__ gw, float* __restrict__ gb, int n, int K, int C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < (long long)K * C) {
+        const int k = (int)(i / C), c = (int)(i - (long long)k * C);
+        float s = 0.f;
+        for (int r = 0; r < n; ++r) s = fmaf(a[(size_t)r * K + k], dz[(size_t)r * C + c], s);
+        gw[i] = s;
+    } else if (i < (long long)K * C + C) {
+        const int c = (int)(i - (long long)K * C);
+        float s = 0.f;
+        for (int r = 0; r < n; ++r) s += dz[(size_t)r * C + c];
+        gb[c] = s;
+    }
+}
+// da[r][k] = sum_c dz[r][c] w[k][c]
+__global__ void dense_dgrad2_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                    float* __restrict__ da, int n, int K, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * K) return;
+    const int r = i / K, k = i - r * K;
+    const float* wr = w + (size_t)k * C;
+    const float* dr = dz + (size_t)r * C;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(dr[c], wr[c], s);
+    da[i] = s;
+}
+__global__ void adadelta2_kernel(float* __restrict__ prm, const float* __restrict__ g, float* __restrict__ a,
+                                 float* __restrict__ d, size_t n, float lr, float rho, float eps) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float na = rho * a[i] + (1.f - rho) * gi * gi;
+    const float u = gi * sqrtf(d[i] + eps) / sqrtf(na + eps);
+    prm[i] = prm[i] - lr * u;
+    d[i] = rho * d[i] + (1.f - rho) * u * u;
+    a[i] = na;
+}
+
+}  // namespace
+
+struct alink_smallres {
+    int H, W, feat;
+    float lr, rho, eps;
+    // tower geometry
+    int H1, W1;      // after conv2 (valid): H-2
+    int P1h, P1w;    // after pool1
+    int H3, W3;      // after conv4 (valid): P1-2
+    int P2h, P2w;    // after pool2
+    int flat;
+    // tower parameter offsets in the flat buffer (Keras order)
+    size_t oW[4], oB[4], oDW, oDB, ntower;
+    alink_head_t* head = nullptr;      // |l-r| -> 128 -> 32 -> 2
+    float *d_p = nullptr, *d_g = nullptr, *d_a = nullptr, *d_d = nullptr;   // tower params / grads / Adadelta
+    // activations for up to 2*MAXN tower passes
+    float *a1 = nullptr, *a2 = nullptr, *p1 = nullptr, *a3 = nullptr, *a4 = nullptr, *p2 = nullptr, *f = nullptr;
+    float *da = nullptr, *db = nullptr;                                       // backward ping-pong
+    float *dfeat = nullptr;
+    uint8_t *arg1 = nullptr, *arg2 = nullptr;
+    float* d_all_grads = nullptr;      // [tower grads | head grads] contiguous copy for all-reduce
+    std::vector<void*> allocs;
+    ~alink_smallres() {
+        for (void* p : allocs) (void)hipFree(p);
+        if (head) alink_head_destroy(head);
+    }
+};
+
+namespace {
+
+template <typename V>
+int sr_alloc(alink_smallres* m, V** p, size_t count) {
+    ALINK_HIP(hipMalloc((void**)p, count * sizeof(V)));
+    m->allocs.push_back(*p);
+    ALINK_HIP(hipMemset(*p, 0, count * sizeof(V)));
+    return ALINK_OK;
+}
+
+const int CI[4] = {3, 32, 32, 64}, CO[4] = {32, 32, 64, 64}, PAD[4] = {1, 0, 1, 0};
+
+// tower forward on `nb` images; masks == nullptr -> inference (no dropout)
+int tower_fwd(alink_smallres* m, const float* img, int nb, int prescale, const uint8_t* mask1, const uint8_t* mask2,
+              hipStream_t st) {
+    const float* P = m->d_p;
+    const float keep_scale = 1.f / (1.f - 0.25f);
+    hipLaunchKernelGGL(conv_fwd_kernel, g1((long long)nb * m->H * m->W * 32), dim3(256), 0, st, img, P + m->oW[0],
+                       P + m->oB[0], m->a1, nb, m->H, m->W, 3, 32, 1, prescale);
+    hipLaunchKernelGGL(conv_fwd_kernel, g1((long long)nb * m->H1 * m->W1 * 32), dim3(256), 0, st, m->a1, P + m->oW[1],
+                       P + m->oB[1], m->a2, nb, m->H, m->W, 32, 32, 0, 0);
+    hipLaunchKernelGGL(pool_fwd_kernel, g1((long long)nb * m->P1h * m->P1w * 32), dim3(256), 0, st, m->a2, m->p1,
+                       m->arg1, mask1, keep_scale, nb, m->H1, m->W1, 32);
+    hipLaunchKernelGGL(conv_fwd_kernel, g1((long long)nb * m->P1h * m->P1w * 64), dim3(256), 0, st, m->p1, P + m->oW[2],
+                       P + m->oB[2], m->a3, nb, m->P1h, m->P1w, 32, 64, 1, 0);
+    hipLaunchKernelGGL(conv_fwd_kernel, g1((long long)nb * m->H3 * m->W3 * 64), dim3(256), 0, st, m->a3, P + m->oW[3],
+                       P + m->oB[3], m->a4, nb, m->P1h, m->P1w, 64, 64, 0, 0);
+    hipLaunchKernelGGL(pool_fwd_kernel, g1((long long)nb * m->P2h * m->P2w * 64), dim3(256), 0, st, m->a4, m->p2,
+                       m->arg2, mask2, keep_scale, nb, m->H3, m->W3, 64);
+    hipLaunchKernelGGL(dense_relu_fwd_kernel, g1((long long)nb * m->feat), dim3(256), 0, st, m->p2, P + m->oDW,
+                       P + m->oDB, m->f, nb, m->flat, m->feat);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+int wgrad(alink_smallres* m, const float* in, const float* dz, int layer, int nb, int H, int W, int prescale,
+          hipStream_t st) {
+    const int Ci = CI[layer], Co = CO[layer], pad = PAD[layer];
+    const long long P = (long long)nb * (H + 2 * pad - 2) * (W + 2 * pad - 2);
+    const int chunk = 1024;
+    dim3 grid((9 * Ci * Co + Co + 255) / 256, (unsigned)((P + chunk - 1) / chunk), 1);
+    hipLaunchKernelGGL(conv_bwd_weight_kernel, grid, dim3(256), 0, st, in, dz, m->d_g + m->oW[layer],
+                       m->d_g + m->oB[layer], nb, H, W, Ci, Co, pad, prescale, chunk);
+    return ALINK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+alink_smallres_t* alink_smallres_create(int img_h, int img_w, int feat, float lr, float rho, float eps) {
+    if (img_h < 12 || img_w < 12 || img_h > 128 || img_w > 128) { set_error("image size %dx%d unsupported", img_h, img_w); return nullptr; }
+    if (feat <= 0 || feat % 8) { set_error("feat must be a positive multiple of 8"); return nullptr; }
+    alink_smallres* m = new alink_smallres();
+    m->H = img_h; m->W = img_w; m->feat = feat; m->lr = lr; m->rho = rho; m->eps = eps;
+    m->H1 = img_h - 2; m->W1 = img_w - 2;
+    m->P1h = m->H1 / 2; m->P1w = m->W1 / 2;
+    m->H3 = m->P1h - 2; m->W3 = m->P1w - 2;
+    m->P2h = m->H3 / 2; m->P2w = m->W3 / 2;
+    m->flat = m->P2h * m->P2w * 64;
+    size_t o = 0;
+    for (int l = 0; l < 4; ++l) { m->oW[l] = o; o += (size_t)9 * CI[l] * CO[l]; m->oB[l] = o; o += CO[l]; }
+    m->oDW = o; o += (size_t)m->flat * feat; m->oDB = o; o += feat; m->ntower = o;
+    m->head = alink_head_create(feat, 128, 32, lr, rho, eps);
+    if (!m->head) { delete m; return nullptr; }
+    const size_t nb = 2 * MAXN;
+    int rc = 0;
+    rc |= sr_alloc(m, &m->d_p, m->ntower); rc |= sr_alloc(m, &m->d_g, m->ntower);
+    rc |= sr_alloc(m, &m->d_a, m->ntower); rc |= sr_alloc(m, &m->d_d, m->ntower);
+    rc |= sr_alloc(m, &m->a1, nb * img_h * img_w * 32);
+    rc |= sr_alloc(m, &m->a2, nb * m->H1 * m->W1 * 32);
+    rc |= sr_alloc(m, &m->p1, nb * m->P1h * m->P1w * 32);
+    rc |= sr_alloc(m, &m->a3, nb * m->P1h * m->P1w * 64);
+    rc |= sr_alloc(m, &m->a4, nb * m->H3 * m->W3 * 64);
+    rc |= sr_alloc(m, &m->p2, nb * m->flat);
+    rc |= sr_alloc(m, &m->f, nb * feat);
+    rc |= sr_alloc(m, &m->dfeat, nb * feat);
+    const size_t big = nb * (size_t)img_h * img_w * 32;
+    rc |= sr_alloc(m, &m->da, big > nb * feat ? big : nb * feat);
+    rc |= sr_alloc(m, &m->db, big > nb * feat ? big : nb * feat);
+    rc |= sr_alloc(m, &m->arg1, nb * m->P1h * m->P1w * 32);
+    rc |= sr_alloc(m, &m->arg2, nb * m->P2h * m->P2w * 64);
+    rc |= sr_alloc(m, &m->d_all_grads, m->ntower + alink_head_num_params(m->head));
+    if (rc) { delete m; return nullptr; }
+    return m;
+}
+
+void alink_smallres_destroy(alink_smallres_t* m) { delete m; }
+size_t alink_smallres_num_params(const alink_smallres_t* m) { return m ? m->ntower + alink_head_num_params(m->head) : 0; }
+
+int alink_smallres_set_params(alink_smallres_t* m, const float* host, size_t count) {
+    ALINK_REQUIRE(m && host, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(count == alink_smallres_num_params(m), ALINK_EINVAL, "expected %zu parameters, got %zu",
+                  alink_smallres_num_params(m), count);
+    ALINK_HIP(hipMemcpy(m->d_p, host, m->ntower * sizeof(float), hipMemcpyHostToDevice));
+    return alink_head_set_params(m->head, host + m->ntower, count - m->ntower);
+}
+int alink_smallres_get_params(const alink_smallres_t* m, float* host, size_t count) {
+    ALINK_REQUIRE(m && host, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(count == alink_smallres_num_params(m), ALINK_EINVAL, "bad parameter count");
+    ALINK_HIP(hipDeviceSynchronize());
+    ALINK_HIP(hipMemcpy(host, m->d_p, m->ntower * sizeof(float), hipMemcpyDeviceToHost));
+    return alink_head_get_params(m->head, host + m->ntower, count - m->ntower);
+}
+int alink_smallres_set_lr(alink_smallres_t* m, float lr) {
+    ALINK_REQUIRE(m && lr >= 0.f, ALINK_EINVAL, "bad lr");
+    m->lr = lr;
+    return alink_head_set_lr(m->head, lr);
+}
+float* alink_smallres_grads_dev(alink_smallres_t* m) { return m ? m->d_all_grads : nullptr; }
+
+int alink_smallres_mask_sizes(const alink_smallres_t* m, int* a, int* b) {
+    ALINK_REQUIRE(m && a && b, ALINK_EINVAL, "NULL argument");
+    *a = m->P1h * m->P1w * 32;
+    *b = m->P2h * m->P2w * 64;
+    return ALINK_OK;
+}
+
+// both inputs through the tower: features of L in f[0:n], of R in f[n:2n].  L and R are separate
+// buffers, so the tower runs on each (activation buffers hold 2n images: R's pass uses the upper half).
+static int tower_pair_fwd(alink_smallres* m, const float* L, const float* R, int n, int prescale,
+                          const uint8_t* masks, hipStream_t st, bool keep_both) {
+    // Run L then R with activation base pointers shifted so both sets of activations survive for the
+    // backward pass.  Implemented by temporarily offsetting the activation pointers.
+    alink_smallres s = *m;   // shallow copy of pointers (no ownership: allocs vector cleared below)
+    s.allocs.clear();
+    s.head = nullptr;
+    const uint8_t *m1 = nullptr, *m2 = nullptr;
+    const size_t e1 = (size_t)m->P1h * m->P1w * 32, e2 = (size_t)m->P2h * m->P2w * 64;
+    if (masks) { m1 = masks; m2 = masks + 2 * (size_t)n * e1; }
+    int rc = tower_fwd(&s, L, n, prescale, m1, m2, st);
+    if (rc) return rc;
+    (void)keep_both;
+    s.a1 += (size_t)n * m->H * m->W * 32;  s.a2 += (size_t)n * m->H1 * m->W1 * 32;
+    s.p1 += (size_t)n * e1;                s.a3 += (size_t)n * m->P1h * m->P1w * 64;
+    s.a4 += (size_t)n * m->H3 * m->W3 * 64; s.p2 += (size_t)n * m->flat;
+    s.f += (size_t)n * m->feat;            s.arg1 += (size_t)n * e1;  s.arg2 += (size_t)n * e2;
+    rc = tower_fwd(&s, R, n, prescale, m1 ? m1 + (size_t)n * e1 : nullptr, m2 ? m2 + (size_t)n * e2 : nullptr, st);
+    return rc;
+}
+
+int alink_smallres_forward(alink_smallres_t* m, const float* dev_L, const float* dev_R, int n, int prescale,
+                           float* dev_probs, void* stream) {
+    ALINK_REQUIRE(m && dev_L && dev_R && dev_probs, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = tower_pair_fwd(m, dev_L, dev_R, n, prescale, nullptr, st, false);
+    if (rc) return rc;
+    return alink_head_forward(m->head, m->f, m->f + (size_t)n * m->feat, nullptr, nullptr, n, dev_probs, stream);
+}
+
+int alink_smallres_eval(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y, int n,
+                        int prescale, float* dev_metrics, void* stream) {
+    ALINK_REQUIRE(m && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
+    int rc = tower_pair_fwd(m, dev_L, dev_R, n, prescale, nullptr, (hipStream_t)stream, false);
+    if (rc) return rc;
+    return alink_head_eval(m->head, m->f, m->f + (size_t)n * m->feat, dev_y, n, dev_metrics, stream);
+}
+
+int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
+                              const float* dev_sw, int n, int prescale, const uint8_t* dev_masks, float grad_scale,
+                              int apply, float* dev_metrics, void* stream) {
+    ALINK_REQUIRE(m && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = tower_pair_fwd(m, dev_L, dev_R, n, prescale, dev_masks, st, true);
+    if (rc) return rc;
+    float* fL = m->f;
+    float* fR = m->f + (size_t)n * m->feat;
+    if ((rc = alink_head_train_step(m->head, fL, fR, dev_y, dev_sw, n, grad_scale, 0, dev_metrics, stream))) return rc;
+    if ((rc = alink_head_input_grads(m->head, fL, fR, n, m->dfeat, m->dfeat + (size_t)n * m->feat, stream))) return rc;
+    // the shared tower sees 2n images: [L ; R] are contiguous in every activation buffer, so ONE
+    // backward pass over 2n images accumulates both branches' weight gradients.  The image buffers
+    // are separate, so conv1's weight gradient is taken per branch.
+    const size_t e1 = (size_t)m->P1h * m->P1w * 32, e2 = (size_t)m->P2h * m->P2w * 64;
+    const uint8_t* m1 = dev_masks;
+    const uint8_t* m2 = dev_masks ? dev_masks + 2 * (size_t)n * e1 : nullptr;
+    (void)e2;
+    // run the backward on 2n images but stop before conv1's weight gradient (needs the two image buffers)
+    {
+        const float* P = m->d_p;
+        float* G = m->d_g;
+        const int nb = 2 * n;
+        const float keep_scale = 1.f / (1.f - 0.25f);
+        ALINK_HIP(hipMemsetAsync(G, 0, m->oDW * sizeof(float), st));
+        hipLaunchKernelGGL(relu_mask_kernel, g1((long long)nb * m->feat), dim3(256), 0, st, m->f, m->dfeat, m->da,
+                           (long long)nb * m->feat);
+        hipLaunchKernelGGL(dense_wgrad2_kernel, g1((long long)m->flat * m->feat + m->feat), dim3(256), 0, st, m->p2,
+                           m->da, G + m->oDW, G + m->oDB, nb, m->flat, m->feat);
+        hipLaunchKernelGGL(dense_dgrad2_kernel, g1((long long)nb * m->flat), dim3(256), 0, st, m->da, P + m->oDW, m->db,
+                           nb, m->flat, m->feat);
+        hipLaunchKernelGGL(pool_bwd_kernel, g1((long long)nb * m->H3 * m->W3 * 64), dim3(256), 0, st, m->db, m->arg2, m2,
+                           keep_scale, m->a4, m->da, nb, m->H3, m->W3, 64);
+        wgrad(m, m->a3, m->da, 3, nb, m->P1h, m->P1w, 0, st);
+        hipLaunchKernelGGL(conv_bwd_data_kernel, g1((long long)nb * m->P1h * m->P1w * 64), dim3(256), 0, st, m->da,
+                           P + m->oW[3], m->a3, m->db, nb, m->P1h, m->P1w, 64, 64, 0);
+        wgrad(m, m->p1, m->db, 2, nb, m->P1h, m->P1w, 0, st);
+        hipLaunchKernelGGL(conv_bwd_data_kernel, g1((long long)nb * m->P1h * m->P1w * 32), dim3(256), 0, st, m->db,
+                           P + m->oW[2], (const float*)nullptr, m->da, nb, m->P1h, m->P1w, 32, 64, 1);
+        hipLaunchKernelGGL(pool_bwd_kernel, g1((long long)nb * m->H1 * m->W1 * 32), dim3(256), 0, st, m->da, m->arg1, m1,
+                           keep_scale, m->a2, m->db, nb, m->H1, m->W1, 32);
+        wgrad(m, m->a1, m->db, 1, nb, m->H, m->W, 0, st);
+        hipLaunchKernelGGL(conv_bwd_data_kernel, g1((long long)nb * m->H * m->W * 32), dim3(256), 0, st, m->db,
+                           P + m->oW[1], m->a1, m->da, nb, m->H, m->W, 32, 32, 0);
+        wgrad(m, dev_L, m->da, 0, n, m->H, m->W, prescale, st);
+        wgrad(m, dev_R, m->da + (size_t)n * m->H * m->W * 32, 0, n, m->H, m->W, prescale, st);
+        ALINK_HIP(hipGetLastError());
+    }
+    // contiguous gradient copy [tower | head] for the data-parallel all-reduce
+    ALINK_HIP(hipMemcpyAsync(m->d_all_grads, m->d_g, m->ntower * sizeof(float), hipMemcpyDeviceToDevice, st));
+    ALINK_HIP(hipMemcpyAsync(m->d_all_grads + m->ntower, alink_head_grads_dev(m->head),
+                             alink_head_num_params(m->head) * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (apply) return alink_smallres_apply_update(m, stream);
+    return ALINK_OK;
+}
+
+int alink_smallres_apply_update(alink_smallres_t* m, void* stream) {
+    ALINK_REQUIRE(m, ALINK_EINVAL, "NULL model");
+    hipStream_t st = (hipStream_t)stream;
+    // gradients are taken from the contiguous buffer (the caller may have all-reduced it)
+    hipLaunchKernelGGL(adadelta2_kernel, g1((long long)m->ntower), dim3(256), 0, st, m->d_p, m->d_all_grads, m->d_a,
+                       m->d_d, m->ntower, m->lr, m->rho, m->eps);
+    ALINK_HIP(hipGetLastError());
+    ALINK_HIP(hipMemcpyAsync(alink_head_grads_dev(m->head), m->d_all_grads + m->ntower,
+                             alink_head_num_params(m->head) * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return alink_head_apply_update(m->head, stream);
+}
+
+}  // extern "C"

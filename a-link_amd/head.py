@@ -77,7 +77,57 @@ class ReduceLROnPlateau(object):
             self.wait += 1
 
 
-class DenseHead(object):
+class KerasFitMixin(object):
+    """Keras 2.1.2 Model.fit for in-memory arrays on top of train_on_batch / test_on_batch
+    (reference code/siamese.py:57).  validation_split holds out the LAST fraction before shuffling;
+    np.random.shuffle(index_array) per epoch; epoch logs are batch-size-weighted means."""
+    stop_training = False
+
+    def fit(self, x, y, batch_size=32, epochs=1, verbose=1, callbacks=None, validation_split=0.0, shuffle=True):
+        L = np.asarray(x[0], dtype=np.float32)
+        R = np.asarray(x[1], dtype=np.float32)
+        y = np.asarray(y, dtype=np.float32)
+        n_all = L.shape[0]
+        if 0.0 < validation_split < 1.0:
+            split_at = int(n_all * (1.0 - validation_split))
+            vL, vR, vy = L[split_at:], R[split_at:], y[split_at:]
+            L, R, y = L[:split_at], R[:split_at], y[:split_at]
+        else:
+            vL = vR = vy = None
+        n = L.shape[0]
+        history = {}
+        self.stop_training = False
+        index_array = np.arange(n)
+        for epoch in range(epochs):
+            if shuffle:
+                np.random.shuffle(index_array)
+            tot, seen = np.zeros(2), 0
+            for s in range(0, n, batch_size):
+                ids = index_array[s:s + batch_size]
+                out = self.train_on_batch([L[ids], R[ids]], y[ids])
+                tot += np.asarray(out) * len(ids)
+                seen += len(ids)
+            logs = {"loss": tot[0] / seen, "acc": tot[1] / seen}
+            if vL is not None and len(vy) > 0:
+                vt, vs = np.zeros(2), 0
+                for s in range(0, len(vy), batch_size):
+                    out = self.test_on_batch([vL[s:s + batch_size], vR[s:s + batch_size]], vy[s:s + batch_size])
+                    k = len(vy[s:s + batch_size])
+                    vt += np.asarray(out) * k
+                    vs += k
+                logs["val_loss"], logs["val_acc"] = vt[0] / vs, vt[1] / vs
+            for cb in (callbacks or []):
+                cb.on_epoch_end(epoch, logs, self)
+            for k, v in logs.items():
+                history.setdefault(k, []).append(v)
+            if verbose:
+                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in sorted(logs.items())))
+            if self.stop_training:
+                break
+        return history
+
+
+class DenseHead(KerasFitMixin):
     """abs(l - r) -> Dense(h1, relu) -> Dense(h2, relu) -> Dense(2) -> softmax; BCE + Adadelta."""
 
     def __init__(self, d_in, h1=512, h2=64, lr=1.0, rho=0.95, eps=1e-8, seed=None, device=0):
@@ -233,55 +283,6 @@ class DenseHead(object):
                                             _abi.ptr(self._metrics), _abi.current_stream()), "alink_head_eval")
         m = self._metrics.cpu().numpy()
         return [float(m[0]), float(m[1])]
-
-    def fit(self, x, y, batch_size=32, epochs=1, verbose=1, callbacks=None, validation_split=0.0, shuffle=True):
-        """Keras 2.1.2 Model.fit for in-memory arrays (reference code/siamese.py:57)."""
-        L = np.asarray(x[0], dtype=np.float32)
-        R = np.asarray(x[1], dtype=np.float32)
-        y = np.asarray(y, dtype=np.float32)
-        n_all = L.shape[0]
-        if 0.0 < validation_split < 1.0:
-            split_at = int(n_all * (1.0 - validation_split))
-            vL, vR, vy = L[split_at:], R[split_at:], y[split_at:]
-            L, R, y = L[:split_at], R[:split_at], y[:split_at]
-        else:
-            vL = vR = vy = None
-        n = L.shape[0]
-        Ld, Rd, yd = self._dev(L), self._dev(R), self._dev(y)
-        torch = self.torch
-        history = {"loss": [], "acc": []}
-        if vL is not None:
-            history["val_loss"], history["val_acc"] = [], []
-        self.stop_training = False
-        index_array = np.arange(n)
-        for epoch in range(epochs):
-            if shuffle:
-                np.random.shuffle(index_array)
-            tot, seen = np.zeros(2), 0
-            for s in range(0, n, batch_size):
-                ids = index_array[s:s + batch_size]
-                idt = torch.from_numpy(ids.astype(np.int64)).to(self.device)
-                out = self.train_on_batch([Ld[idt], Rd[idt]], yd[idt])
-                tot += np.asarray(out) * len(ids)
-                seen += len(ids)
-            logs = {"loss": tot[0] / seen, "acc": tot[1] / seen}
-            if vL is not None and len(vy) > 0:
-                vt, vs = np.zeros(2), 0
-                for s in range(0, len(vy), batch_size):
-                    out = self.test_on_batch([vL[s:s + batch_size], vR[s:s + batch_size]], vy[s:s + batch_size])
-                    k = len(vy[s:s + batch_size])
-                    vt += np.asarray(out) * k
-                    vs += k
-                logs["val_loss"], logs["val_acc"] = vt[0] / vs, vt[1] / vs
-            for cb in (callbacks or []):
-                cb.on_epoch_end(epoch, logs, self)
-            for k, v in logs.items():
-                history.setdefault(k, []).append(v)
-            if verbose:
-                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in sorted(logs.items())))
-            if self.stop_training:
-                break
-        return history
 
 
 def committee_predict_device(heads, L, R, li=None, ri=None):

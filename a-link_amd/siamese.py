@@ -116,6 +116,30 @@ class SiameseNetwork:
         return self.siamese_net.predict(self.preprocess(X), batch_size=1024)
 
 
+class SmallRes(SiameseNetwork, object):
+    """code/siamese.py:134-184.  `preprocess` = (x - 128)/128 per side, applied by predict and finetune
+    (and by customTrainModel only when preprocess=True, code/siamese.py:88-89)."""
+    _identity_preprocess = False
+
+    def __init__(self, imageShape, featureShape, name, learningRate, seed=None, adadelta_epsilon=1e-8):
+        from .smallres import SmallResNet
+        self.learningRate = learningRate
+        self.shape = imageShape
+        self.modelName = name
+        self.siamese_net = SmallResNet(imageShape, featureShape[0], lr=learningRate, rho=0.95, eps=adadelta_epsilon,
+                                       seed=seed)
+
+    def getDenseBarebones(self):
+        return [(128, 'relu'), (32, 'relu'), (2, None)]
+
+    def preprocess(self, X):
+        X_temp = [(np.asarray(x, dtype=np.float32) - 128.) / 128. for x in X]
+        return X_temp
+
+    def predict(self, X):
+        return self.siamese_net.predict(self.preprocess(X), batch_size=1024)
+
+
 class ArcFace:
     def __init__(self, shape, model_path, dtype="bf16", max_batch=256):
         args = _Args({

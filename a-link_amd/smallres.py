@@ -1,0 +1,144 @@
+"""smallres — SmallRes, the end-to-end-trained low-resolution siamese CNN (reference
+code/siamese.py:134-184; driver code/ALINK_MTP.py:107,121,255).
+
+`SmallResNet` is the Keras-Model-like object (`siamese_net`): predict / train_on_batch / test_on_batch /
+fit / get_weights / set_weights / save_weights / load_weights, all on libalink_hip.so (smallres.hip).
+Dropout masks are drawn on the host with np.random (the reference's come from TensorFlow's op-level
+RNG, which cannot be reproduced; the distribution — keep probability 0.75, scale 1/0.75 — is the same).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from .head import KerasFitMixin, glorot_uniform
+
+MAXN = 256
+
+
+class SmallResNet(KerasFitMixin):
+    def __init__(self, image_shape, feat, lr=1.0, rho=0.95, eps=1e-8, seed=None, device=0, prescale=False):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _abi.AlinkError("no ROCm device visible: a-link_amd computes only on the GPU (no CPU fallback)")
+        self.device = "cuda:%d" % device
+        self.lib = _abi.init(device)
+        self.H, self.W = int(image_shape[0]), int(image_shape[1])
+        assert int(image_shape[2]) == 3
+        self.feat = int(feat)
+        self.h = self.lib.alink_smallres_create(self.H, self.W, self.feat, lr, rho, eps)
+        if not self.h:
+            raise _abi.AlinkError("alink_smallres_create: " + self.lib.alink_last_error().decode())
+        self.lr = lr
+        a, b = C.c_int(), C.c_int()
+        _abi.check(self.lib.alink_smallres_mask_sizes(self.h, C.byref(a), C.byref(b)))
+        self.mask_sizes = (a.value, b.value)
+        self.flat = b.value
+        self.training_dropout = True
+        rng = np.random.RandomState(seed) if seed is not None else np.random
+        ws = []
+        for ci, co in ((3, 32), (32, 32), (32, 64), (64, 64)):
+            lim = np.sqrt(6.0 / (9 * ci + 9 * co))               # glorot_uniform on (3,3,ci,co)
+            ws += [rng.uniform(-lim, lim, (3, 3, ci, co)).astype(np.float32), np.zeros(co, np.float32)]
+        ws += [glorot_uniform(rng, self.flat, self.feat), np.zeros(self.feat, np.float32)]
+        ws += [glorot_uniform(rng, self.feat, 128), np.zeros(128, np.float32), glorot_uniform(rng, 128, 32),
+               np.zeros(32, np.float32), glorot_uniform(rng, 32, 2), np.zeros(2, np.float32)]
+        self.set_weights(ws)
+        self._metrics = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self.prescale = 1 if prescale else 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.alink_smallres_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _shapes(self):
+        return [(3, 3, 3, 32), (32,), (3, 3, 32, 32), (32,), (3, 3, 32, 64), (64,), (3, 3, 64, 64), (64,),
+                (self.flat, self.feat), (self.feat,), (self.feat, 128), (128,), (128, 32), (32,), (32, 2), (2,)]
+
+    def set_weights(self, ws):
+        shapes = self._shapes()
+        assert len(ws) == len(shapes)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(w, np.float32).reshape(s).ravel()
+                                                    for w, s in zip(ws, shapes)]), dtype=np.float32)
+        _abi.check(self.lib.alink_smallres_set_params(self.h, _abi.ptr(flat), flat.size), "alink_smallres_set_params")
+
+    def get_weights(self):
+        n = self.lib.alink_smallres_num_params(self.h)
+        flat = np.empty(n, dtype=np.float32)
+        _abi.check(self.lib.alink_smallres_get_params(self.h, _abi.ptr(flat), n), "alink_smallres_get_params")
+        out, o = [], 0
+        for s in self._shapes():
+            k = int(np.prod(s))
+            out.append(flat[o:o + k].reshape(s).copy())
+            o += k
+        return out
+
+    def get_lr(self):
+        return self.lr
+
+    def set_lr(self, lr):
+        self.lr = float(lr)
+        _abi.check(self.lib.alink_smallres_set_lr(self.h, float(lr)))
+
+    def save_weights(self, path):
+        np.savez(path if path.endswith(".npz") else path + ".npz", *self.get_weights())
+
+    def load_weights(self, path):
+        with np.load(path if path.endswith(".npz") else path + ".npz") as z:
+            self.set_weights([z["arr_%d" % i] for i in range(len(self._shapes()))])
+
+    def _dev(self, a):
+        torch = self.torch
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device, torch.float32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    def predict(self, X, batch_size=1024, verbose=0):
+        L, R = self._dev(X[0]), self._dev(X[1])
+        n = L.shape[0]
+        out = self.torch.empty((n, 2), dtype=self.torch.float32, device=self.device)
+        for s in range(0, n, MAXN):
+            m = min(MAXN, n - s)
+            _abi.check(self.lib.alink_smallres_forward(self.h, _abi.ptr(L[s:s + m]), _abi.ptr(R[s:s + m]), m,
+                                                       self.prescale, _abi.ptr(out[s:s + m]), _abi.current_stream()),
+                       "alink_smallres_forward")
+        return out.cpu().numpy()
+
+    def draw_masks(self, n):
+        """keep-masks (u8) for the 2n tower passes: Dropout(0.25) after each pool (code/siamese.py:146,153)."""
+        e1, e2 = self.mask_sizes
+        return (np.random.rand(2 * n * e1 + 2 * n * e2) >= 0.25).astype(np.uint8)
+
+    def train_on_batch(self, x, y, class_weight=None, sample_weight=None, masks=None):
+        L, R, yd = self._dev(x[0]), self._dev(x[1]), self._dev(y)
+        n = L.shape[0]
+        assert n <= MAXN, "train batches larger than %d pairs are not supported" % MAXN
+        sw = sample_weight
+        if sw is None and class_weight is not None:
+            sw = np.asarray([class_weight[c] for c in np.asarray(y).argmax(axis=1)], np.float32)
+        swd = self._dev(sw) if sw is not None else None
+        if masks is None and self.training_dropout:
+            masks = self.draw_masks(n)
+        md = self.torch.from_numpy(np.ascontiguousarray(masks, np.uint8)).to(self.device) if masks is not None else None
+        _abi.check(self.lib.alink_smallres_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
+                                                      self.prescale, _abi.ptr(md), 0.0, 1, _abi.ptr(self._metrics),
+                                                      _abi.current_stream()), "alink_smallres_train_step")
+        m = self._metrics.cpu().numpy()
+        return [float(m[0]), float(m[1])]
+
+    def test_on_batch(self, x, y):
+        L, R, yd = self._dev(x[0]), self._dev(x[1]), self._dev(y)
+        tot, seen = np.zeros(2), 0
+        for s in range(0, L.shape[0], MAXN):
+            m = min(MAXN, L.shape[0] - s)
+            _abi.check(self.lib.alink_smallres_eval(self.h, _abi.ptr(L[s:s + m]), _abi.ptr(R[s:s + m]),
+                                                    _abi.ptr(yd[s:s + m]), m, self.prescale, _abi.ptr(self._metrics),
+                                                    _abi.current_stream()), "alink_smallres_eval")
+            tot += self._metrics.cpu().numpy() * m
+            seen += m
+        return [float(tot[0] / seen), float(tot[1] / seen)]

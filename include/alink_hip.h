@@ -143,9 +143,46 @@ int alink_head_train_step(alink_head_t* h, const float* dev_L, const float* dev_
                           const float* dev_y, const float* dev_sw, int n, float grad_scale,
                           int apply, float* dev_metrics, void* stream);
 int alink_head_apply_update(alink_head_t* h, void* stream);
+/* Gradient of the last alink_head_train_step's loss w.r.t. its inputs (for end-to-end models such as
+ * SmallRes, code/siamese.py:158-168): dL, dR are (n, d_in) f32. */
+int alink_head_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, int n,
+                           float* dev_dL, float* dev_dR, void* stream);
 /* Keras test_on_batch: {loss, binary_accuracy} without touching parameters. */
 int alink_head_eval(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
                     int n, float* dev_metrics, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SmallRes: the end-to-end-trained low-resolution siamese CNN (code/siamese.py:134-184):
+ *   tower  conv3x3(3->32,same) relu, conv3x3(32->32,valid) relu, maxpool2, dropout.25,
+ *          conv3x3(32->64,same) relu, conv3x3(64->64,valid) relu, maxpool2, dropout.25, flatten,
+ *          dense(feat) relu        (shared by both inputs)
+ *   head   |l-r| -> dense128 relu -> dense32 relu -> dense2 -> softmax, BCE + Adadelta
+ * f32 throughout.  Pixels are (n, H, W, 3) f32; `prescale` applies SmallRes.preprocess
+ * ((x-128)/128, code/siamese.py:179-181) in the first kernel.
+ * Parameters in Keras order: conv kernels (3,3,in,out) + bias x4, dense (in,out) + bias, then the head.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct alink_smallres alink_smallres_t;
+alink_smallres_t* alink_smallres_create(int img_h, int img_w, int feat, float lr, float rho, float eps);
+void alink_smallres_destroy(alink_smallres_t* m);
+size_t alink_smallres_num_params(const alink_smallres_t* m);
+int alink_smallres_set_params(alink_smallres_t* m, const float* host, size_t count);
+int alink_smallres_get_params(const alink_smallres_t* m, float* host, size_t count);
+int alink_smallres_set_lr(alink_smallres_t* m, float lr);
+float* alink_smallres_grads_dev(alink_smallres_t* m);      /* flat tower+head gradients (all-reduce) */
+/* predict: probs (n,2).  n <= 256 per call. */
+int alink_smallres_forward(alink_smallres_t* m, const float* dev_L, const float* dev_R, int n, int prescale,
+                           float* dev_probs, void* stream);
+/* one Keras train_on_batch (apply != 0) or gradients only.  dev_masks: the two dropout keep-masks for
+ * the 2n tower passes, u8, laid out [2n*P1*P1*32] then [2n*P2*P2*64] (1 = keep), or NULL = no dropout.
+ * dev_metrics: {loss, binary_accuracy}. */
+int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
+                              const float* dev_sw, int n, int prescale, const uint8_t* dev_masks,
+                              float grad_scale, int apply, float* dev_metrics, void* stream);
+int alink_smallres_apply_update(alink_smallres_t* m, void* stream);
+int alink_smallres_eval(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y, int n,
+                        int prescale, float* dev_metrics, void* stream);
+/* sizes of the two dropout masks per tower image (elements): P1*P1*32 and P2*P2*64 */
+int alink_smallres_mask_sizes(const alink_smallres_t* m, int* per_image_1, int* per_image_2);
 
 /* ------------------------------------------------------------------------------------------------
  * Pool scoring helpers (HBM-bound): uncertainty measures (code/uncertainty.py:15-60) and top-k

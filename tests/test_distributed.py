@@ -1,0 +1,106 @@
+"""CPU, world_size 2, gloo: the sharding / merge / gradient-normalisation logic of distributed.py.
+(The device kernels themselves are covered by the -m gpu tests; here the per-rank compute is the
+NumPy oracle so that the N > 1 control path is exercised without a GPU.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import a_link_amd  # noqa: F401
+from a_link_amd import distributed as D
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 8, 100000):
+        for w in (1, 2, 3, 8):
+            parts = [D.shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [h - l for l, h in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import siamese_head as O
+        # ---- 1. pool top-k: shard scores, local top-k, merge == global top-k (ties -> lower index)
+        rng = np.random.RandomState(0)
+        scores = rng.rand(1000).astype(np.float32)
+        scores[[10, 500, 900]] = 2.0                      # a three-way tie at the top, across shards
+        k = 16
+        lo, hi = D.shard_range(len(scores), rank, world)
+        loc = scores[lo:hi]
+        order = np.lexsort((np.arange(lo, hi), -loc))[:k]
+        v, i = D.merge_topk(torch.from_numpy(loc[order]), torch.from_numpy(order + lo), k, largest=True)
+        want = np.lexsort((np.arange(1000), -scores))[:k]
+        ok1 = np.array_equal(i.numpy(), want) and np.array_equal(v.numpy(), scores[want])
+        # smallest-k with a short shard (k > local size on purpose)
+        v2, i2 = D.merge_topk(torch.from_numpy(np.sort(loc)[:5]), torch.from_numpy(np.argsort(loc, kind="stable")[:5] + lo),
+                              8, largest=False)
+        cand = np.concatenate([np.argsort(scores[l:h], kind="stable")[:5] + l for l, h in D.dp_batch_slices(1000, world)])
+        want2 = cand[np.lexsort((cand, scores[cand]))][:8]
+        ok2 = np.array_equal(i2.numpy(), want2)
+
+        # ---- 2. DP gradient normalisation: per-rank grads with the GLOBAL denominator, summed,
+        # equal the full-batch Keras gradients (class-weighted, one zero weight)
+        ws = O.init_weights(64, 128, 32, seed=3)
+        rs = np.random.RandomState(1)
+        L, R = rs.randn(13, 64).astype(np.float32), rs.randn(13, 64).astype(np.float32)
+        y = O.to_categorical(rs.randint(0, 2, 13))
+        sw = np.where(y[:, 1] > 0, 2.0 / 3, 1.0 / 3).astype(np.float32)
+        sw[4] = 0.0
+        full, loss_full, _ = O.gradients(ws, L, R, y, sw)
+        denom = float((sw != 0).sum())
+        lo, hi = D.shard_range(13, rank, world)
+        # local gradients of sum_i w_i l_i / denom  ==  oracle gradients with weights w_i * n_loc_nonzero / denom
+        nloc = float((sw[lo:hi] != 0).sum())
+        loc_g, loc_loss, _ = O.gradients(ws, L[lo:hi], R[lo:hi], y[lo:hi], sw[lo:hi])
+        flat = torch.from_numpy(np.concatenate([g.ravel() for g in loc_g]) * np.float32(nloc / denom))
+        D.allreduce_sum_(flat)
+        ref = np.concatenate([g.ravel() for g in full])
+        ok3 = np.allclose(flat.numpy(), ref, rtol=1e-5, atol=1e-7)
+        lt = torch.tensor([loc_loss * nloc / denom], dtype=torch.float64)
+        D.allreduce_sum_(lt)
+        ok4 = abs(lt.item() - loss_full) < 1e-6
+
+        # ---- 3. sharded embedding gather keeps order (fake feature model: row id -> embedding)
+        class Fake(object):
+            def process(self, X):
+                return np.repeat(np.asarray(X, np.float32).reshape(len(X), -1)[:, :1], 4, axis=1)
+        X = np.arange(11, dtype=np.float32).reshape(11, 1, 1, 1)
+        E, (l0, h0) = D.embed_pool_sharded(Fake(), X)
+        ok5 = np.array_equal(E.numpy()[:, 0], np.arange(11)) and (l0, h0) == D.shard_range(11, rank, world)
+        q.put((rank, ok1, ok2, ok3, ok4, ok5))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    for r in res:
+        assert all(r[1:]), r

@@ -128,3 +128,29 @@ def test_save_load_roundtrip(gpu, tmp_path):
     assert b.maybeLoadFromMemory()
     L, R = _data(10, 512, 0)
     assert np.array_equal(a.predict([L, R]), b.predict([L, R]))
+
+
+def test_dp_train_step_single_rank_group(gpu):
+    """distributed.dp_train_on_batch on a 1-rank process group (RCCL): gradient alias, global
+    normaliser, all-reduce, update — must equal the plain train_on_batch / the oracle."""
+    import os
+    import torch.distributed as dist
+    from a_link_amd import distributed as D
+    from oracle import siamese_head as O
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        g, o = _pair(lr=0.1)
+        L, R = _data(16, 512, 42)
+        y = O.to_categorical(np.random.RandomState(3).randint(0, 2, 16))
+        cw = {0: 0.25, 1: 0.75}
+        mg = D.dp_train_on_batch(g, [L, R], y, class_weight=cw)
+        mo = o.train_on_batch([L, R], y, class_weight=cw)
+        np.testing.assert_allclose(mg, mo, rtol=2e-5, atol=1e-6)
+        for a, b in zip(g.get_weights(), o.get_weights()):
+            np.testing.assert_allclose(a, b, atol=3e-6)
+        gt = g.grads_tensor()
+        assert gt.is_cuda and gt.numel() == 295618
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,133 @@
+"""GPU: pool-scale scoring + exact top-k (select.hip), the committee over a sharded pool (config 3
+shape, scaled down), and one full A-LINK iteration (config 4 shape) with the selection set compared
+to the oracle's."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _probs(n, c, seed):
+    rng = np.random.RandomState(seed)
+    z = rng.randn(n, c).astype(np.float32) * 2
+    e = np.exp(z - z.max(1, keepdims=True))
+    return (e / e.sum(1, keepdims=True)).astype(np.float32)
+
+
+def test_scores_match_reference_functions(gpu):
+    from a_link_amd import uncertainty as U
+    from oracle import al_logic as O
+    for c in (2, 5):
+        p = _probs(10007, c, c)
+        pd = torch.from_numpy(p).cuda()
+        np.testing.assert_allclose(U.score_device(pd, "uncertainty").cpu().numpy(), O.proba_uncertainty(p), atol=1e-7)
+        np.testing.assert_allclose(U.score_device(pd, "margin").cpu().numpy(), O.proba_margin(p), atol=1e-7)
+        np.testing.assert_allclose(U.score_device(pd, "entropy").cpu().numpy(), O.proba_entropy(p), atol=2e-6)
+    a, b = _probs(5000, 2, 1), _probs(5000, 2, 2)
+    d = U.score_device(torch.from_numpy(a).cuda(), "disparity", b=torch.from_numpy(b).cuda(), col=0).cpu().numpy()
+    assert np.array_equal(d, -np.absolute(b[:, 0] - a[:, 0]))
+
+
+@pytest.mark.parametrize("P,k", [(1, 1), (777, 100), (5000, 4096), (300000, 1024), (100000, 20000)])
+def test_topk_exact_with_ties(gpu, P, k):
+    from a_link_amd import uncertainty as U
+    rng = np.random.RandomState(P)
+    s = rng.rand(P).astype(np.float32)
+    s[rng.randint(0, P, max(1, P // 10))] = 0.5            # many exact ties
+    s[rng.randint(0, P, max(1, P // 50))] = -0.0
+    sd = torch.from_numpy(s).cuda()
+    for largest in (True, False):
+        idx, vals = U.topk_device(sd, k, largest=largest)
+        want = np.lexsort((np.arange(P), -s if largest else s))[:k]        # ties -> lower index
+        assert np.array_equal(idx.cpu().numpy(), want)
+        assert np.array_equal(vals.cpu().numpy(), s[want])
+
+
+def test_committee_over_pool_uncertainty_topk(gpu):
+    """config 3, scaled: committee of 3 heads scores pool images against a fixed gallery; entropy +
+    top-k indices equal the oracle's on the same embeddings."""
+    from a_link_amd import committee, siamese, uncertainty as U
+    from oracle import al_logic as OA
+    from oracle import siamese_head as O
+    rng = np.random.RandomState(0)
+    pool = rng.randn(2048, 512).astype(np.float32)
+    pool /= np.linalg.norm(pool, axis=1, keepdims=True)
+    gallery = pool[:16].copy()
+    li = np.repeat(np.arange(2048, dtype=np.int32), 16)
+    ri = np.tile(np.arange(16, dtype=np.int32), 2048)
+    members = [siamese.SiameseNetwork((512,), "c%d" % i, 0.1, seed=10 + i) for i in range(3)]
+    bag = committee.Bagging(members, [])
+    probs = bag.predict_indexed(pool, gallery, li, ri)
+    ref_members = []
+    for m in members:
+        om = O.HeadModel(512)
+        om.set_weights(m.siamese_net.get_weights())
+        ref_members.append(om.predict([pool[li], gallery[ri]]))
+    ref = OA.bagging_predict(ref_members)
+    np.testing.assert_allclose(probs.cpu().numpy(), ref, atol=2e-6)
+    ent = U.score_device(probs, "entropy")
+    idx, _ = U.topk_device(ent, 1024, largest=True)
+    ref_ent = OA.proba_entropy(ref)
+    # same set wherever the oracle's k-th gap exceeds the arithmetic noise
+    order = np.argsort(-ref_ent, kind="stable")
+    gap = ref_ent[order[1023]] - ref_ent[order[1024]]
+    got = set(idx.cpu().numpy().tolist())
+    want = set(order[:1024].tolist())
+    assert len(got ^ want) <= (0 if gap > 1e-5 else 4)
+
+
+def test_one_alink_iteration_selection_identical(gpu):
+    """config 4 shape: 16 persons, unique images embedded ONCE (dedup), pairs gathered by index,
+    M1 committee + M2 on noisy copies, selection rule -> identical query set to the oracle run on the
+    oracle's own embeddings of the same pixels."""
+    from a_link_amd import committee, pairs, selection, siamese, weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import al_logic as OA
+    from oracle import ir_resnet
+    from oracle import siamese_head as O
+    size = (32, 32)
+    params = W.synthetic_ir_params((1, 1, 1, 1), size=size, seed=11)
+    bb = IRBackbone(params, image_size=size, max_batch=64)
+    rng = np.random.default_rng(5)
+    n_plain = [2, 1, 2, 2, 1, 2, 2, 2]
+    n_dig = [2, 3, 2, 1, 2, 2, 3, 2]
+    uniq = rng.integers(0, 256, (sum(n_plain) + sum(n_dig), 32, 32, 3)).astype(np.float32)
+    li, ri, y = pairs.createMiniBatchIndices(n_plain, n_dig)
+    noises = [uniq + rng.normal(10, np.sqrt(10), uniq.shape).astype(np.float32),       # Gaussian (code/noise.py:33-45)
+              uniq + uniq * (rng.normal(0, 1, uniq.shape).astype(np.float32) / 15)]    # Speckle  (code/noise.py:79-88)
+    m1 = [siamese.SiameseNetwork((512,), "m1", 0.1, seed=1)]
+    m2 = siamese.SiameseNetwork((512,), "m2", 0.1, seed=2)
+    bag = committee.Bagging(m1, [])
+    E = bb.embed(uniq)
+    ens = bag.predict_indexed(E, E, li, ri).cpu().numpy()
+    dis = []
+    for nz in noises:
+        En = bb.embed(nz)
+        dis.append(m2.siamese_net.predict_device(En, En, li, ri).cpu().numpy())
+    q, active, labels = selection.select_queries(ens, dis, y, col=0, disparity_ratio=0.25, eps=0.05)
+
+    # oracle: f32 CPU embeddings of the same pixels, NumPy heads, reference-shaped selection loops
+    Eo = ir_resnet.embed(params, uniq)
+    o1, o2 = O.HeadModel(512), O.HeadModel(512)
+    o1.set_weights(m1[0].siamese_net.get_weights())
+    o2.set_weights(m2.siamese_net.get_weights())
+    ens_o = OA.bagging_predict([o1.predict([Eo[li], Eo[ri]])])
+    dis_o = []
+    for nz in noises:
+        Eno = ir_resnet.embed(params, nz)
+        dis_o.append(o2.predict([Eno[li], Eno[ri]]))
+    qs, act_o = OA.select_queries(ens_o, dis_o, y, 0, 0.25, 0.05)
+    assert len(li) == sum(n_plain) * sum(n_dig) + sum(n_dig) ** 2
+    assert np.abs(ens - ens_o).max() < 5e-3           # bf16 backbone vs f32 oracle, through the head
+    # the selection SET must agree except for pairs sitting within the embedding noise of a cut
+    d_o = [-np.abs(d[:, 0] - ens_o[:, 0]) for d in dis_o]
+    k = int(len(li) * 0.25)
+    fragile = set()
+    for d in d_o:
+        srt = np.sort(d)
+        thr = srt[k - 1]
+        fragile |= set(np.nonzero(np.abs(d - thr) < 2e-2)[0].tolist())
+    fragile |= set(np.nonzero(np.abs(np.abs(ens_o[:, 0] - 0.5) - 0.05) < 1e-2)[0].tolist())
+    assert (set(q) ^ qs) <= fragile, (sorted(set(q) ^ qs), len(fragile))
+    assert abs(active - act_o) <= len(fragile)

@@ -1,0 +1,66 @@
+"""GPU parity of SmallRes (smallres.hip) against the torch-CPU autograd oracle (oracle/smallres.py):
+predict, one and several train_on_batch steps with explicit dropout masks, test_on_batch,
+preprocessing, and the reference-shaped API (siamese.SmallRes)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _imgs(n, s, seed):
+    rng = np.random.RandomState(seed)
+    return rng.randint(0, 256, (n, s, s, 3)).astype(np.float32)
+
+
+@pytest.mark.parametrize("size,feat", [(32, 2048), (48, 256)])
+def test_forward_and_training_match_oracle(gpu, size, feat):
+    from a_link_amd.smallres import SmallResNet
+    from oracle import siamese_head as O
+    from oracle import smallres as OS
+    net = SmallResNet((size, size, 3), feat, lr=0.1, seed=3)
+    ws = net.get_weights()
+    rng = np.random.RandomState(7)
+    for i in range(1, len(ws), 2):                       # non-zero biases
+        ws[i] = (rng.randn(*ws[i].shape) * 0.05).astype(np.float32)
+    net.set_weights(ws)
+    om = OS.SmallResModel(ws, lr=0.1)
+    n = 6
+    L = (_imgs(n, size, 1) - 128.) / 128.
+    R = (_imgs(n, size, 2) - 128.) / 128.
+    np.testing.assert_allclose(net.predict([L, R]), om.predict([L, R]), atol=2e-5)
+    p1, p2 = (size - 2) // 2, ((size - 2) // 2 - 2) // 2
+    shapes = ((p1, p1, 32), (p2, p2, 64))
+    assert net.mask_sizes == (p1 * p1 * 32, p2 * p2 * 64)
+    y = O.to_categorical(rng.randint(0, 2, n))
+    for step in range(3):
+        masks = (rng.rand(2 * n * (net.mask_sizes[0] + net.mask_sizes[1])) >= 0.25).astype(np.uint8) if step < 2 else None
+        sw = None if step != 1 else np.array([1, 0.5, 0, 2, 1, 1], np.float32)
+        net.training_dropout = masks is not None
+        mg = net.train_on_batch([L, R], y, sample_weight=sw, masks=masks)
+        mo, _ = om.train_on_batch([L, R], y, sample_weight=sw, masks=masks, mask_shapes=shapes)
+        np.testing.assert_allclose(mg, mo, rtol=1e-4, atol=1e-5)
+        for a, b in zip(net.get_weights(), om.ws):
+            np.testing.assert_allclose(a, b, atol=3e-5)
+    np.testing.assert_allclose(net.test_on_batch([L, R], y), om.test_on_batch([L, R], y), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(net.predict([L, R]), om.predict([L, R]), atol=5e-5)
+
+
+def test_reference_shaped_api(gpu, tmp_path):
+    from a_link_amd import siamese
+    from oracle import smallres as OS
+    m = siamese.SmallRes((32, 32, 3), (2048,), str(tmp_path / "lowres"), 0.1, seed=1)
+    om = OS.SmallResModel(m.siamese_net.get_weights())
+    L, R = _imgs(5, 32, 3), _imgs(5, 32, 4)               # raw 0..255 pixels: predict applies preprocess
+    got = m.predict([L, R])
+    ref = om.predict([(L - 128.) / 128., (R - 128.) / 128.])
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+    assert m.getDenseBarebones() == [(128, 'relu'), (32, 'relu'), (2, None)]
+    # finetune runs (dropout on, random masks) and changes the weights; save/load round-trips
+    np.random.seed(0)
+    Y = np.array([[1], [0], [1], [0], [1]])
+    hist = m.finetune([L, R], Y, 1, 2, verbose=0)
+    assert "loss" in hist and np.isfinite(hist["loss"][0])
+    m.save()
+    m2 = siamese.SmallRes((32, 32, 3), (2048,), str(tmp_path / "lowres"), 0.1, seed=2)
+    assert m2.maybeLoadFromMemory()
+    assert np.array_equal(m2.predict([L, R]), m.predict([L, R]))
