@@ -38,6 +38,7 @@ PROTOTYPES = {
     "alink_backbone_num_tensors": (_i, [_vp]),
     "alink_backbone_tensor_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_sz)]),
     "alink_backbone_finalize": (_i, [_vp]),
+    "alink_backbone_set_streams": (_i, [_vp, _i]),
     "alink_backbone_workspace_bytes": (_sz, [_vp, _i]),
     "alink_embed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "alink_embed_profile": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_i)]),

@@ -14,7 +14,7 @@ from . import weights as W
 
 class IRBackbone(object):
     def __init__(self, params, image_size=(112, 112), emb=512, dtype="bf16", device=0, max_batch=256,
-                 widths=W.WIDTHS):
+                 widths=W.WIDTHS, streams=4, shards_per_call=1):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
@@ -46,8 +46,14 @@ class IRBackbone(object):
             a = np.ascontiguousarray(params[key], dtype=np.float32)
             _abi.check(self.lib.alink_backbone_load(self.h, name.value, _abi.ptr(a), a.size), "load " + key)
         _abi.check(self.lib.alink_backbone_finalize(self.h), "alink_backbone_finalize")
-        self._ws = None
-        self._ws_n = 0
+        _abi.check(self.lib.alink_backbone_set_streams(self.h, int(shards_per_call)), "alink_backbone_set_streams")
+        # Inputs larger than max_batch are cut into max_batch-image chunks issued round-robin on
+        # `streams` side streams (each with its own workspace) and joined once at the end: chunks are
+        # independent, and de-synchronising them lets the HBM bursts of one chunk's tiles overlap the
+        # matrix-core phases of the others (+8...10 % measured on r100).
+        self.n_streams = max(1, int(streams))
+        self._side = None
+        self._ws = {}
 
     def __del__(self):
         try:
@@ -58,13 +64,15 @@ class IRBackbone(object):
             pass
 
     # -- workspace -------------------------------------------------------------------------------
-    def _workspace(self, n):
-        if self._ws is None or n > self._ws_n:
+    def _workspace(self, n, slot=0):
+        cur = self._ws.get(slot)
+        if cur is None or n > cur[1]:
             nbytes = self.lib.alink_backbone_workspace_bytes(self.h, n)
-            self._ws = self.torch.empty(nbytes + 256, dtype=self.torch.uint8, device="cuda:%d" % self.device)
-            self._ws_n = n
-        off = (-self._ws.data_ptr()) % 256
-        return self._ws.data_ptr() + off, self._ws.numel() - off
+            cur = (self.torch.empty(nbytes + 256, dtype=self.torch.uint8, device="cuda:%d" % self.device), n)
+            self._ws[slot] = cur
+        t = cur[0]
+        off = (-t.data_ptr()) % 256
+        return t.data_ptr() + off, t.numel() - off
 
     @staticmethod
     def _layout_of(x, image_size):
@@ -87,12 +95,34 @@ class IRBackbone(object):
         n = x.shape[0]
         if out is None:
             out = torch.empty((n, self.emb), dtype=torch.float32, device=x.device)
-        st = _abi.current_stream()
-        for i in range(0, n, self.max_batch):
+        nchunks = (n + self.max_batch - 1) // self.max_batch
+        if nchunks == 1 or self.n_streams == 1:
+            st = _abi.current_stream()
+            for i in range(0, n, self.max_batch):
+                m = min(self.max_batch, n - i)
+                ws, wsb = self._workspace(m)
+                _abi.check(self.lib.alink_embed(self.h, _abi.ptr(x[i:i + m]), layout, m, _abi.ptr(out[i:i + m]),
+                                                C.c_void_p(ws), wsb, st), "alink_embed")
+            return out
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=x.device) for _ in range(self.n_streams)]
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)                       # inputs (and `out`) are valid in caller-stream order
+        used = min(self.n_streams, nchunks)
+        for s in self._side[:used]:
+            s.wait_event(ready)
+        for j, i in enumerate(range(0, n, self.max_batch)):
             m = min(self.max_batch, n - i)
-            ws, wsb = self._workspace(m)
+            slot = j % used
+            ws, wsb = self._workspace(m, slot + 1)
             _abi.check(self.lib.alink_embed(self.h, _abi.ptr(x[i:i + m]), layout, m, _abi.ptr(out[i:i + m]),
-                                            C.c_void_p(ws), wsb, st), "alink_embed")
+                                            C.c_void_p(ws), wsb, C.c_void_p(self._side[slot].cuda_stream)),
+                       "alink_embed")
+        for s in self._side[:used]:
+            done = torch.cuda.Event()
+            done.record(s)
+            cur.wait_event(done)                # results are valid in caller-stream order
         return out
 
     def embed(self, x):

@@ -106,9 +106,22 @@ struct alink_backbone {
     int fc_K = 0, fc_splitk = 1, fc_kps = 0;
     int Hf = 0, Wf = 0;                                        // final feature map size
     std::vector<void*> allocs;
+    // Optional sub-batch streams (alink_backbone_set_streams): one call is split into image shards on
+    // internal streams.  Measured: pays only when shards from SEVERAL calls overlap without a join
+    // (host code pipelines 256-image chunks over streams instead — backbone.py); within one call the
+    // join at the end costs more than the de-synchronised HBM bursts gain.
+    static constexpr int MAXSUB = 8;
+    int nsub = 1;   // default off: a per-call join costs more than the de-synchronisation gains
+    hipStream_t sub[MAXSUB] = {};
+    hipEvent_t ev_start = nullptr, ev_done[MAXSUB] = {};
 
     ~alink_backbone() {
         for (void* p : allocs) (void)hipFree(p);
+        for (int i = 0; i < MAXSUB; ++i) {
+            if (sub[i]) (void)hipStreamDestroy(sub[i]);
+            if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
+        }
+        if (ev_start) (void)hipEventDestroy(ev_start);
     }
 };
 
@@ -423,8 +436,20 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
         bb->Hf = H;
         bb->Wf = W;
     }
+    for (int i = 0; i < alink_backbone::MAXSUB; ++i) {
+        ALINK_HIP(hipStreamCreateWithFlags(&bb->sub[i], hipStreamNonBlocking));
+        ALINK_HIP(hipEventCreateWithFlags(&bb->ev_done[i], hipEventDisableTiming));
+    }
+    ALINK_HIP(hipEventCreateWithFlags(&bb->ev_start, hipEventDisableTiming));
     bb->raw.clear();
     bb->finalized = true;
+    return ALINK_OK;
+}
+
+int alink_backbone_set_streams(alink_backbone_t* bb, int n) {
+    ALINK_REQUIRE(bb && n >= 1 && n <= alink_backbone::MAXSUB, ALINK_EINVAL, "streams must be 1..%d",
+                  alink_backbone::MAXSUB);
+    bb->nsub = n;
     return ALINK_OK;
 }
 
@@ -450,11 +475,30 @@ static void ws_layout(const alink_backbone* bb, int N, size_t off[6], size_t* to
     *total = o;
 }
 
+// shard sizes of an N-image forward: at least 64 images per shard, at most bb->nsub shards
+static int split_plan(const alink_backbone* bb, int N, int counts[alink_backbone::MAXSUB]) {
+    int S = bb->nsub;
+    while (S > 1 && N / S < 64) --S;
+    for (int i = 0; i < S; ++i) counts[i] = N / S + (i < N % S ? 1 : 0);
+    return S;
+}
+
 size_t alink_backbone_workspace_bytes(const alink_backbone_t* bb, int n_images) {
     if (!bb || !bb->finalized || n_images <= 0) return 0;
-    size_t off[6], total;
-    ws_layout(bb, n_images, off, &total);
-    return total;
+    size_t off[6], total, single;
+    ws_layout(bb, n_images, off, &single);
+    // any stream count up to MAXSUB may be selected later: take the worst case
+    size_t worst = single;
+    for (int S = 2; S <= alink_backbone::MAXSUB; ++S) {
+        if (n_images / S < 64) break;
+        size_t sum = 0;
+        for (int i = 0; i < S; ++i) {
+            ws_layout(bb, n_images / S + (i < n_images % S ? 1 : 0), off, &total);
+            sum += total;
+        }
+        worst = std::max(worst, sum);
+    }
+    return worst;
 }
 
 int g_ablate = 0;
@@ -558,8 +602,37 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
 
 int alink_embed(alink_backbone_t* bb, const void* dev_in, int layout, int n_images, float* dev_out,
                 void* dev_workspace, size_t workspace_bytes, void* stream) {
-    return embed_impl(bb, dev_in, layout, n_images, dev_out, dev_workspace, workspace_bytes,
-                      (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
+    ALINK_REQUIRE(bb && bb->finalized, ALINK_ESTATE, "alink_embed before alink_backbone_finalize");
+    ALINK_REQUIRE(n_images > 0, ALINK_EINVAL, "n_images must be positive");
+    ALINK_REQUIRE(layout >= 0 && layout <= 2, ALINK_EINVAL, "unknown pixel layout %d", layout);
+    int counts[alink_backbone::MAXSUB];
+    const int S = split_plan(bb, n_images, counts);
+    hipStream_t st = (hipStream_t)stream;
+    if (S == 1)
+        return embed_impl(bb, dev_in, layout, n_images, dev_out, dev_workspace, workspace_bytes, st, nullptr,
+                          nullptr, nullptr, nullptr);
+    ALINK_REQUIRE(dev_workspace && ((uintptr_t)dev_workspace & 255) == 0, ALINK_EINVAL,
+                  "workspace must be 256-byte aligned");
+    const size_t px_bytes = (size_t)bb->cfg.height * bb->cfg.width * 3 * (layout == ALINK_LAYOUT_NHWC_U8 ? 1 : 4);
+    ALINK_HIP(hipEventRecord(bb->ev_start, st));
+    size_t woff = 0;
+    int n0 = 0;
+    for (int i = 0; i < S; ++i) {
+        size_t off[6], need;
+        ws_layout(bb, counts[i], off, &need);
+        ALINK_REQUIRE(woff + need <= workspace_bytes, ALINK_ENOMEM, "workspace too small: %zu < %zu", workspace_bytes,
+                      woff + need);
+        ALINK_HIP(hipStreamWaitEvent(bb->sub[i], bb->ev_start, 0));
+        const int rc = embed_impl(bb, (const char*)dev_in + (size_t)n0 * px_bytes, layout, counts[i],
+                                  dev_out + (size_t)n0 * bb->cfg.emb, (char*)dev_workspace + woff, need, bb->sub[i],
+                                  nullptr, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        ALINK_HIP(hipEventRecord(bb->ev_done[i], bb->sub[i]));
+        ALINK_HIP(hipStreamWaitEvent(st, bb->ev_done[i], 0));
+        woff += need;
+        n0 += counts[i];
+    }
+    return ALINK_OK;
 }
 
 int alink_embed_profile(alink_backbone_t* bb, const void* dev_in, int layout, int n_images, float* dev_out,

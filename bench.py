@@ -32,9 +32,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="r100", choices=["r100", "r50", "r34", "r18"])
-    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=1024, help="images per step per GPU")
+    ap.add_argument("--chunk", type=int, default=256, help="images per alink_embed call (chunks of a step are "
+                    "issued round-robin on --streams streams)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--input", default="f32", choices=["f32", "u8"], help="pixel type resident in HBM")
+    ap.add_argument("--streams", type=int, default=4, help="streams the chunks of one step are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile / fine-tune timing")
     args = ap.parse_args()
@@ -58,7 +61,8 @@ def main():
 
     units = W.ARCH_UNITS[args.model]
     params = W.synthetic_ir_params(units, seed=1)
-    bb = IRBackbone(params, image_size=(112, 112), dtype=args.dtype, device=local_rank, max_batch=args.batch)
+    bb = IRBackbone(params, image_size=(112, 112), dtype=args.dtype, device=local_rank, max_batch=args.chunk,
+                    streams=args.streams)
     del params
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(rank)           # rank 0 == seed 0
@@ -96,10 +100,12 @@ def main():
         "value": emb_per_s, "unit": "embeddings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "LResNet%sE-IR embed, batch %d x 3x112x112 per GPU, %s pixels resident in HBM"
-                               % (args.model[1:], B, args.input),
+        "config": {"workload": "LResNet%sE-IR embed, %d x 3x112x112 images per step per GPU (as %d-image launches "
+                               "round-robin on %d streams), %s pixels resident in HBM"
+                               % (args.model[1:], B, args.chunk, args.streams, args.input),
                    "arch": args.model, "units": list(units), "batch_per_gpu": B, "global_batch": B * world,
-                   "gflop_per_embedding": gflop_per_emb, "sharding": "images (dp%d), no collective" % world},
+                   "gflop_per_embedding": gflop_per_emb, "sharding": "images (dp%d), no collective" % world,
+                   "images_per_launch": args.chunk, "intra_gpu_streams": args.streams},
         "tflops_end_to_end": emb_per_s * gflop_per_emb / 1e3,
         "frac_mfma_peak_end_to_end": emb_per_s * gflop_per_emb / 1e3 / (MFMA_PEAK_TFLOPS * world),
     }
@@ -108,7 +114,7 @@ def main():
         # ---- roofline of the dominant kernel (conv_igemm_kernel): HIP events around every launch
         conv_ms, conv_fl, other_ms = [], [], []
         for _ in range(3):
-            prof = bb.profile(x)
+            prof = bb.profile(x[:args.chunk])
             conv_ms.append(sum(ms for k, ms, f in prof if k == 1))
             conv_fl.append(sum(f for k, ms, f in prof if k == 1))
             other_ms.append(sum(ms for k, ms, f in prof if k != 1))
@@ -157,7 +163,7 @@ def main():
         # cannot be installed) on a bounded sample of the same workload
         params = W.synthetic_ir_params(units, seed=1)
         cores = torch.get_num_threads()
-        xs = x[:8].float().cpu().numpy()
+        xs = x[:8].float().cpu().numpy()  # bounded sample of the same pixels
         t1 = time.perf_counter()
         ir_resnet.embed(params, xs, batch=8)
         one = time.perf_counter() - t1

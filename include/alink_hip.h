@@ -78,6 +78,12 @@ int alink_backbone_tensor_info(const alink_backbone_t* bb, int i, const char** n
 /* fold BN into weights/biases, convert, upload.  Synchronous; allocates device memory. */
 int alink_backbone_finalize(alink_backbone_t* bb);
 
+/* Optional: split one alink_embed call into up to `n` (1..8, default 1 = off) independent image
+ * shards of >= 64 images on internal streams (ordered after / before `stream` with events).  Results
+ * do not depend on n.  Callers that embed many batches get more from issuing whole 256-image calls
+ * round-robin on their own streams (what a-link_amd/backbone.py does): the calls are independent. */
+int alink_backbone_set_streams(alink_backbone_t* bb, int n);
+
 size_t alink_backbone_workspace_bytes(const alink_backbone_t* bb, int n_images);
 
 /* N images -> N L2-normalised embeddings (code/face_model.py:86-93, batched).

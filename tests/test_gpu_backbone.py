@@ -124,3 +124,27 @@ def test_error_paths(gpu):
     bb = IRBackbone(params, image_size=size)
     with pytest.raises(ValueError):
         bb.embed(np.zeros((2, 31, 32, 3), np.float32))
+
+
+def test_stream_sharding_is_invisible(gpu):
+    """alink_embed splits batches >= 128 into shards on internal streams: results must not depend on
+    the shard count, and must equal per-image results."""
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    size = (32, 32)
+    params = W.synthetic_ir_params((1, 1, 1, 1), size=size, seed=9)
+    x = _pixels(300, size, seed=3)
+    outs = []
+    for shards in (1, 2, 4, 8):
+        bb = IRBackbone(params, image_size=size, max_batch=300, shards_per_call=shards)
+        outs.append(bb.embed(x))
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+    # chunked over side streams (the pool-inference path): 300 images as 64-image launches on 3 streams
+    bb = IRBackbone(params, image_size=size, max_batch=64, streams=3)
+    xd = torch.from_numpy(x).cuda()
+    for _ in range(3):                                  # repeated calls reuse workspaces / streams safely
+        got = bb.embed_device(xd)
+        assert np.array_equal(got.cpu().numpy(), outs[0])
+    bb = IRBackbone(params, image_size=size, max_batch=8, streams=4)
+    assert np.array_equal(bb.embed(x[137:138])[0], outs[0][137])
