@@ -21,6 +21,7 @@
 //   Adadelta: a = rho*a + (1-rho)*g^2; u = g*sqrt(d+eps)/sqrt(a+eps); p -= lr*u; d = rho*d+(1-rho)*u^2.
 #include "alink_common.h"
 
+#include <algorithm>
 #include <vector>
 
 using namespace alink;
@@ -221,6 +222,38 @@ __global__ void dense_fwd_relu_in_kernel(const float* __restrict__ zin, const fl
 #pragma unroll 8
     for (int k = 0; k < K; ++k) s = fmaf(fmaxf(ar[k], 0.f), w[(size_t)k * C + c], s);
     z[i] = s + b[c];
+}
+
+// Small-batch dense forward with enough waves to hide latency: block = (one row, 64 columns) x 8
+// K-slices (one wave each, coalesced weight rows, broadcast activation), fixed-order LDS reduce.
+// z[r][c] = sum_k act(a[r][k]) * w[k][c] + b[c]   (act = relu when relu_in).  K % 8 == 0.
+__global__ __launch_bounds__(512) void dense_fwd_tiled_kernel(const float* __restrict__ a,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ b, float* __restrict__ z,
+                                                             int n, int K, int C, int relu_in) {
+    __shared__ float part[8][64];
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, r = blockIdx.y;
+    const int kper = K >> 3;
+    const float* ar = a + (size_t)r * K + ks * kper;
+    const float* wp = w + (size_t)(ks * kper) * C + c;
+    float s = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int k = 0; k < kper; ++k) {
+            float av = ar[k];
+            if (relu_in) av = fmaxf(av, 0.f);
+            s = fmaf(av, wp[(size_t)k * C], s);
+        }
+    }
+    part[ks][lane] = s;
+    __syncthreads();
+    if (ks == 0 && c < C) {
+        float t = part[0][lane];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += part[i][lane];
+        z[(size_t)r * C + c] = t + b[c];
+    }
 }
 
 struct HeadLoss {
@@ -436,10 +469,10 @@ int small_pass(alink_head* h, const float* L, const float* R, const float* y, co
     float* P = h->d_params;
     float* G = h->d_grads;
     hipLaunchKernelGGL(absdiff_kernel, g1((long long)n * D), dim3(256), 0, st, L, R, h->d_dm, n, D);
-    hipLaunchKernelGGL(dense_fwd_kernel, g1((long long)n * h1), dim3(256), 0, st, h->d_dm, P + h->oW1,
-                       P + h->ob1, h->d_z1, n, D, h1);
-    hipLaunchKernelGGL(dense_fwd_relu_in_kernel, g1((long long)n * h2), dim3(256), 0, st, h->d_z1, P + h->oW2,
-                       P + h->ob2, h->d_z2, n, h1, h2);
+    hipLaunchKernelGGL(dense_fwd_tiled_kernel, dim3((h1 + 63) / 64, n), dim3(512), 0, st, h->d_dm, P + h->oW1,
+                       P + h->ob1, h->d_z1, n, D, h1, 0);
+    hipLaunchKernelGGL(dense_fwd_tiled_kernel, dim3((h2 + 63) / 64, n), dim3(512), 0, st, h->d_z1, P + h->oW2,
+                       P + h->ob2, h->d_z2, n, h1, h2, 1);
     HeadLoss lp{};
     lp.z2 = h->d_z2; lp.w3 = P + h->oW3; lp.b3 = P + h->ob3; lp.y = y; lp.sw = sw; lp.probs = h->d_p;
     lp.dz3 = h->d_dz3; lp.dz2 = h->d_dz2; lp.gw3 = G + h->oW3; lp.gb3 = G + h->ob3; lp.metrics = metrics;
