@@ -242,6 +242,8 @@ class DenseHead(KerasFitMixin):
         assert L.shape[1] == self.d_in and R.shape[1] == self.d_in
         if out is None:
             out = torch.empty((P, 2), dtype=torch.float32, device=self.device)
+        if P == 0:
+            return out
         _abi.check(self.lib.alink_head_forward(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(li), _abi.ptr(ri), P,
                                                _abi.ptr(out), _abi.current_stream()), "alink_head_forward")
         return out
@@ -296,6 +298,8 @@ def committee_predict_device(heads, L, R, li=None, ri=None):
     else:
         P = L.shape[0]
     out = torch.empty((P, 2), dtype=torch.float32, device=h0.device)
+    if P == 0:
+        return out
     arr = (C.c_void_p * len(heads))(*[h.h for h in heads])
     _abi.check(h0.lib.alink_committee_forward(arr, len(heads), _abi.ptr(L), _abi.ptr(R), _abi.ptr(li), _abi.ptr(ri),
                                               P, _abi.ptr(out), None, _abi.current_stream()), "alink_committee_forward")

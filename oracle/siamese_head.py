@@ -197,3 +197,34 @@ def bagging_predict(member_predictions):
     """Bagging.predict arithmetic (code/committee.py:18): np.sum(np.array(preds), axis=0) / len(models)."""
     preds = np.array(member_predictions)
     return np.array(np.sum(preds, axis=0) / len(member_predictions))
+
+
+def custom_train_model(model, data_gen, epochs, batch_size, val_ratio=0.2, n_steps=320000):
+    """SiameseNetwork.customTrainModel (reference code/siamese.py:81-112), python loops kept.
+    The reference file has no `from __future__ import division`, so under Python 2
+    `len(y_train) / np.sum(y_train == 1)` is an INTEGER division (int / numpy.int64 floors)."""
+    steps_per_epoch = int(n_steps / batch_size)
+    logs = []
+    for eno in range(epochs):
+        train_loss = val_loss = train_acc = val_acc = 0
+        for i in range(steps_per_epoch):
+            x, y = next(data_gen)
+            indices = np.random.permutation(len(y))
+            split_point = int(len(y) * val_ratio)
+            x_train, y_train = [pp[indices[split_point:]] for pp in x], y[indices[split_point:]]
+            x_test, y_test = [pp[indices[:split_point]] for pp in x], y[indices[:split_point]]
+            with np.errstate(divide='ignore'):
+                class_1_weight = np.int64(len(y_train)) // np.sum(y_train == 1)
+                class_0_weight = np.int64(len(y_train)) // np.sum(y_train == 0)
+            scaling_factor = float(class_1_weight + class_0_weight)
+            class_weight = {0: class_0_weight / scaling_factor, 1: class_1_weight / scaling_factor}
+            tm = model.train_on_batch(x_train, to_categorical(y_train, 2), class_weight=class_weight)
+            train_loss += tm[0]
+            train_acc += tm[1]
+            if len(y_test) > 0:
+                vm = model.test_on_batch(x_test, to_categorical(y_test, 2))
+                val_loss += vm[0]
+                val_acc += vm[1]
+        logs.append((train_loss / steps_per_epoch, train_acc / steps_per_epoch, val_loss / steps_per_epoch,
+                     val_acc / steps_per_epoch))
+    return logs

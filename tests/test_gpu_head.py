@@ -154,3 +154,48 @@ def test_dp_train_step_single_rank_group(gpu):
         assert gt.is_cuda and gt.numel() == 295618
     finally:
         dist.destroy_process_group()
+
+
+def test_custom_train_model_matches_oracle(gpu):
+    """SiameseNetwork.customTrainModel (reference code/siamese.py:81-112): generator batches, random
+    80/20 split, Python-2 integer-division class weights, train_on_batch + test_on_batch."""
+    from a_link_amd import siamese
+    from oracle import siamese_head as O
+
+    def gen(seed):
+        rs = np.random.RandomState(seed)
+        while True:
+            n = 16
+            L, R = rs.randn(n, 512).astype(np.float32), rs.randn(n, 512).astype(np.float32)
+            y = (rs.rand(n, 1) > 0.3).astype(int)       # unbalanced: class weights differ
+            yield [L, R], y
+
+    net = siamese.SiameseNetwork((512,), "ctm", 0.1, seed=31)
+    o = O.HeadModel(512, lr=0.1)
+    o.set_weights(net.siamese_net.get_weights())
+    np.random.seed(5)
+    lg = net.customTrainModel(gen(1), 2, 16, 0.2, n_steps=16 * 6, verbose=0)
+    np.random.seed(5)
+    lo = O.custom_train_model(o, gen(1), 2, 16, 0.2, n_steps=16 * 6)
+    np.testing.assert_allclose(np.array(lg), np.array(lo), rtol=1e-4, atol=1e-5)
+    for a, b in zip(net.siamese_net.get_weights(), o.get_weights()):
+        np.testing.assert_allclose(a, b, atol=2e-5)
+    acc = net.testAccuracy(np.random.RandomState(0).randn(20, 512).astype(np.float32), np.arange(20) % 4)
+    assert 0.0 <= acc <= 1.0
+
+
+def test_head_error_paths(gpu):
+    from a_link_amd.head import DenseHead
+    with pytest.raises(gpu.AlinkError):
+        DenseHead(510)                       # d_in not a multiple of 8
+    with pytest.raises(gpu.AlinkError):
+        DenseHead(512, h1=100)
+    with pytest.raises(gpu.AlinkError):
+        DenseHead(512, h2=48)
+    h = DenseHead(64, 128, 32, seed=0)
+    with pytest.raises(AssertionError):
+        h.set_weights([np.zeros((64, 128))])
+    L = np.zeros((5000, 64), np.float32)
+    with pytest.raises(gpu.AlinkError):      # train batches are capped (scratch sized for 4096 rows)
+        h.train_on_batch([L, L], np.zeros((5000, 2), np.float32))
+    assert h.predict([L[:0], L[:0]]).shape == (0, 2)
