@@ -83,19 +83,23 @@ struct IC2 { static constexpr int a = A, b = B; };
 
 // NWB = number of weight buffers in LDS (2; a 3-buffer counted-vmcnt pipeline measured slower, see
 // DESIGN.md "what did not work").
-template <typename T, int WPX, int WCO, int TPW, int TCW, int TR, int PITCH, int NWB>
-__global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const ConvParams p) {
+// NWV = waves per workgroup: 8 (one workgroup per CU, X double-buffered) or 4 (XDB = false: single X
+// buffer, <= 80 KB of LDS, so TWO independent workgroups share a CU and cover each other's DMA waits,
+// barriers, prologue and epilogue).
+template <typename T, int WPX, int WCO, int TPW, int TCW, int TR, int PITCH, int NWB, int NWV, bool XDB>
+__global__ __launch_bounds__(NWV * 64, 2) void conv3x3_direct_kernel(const ConvParams p) {
     typedef typename Vec8<T>::type vec8;
     typedef Geo<WPX, TPW, TR> G;
-    static_assert(WPX * WCO == 8, "8 waves");
+    constexpr int NT = NWV * 64;
+    static_assert(WPX * WCO == NWV, "wave grid");
     static_assert(NWB == 2, "two weight buffers");
     constexpr int R = G::R;
     constexpr int BN = WCO * TCW * 16;
     constexpr int XPIX = (R + 2) * PITCH;                       // pixels in the staged region
-    constexpr int XSLOTS = (XPIX * 8 + 511) / 512;              // 16-B DMA slots per thread
-    constexpr int XSTRIDE = XSLOTS * 8192;                      // bytes per X buffer (every slot in bounds)
+    constexpr int XSLOTS = (XPIX * 8 + NT - 1) / NT;            // 16-B DMA slots per thread
+    constexpr int XSTRIDE = XSLOTS * NT * 16;                   // bytes per X buffer (every slot in bounds)
     constexpr int WBYTES = BN * 128;
-    constexpr int WSLOTS = BN * 8 / 512;
+    constexpr int WSLOTS = BN * 8 / NT;
     static_assert(WSLOTS >= 1, "BN >= 64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const ConvParams
     const int H = p.H, W = p.W, Cin = p.Cin;
     const int ncc = Cin >> 6;
     const int nk = ncc * 9;
-    const bool xdouble = ncc > 1;
+    const bool xdouble = XDB && ncc > 1;
     const int woff0 = (xdouble ? 2 : 1) * XSTRIDE;              // weight buffers follow the X buffers
 
     const int ntn = p.Cout / BN;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const ConvParams
     int xoff[XSLOTS];
 #pragma unroll
     for (int i = 0; i < XSLOTS; ++i) {
-        const int s = tid + 512 * i;
+        const int s = tid + NT * i;
         const int idx = s >> 3, pos = s & 7;
         const int rr = idx / PITCH, pc = idx % PITCH;
         const int c16 = pos ^ ((pc >> 1) & 7);
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const ConvParams
     }
     auto stage_x_slot = [&](int i, int buf, int cc) {
         const T* src = xoff[i] >= 0 ? gin + (xoff[i] + cc * 64) : gz + (lane & 7) * 8;
-        dma16(src, smem + buf * XSTRIDE + (512 * i + wave * 64) * 16);
+        dma16(src, smem + buf * XSTRIDE + (NT * i + wave * 64) * 16);
     };
     // ---- W staging.  Weights of direct-variant layers are stored in K-step order
     // [cout][chunk][tap][64], so the source of K-step kt is a per-thread pointer advanced by 64
@@ -144,14 +148,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const ConvParams
     const T* wp[WSLOTS];
 #pragma unroll
     for (int i = 0; i < WSLOTS; ++i) {
-        const int s = tid + 512 * i;
+        const int s = tid + NT * i;
         const int row = s >> 3, pos = s & 7;
         wp[i] = gw + ((size_t)(n0 + row) * K + (pos ^ ((row >> 1) & 7)) * 8);
     }
     auto stage_w = [&](int bufoff) {   // stages the next not-yet-staged K-step
 #pragma unroll
         for (int i = 0; i < WSLOTS; ++i) {
-            dma16(wp[i], smem + woff0 + bufoff + (512 * i + wave * 64) * 16);
+            dma16(wp[i], smem + woff0 + bufoff + (NT * i + wave * 64) * 16);
             wp[i] += 64;
         }
     };
@@ -195,9 +199,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const ConvParams
     const int ncls = p.border_cls ? 9 : 1;
     float* const ebias = (float*)(smem + woff0 + NWB * WBYTES);
     float* const ealpha = ebias + 9 * BN;
-    for (int i = tid; i < ncls * BN; i += 512) ebias[i] = p.bias[(i / BN) * p.Cout + n0 + (i % BN)];
+    for (int i = tid; i < ncls * BN; i += NT) ebias[i] = p.bias[(i / BN) * p.Cout + n0 + (i % BN)];
     if (p.alpha)
-        for (int i = tid; i < BN; i += 512) ealpha[i] = p.alpha[n0 + i];
+        for (int i = tid; i < BN; i += NT) ealpha[i] = p.alpha[n0 + i];
     unsigned long long* stamps = (unsigned long long*)p.stamps;
     if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
 #pragma unroll
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const ConvParams
             constexpr int ky = tap / 3, kx = tap % 3;
             const int t = cc * 9 + tap;
             if (t + 1 < nk) stage_w(wtog ^ WBYTES);
-            if (more_x) {
+            if (XDB && more_x) {
 #pragma unroll
                 for (int i = tap; i < XSLOTS; i += 9) stage_x_slot(i, xnext_buf, cc + 1);
             }
@@ -242,6 +246,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const ConvParams
         step(IC2<0, 0>{}); step(IC2<1, 0>{}); step(IC2<2, 0>{});
         step(IC2<3, 0>{}); step(IC2<4, 0>{}); step(IC2<5, 0>{});
         step(IC2<6, 0>{}); step(IC2<7, 0>{}); step(IC2<8, 0>{});
+        if (!XDB && more_x) {
+            // single X buffer: every wave is past its last read of this chunk (barrier above); refill
+            // and wait — the co-resident workgroup keeps the matrix cores busy meanwhile
+#pragma unroll
+            for (int i = 0; i < XSLOTS; ++i) stage_x_slot(i, 0, cc + 1);
+            wait_dma_then_barrier<0>();
+        }
     }
 
     if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
@@ -310,22 +321,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(const ConvParams
     }
 }
 
-template <int WPX, int WCO, int TPW, int TCW, int TR, int PITCH, int NWB>
+template <int WPX, int WCO, int TPW, int TCW, int TR, int PITCH, int NWB, int NWV = 8, bool XDB = true>
 struct Variant {
     static constexpr int R = Geo<WPX, TPW, TR>::R;
     static constexpr int BN = WCO * TCW * 16;
+    static constexpr int NT = NWV * 64;
     static size_t lds_bytes(int Cin) {
-        const size_t xslots = ((size_t)(R + 2) * PITCH * 8 + 511) / 512;
-        const size_t xb = xslots * 8192, wb = (size_t)BN * 128;
+        const size_t xslots = ((size_t)(R + 2) * PITCH * 8 + NT - 1) / NT;
+        const size_t xb = xslots * NT * 16, wb = (size_t)BN * 128;
         // fragment reads of dummy columns run up to 2 pixels past a row: they land in the weight
         // buffers that follow, still inside the allocation
-        return (Cin > 64 ? 2 : 1) * xb + NWB * wb + 10 * BN * 4;   // + bias[9][BN] + alpha[BN]
+        return ((XDB && Cin > 64) ? 2 : 1) * xb + NWB * wb + 10 * BN * 4;   // + bias[9][BN] + alpha[BN]
     }
     template <typename T>
     static hipError_t launch(const ConvParams& p, hipStream_t st) {
         const int tiles_m = p.N * ((p.H + R - 1) / R), ntn = p.Cout / BN;
-        dim3 grid(tiles_m * ntn, 1, 1), block(512, 1, 1);
-        hipLaunchKernelGGL((conv3x3_direct_kernel<T, WPX, WCO, TPW, TCW, TR, PITCH, NWB>), grid, block,
+        dim3 grid(tiles_m * ntn, 1, 1), block(NT, 1, 1);
+        hipLaunchKernelGGL((conv3x3_direct_kernel<T, WPX, WCO, TPW, TCW, TR, PITCH, NWB, NWV, XDB>), grid, block,
                            lds_bytes(p.Cin), st, p);
         return hipGetLastError();
     }
@@ -333,7 +345,7 @@ struct Variant {
     template <typename T>
     static hipError_t set_attr() {
         const size_t want = fits(128) ? lds_bytes(128) : lds_bytes(64);
-        return hipFuncSetAttribute((const void*)conv3x3_direct_kernel<T, WPX, WCO, TPW, TCW, TR, PITCH, NWB>,
+        return hipFuncSetAttribute((const void*)conv3x3_direct_kernel<T, WPX, WCO, TPW, TCW, TR, PITCH, NWB, NWV, XDB>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
     }
 };
@@ -344,18 +356,27 @@ typedef Variant<2, 4, 7, 2, 2, 32, 2>  D3;   // W = 28,  Cout % 128 == 0   (stag
 typedef Variant<2, 4, 8, 2, 4, 64, 2>  D4;   // W = 56,  Cout % 128 == 0   (stage-2 unit-1 conv1)
 typedef Variant<4, 2, 7, 2, 4, 64, 2>  D5;   // W = 56,  Cout % 64 == 0    (stage 1)
 typedef Variant<4, 2, 7, 2, 7, 128, 2> D6;   // W = 112, Cout % 64 == 0    (stage-1 unit-1 conv1)
+// 4-wave, single-X-buffer variants: two workgroups per CU
+typedef Variant<2, 2, 7, 4, 1, 16, 2, 4, false> S1;   // W = 14, Cout % 128 == 0  (69 KB)
+typedef Variant<2, 2, 7, 4, 2, 32, 2, 4, false> S3;   // W = 28, Cout % 128 == 0  (73 KB)
 
 bool g_use_direct = true;
+bool g_use_pair = true;     // prefer the two-workgroups-per-CU variants where they exist
 
 }  // namespace
 
 extern "C" void alink_debug_set_direct(int on) { g_use_direct = on != 0; }
+extern "C" void alink_debug_set_pair(int on) { g_use_pair = on != 0; }
 
 // Which direct variant (1..6) serves this convolution, 0 = none (use conv_igemm).
 int direct_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout) {
     if (!g_use_direct || ksz != 3 || stride != 1 || pad != 1 || Cin % 64 || Cout % 64) return 0;
     if (W > 14 * 8 || H < 1) return 0;
     const int tr = (W + 15) / 16, pitch = (W + 2 + 15) / 16 * 16;
+    if (g_use_pair) {
+        if (tr == 1 && pitch == 16 && W >= 12 && Cout % 128 == 0 && S1::lds_bytes(Cin) <= 80 * 1024) return 7;
+        if (tr == 2 && pitch == 32 && Cout % 128 == 0 && S3::lds_bytes(Cin) <= 80 * 1024) return 8;
+    }
     if (tr == 1 && pitch == 16 && W >= 12 && Cout % 256 == 0 && D1::fits(Cin)) return 1;
     if (tr == 2 && pitch == 32 && Cout % 256 == 0 && D2::fits(Cin)) return 2;
     if (tr == 2 && pitch == 32 && Cout % 128 == 0 && D3::fits(Cin)) return 3;
@@ -365,14 +386,14 @@ int direct_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout
     return 0;
 }
 // consecutive output channels per lane of a variant: 16 -> perm64 weight rows, 8 -> perm32
-int direct_variant_cpl(int v) { return (v == 1 || v == 2) ? 16 : 8; }
+int direct_variant_cpl(int v) { return (v == 1 || v == 2 || v == 7 || v == 8) ? 16 : 8; }
 
 hipError_t direct_set_attributes() {
     hipError_t e;
 #define A(V)                                                         \
     if ((e = V::set_attr<__bf16>()) != hipSuccess) return e;         \
     if ((e = V::set_attr<_Float16>()) != hipSuccess) return e;
-    A(D1) A(D2) A(D3) A(D4) A(D5) A(D6)
+    A(D1) A(D2) A(D3) A(D4) A(D5) A(D6) A(S1) A(S3)
 #undef A
     return hipSuccess;
 }
@@ -388,6 +409,8 @@ hipError_t launch_conv3x3_direct(int variant, int dtype, const ConvParams& p, hi
         case 4: return L(D4);
         case 5: return L(D5);
         case 6: return L(D6);
+        case 7: return L(S1);
+        case 8: return L(S3);
     }
 #undef L
     return hipErrorInvalidValue;

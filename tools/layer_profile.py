@@ -18,6 +18,7 @@ ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--ablate", type=int, default=0)
 ap.add_argument("--no-direct", action="store_true")
+ap.add_argument("--no-pair", action="store_true")
 a = ap.parse_args()
 units = W.ARCH_UNITS[a.model]
 from a_link_amd import _abi
@@ -25,6 +26,8 @@ _lib = _abi.load()
 _lib.alink_debug_set_ablate(a.ablate)
 if a.no_direct:
     _lib.alink_debug_set_direct(0)
+if a.no_pair:
+    _lib.alink_debug_set_pair(0)
 bb = IRBackbone(W.synthetic_ir_params(units, seed=1), dtype=a.dtype, max_batch=a.batch)
 x = torch.randint(0, 256, (a.batch, 112, 112, 3), dtype=torch.uint8).float().cuda()
 for _ in range(2):
