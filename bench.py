@@ -121,9 +121,27 @@ def main():
         n_conv = sum(1 for k, _, _ in prof if k == 1)
         cms = float(np.median(conv_ms))
         achieved = conv_fl[0] / (cms * 1e-3) / 1e12
-        line["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (all %d launches of one forward)" % n_conv,
+        # HBM traffic per launch: PMC counters are collected in separate rocprofv3 --pmc passes
+        # (tools/pmc_summary.py -> profiles/*pmc_hbm_traffic*.csv); read the newest committed summary
+        traffic = None
+        try:
+            import glob
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic_%s_*.csv" % args.model)))
+            if pm:
+                mb, nl = 0.0, 0.0
+                for ln in open(pm[-1]).read().splitlines()[1:]:
+                    f = ln.split(",")
+                    if f[0] in ("conv3x3_direct_kernel", "conv_igemm_kernel"):
+                        nl += float(f[1]); mb += float(f[2]) + float(f[3])
+                traffic = {"bytes_per_launch": mb * 1e6 / nl, "launches": nl, "per_images": 256,
+                           "source": os.path.basename(pm[-1])}
+        except Exception:
+            traffic = None
+        line["roofline"] = {"bound": "mfma",
+                            "kernel": "conv3x3_direct_kernel + conv_igemm_kernel (all %d conv launches of one "
+                                      "%d-image forward, timed one by one on a single stream)" % (n_conv, args.chunk),
                             "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                            "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                             "flops_per_forward": conv_fl[0], "kernel_ms_per_forward": cms,
                             "avg_launch_ms": cms / n_conv, "non_conv_ms_per_forward": float(np.median(other_ms))}
         # ---- fine-tune step (second half of BASELINE.json's metric): head-512, batch 16
