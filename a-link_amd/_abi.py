@@ -25,6 +25,7 @@ class IRCfg(C.Structure):
 
 
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+_u64 = C.c_uint64
 _fp = C.POINTER(C.c_float)
 
 # name -> (restype, argtypes)
@@ -55,6 +56,8 @@ PROTOTYPES = {
     "alink_head_grads_dev": (_vp, [_vp]),
     "alink_head_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "alink_committee_forward": (_i, [C.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "alink_pair_scores_matrix": (_i, [C.POINTER(_vp), _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "alink_roc_counts": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "alink_head_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp]),
     "alink_head_apply_update": (_i, [_vp, _vp]),
     "alink_head_eval": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -71,6 +74,16 @@ PROTOTYPES = {
     "alink_smallres_apply_update": (_i, [_vp, _vp]),
     "alink_smallres_eval": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "alink_smallres_mask_sizes": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "alink_noise_gaussian": (_i, [_vp, _vp, _i64, _f, _f, _u64, _u64, _vp]),
+    "alink_noise_speckle": (_i, [_vp, _vp, _i64, _f, _u64, _u64, _vp]),
+    "alink_noise_saltpepper": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _u64, _vp]),
+    "alink_noise_poisson_scratch_bytes": (_sz, [_i, _i64]),
+    "alink_noise_poisson": (_i, [_vp, _vp, _i, _i64, _u64, _vp, _sz, _vp, _vp]),
+    "alink_perlin_nodes": (_i, [_i, C.POINTER(_i)]),
+    "alink_perlin_vectors": (_i, [_i, _i, _u64, _vp, _vp]),
+    "alink_noise_perlin": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i), _vp, _vp]),
+    "alink_resize_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "alink_perturb_images": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "alink_score": (_i, [_i, _vp, _vp, _i, _i64, _i, _vp, _vp]),
     "alink_topk_scratch_bytes": (_sz, [_i64, _i]),
     "alink_topk": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),

@@ -4,9 +4,8 @@ Bagging.predict (code/committee.py:13-20) = sum of member predictions / number o
 member is a device-resident DenseHead the mean is fused on the GPU (alink_committee_forward: member
 softmaxes accumulated in member order, one divide); any other duck-typed member falls back to the
 reference's own host arithmetic on the members' outputs.
-attackModel / resize (code/committee.py:22-37) drive the noise objects and need cv2-style bilinear
-resize; resize here is the identity when the size already matches and raises otherwise (noise stage =
-SURVEY.md §8f N1, not built yet).
+attackModel / resize (code/committee.py:22-37) drive the noise objects (noise.py) and resize with
+the device bilinear kernel (cv2.resize INTER_LINEAR rule, alink_resize_bilinear).
 """
 import numpy as np
 
@@ -46,11 +45,9 @@ class Bagging:
         return _head.committee_predict_device(hs, emb_left, emb_right, li, ri)
 
     def resize(self, images, new_size):
-        images = np.asarray(images)
-        if tuple(images.shape[1:3]) == (new_size[1], new_size[0]) or tuple(images.shape[1:3]) == tuple(new_size):
-            return np.array(images)
-        raise NotImplementedError("bilinear resize (cv2.resize, code/committee.py:22-26) is part of the noise "
-                                  "stage (SURVEY.md §8f N1), not built yet")
+        """cv2.resize(image, new_size) per image (code/committee.py:22-26); new_size = (width, height)."""
+        from . import noise as _noise
+        return np.array(_noise.resize_images(images, new_size))
 
     def attackModel(self, image_pairs, target_size, target_labels=None):
         perturbed_l, perturbed_r = [], []

@@ -61,6 +61,9 @@ struct HeadFwd {
     int D, h1, h2;
     int accumulate;     // add to probs already there (committee member > 0)
     float final_div;    // > 0: divide by it after adding (last committee member)
+    int matN;           // > 0: score-matrix mode, pair p = (mat_row0 + p / matN, p % matN) of one matrix L == R
+    int mat_row0;
+    int out_col;        // >= 0: write only this softmax column, probs is [P] (else [P][2])
 };
 
 // out-of-place repack W (in,out) row-major -> [in/8][out][2][4]:  k = 8*k8 + 2*s + h
@@ -88,15 +91,29 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const HeadFwd p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
+    // rows of the embedding matrices this tile's 32 pairs read (computed once, kept in LDS)
+    __shared__ long long s_lrow[TP], s_rrow[TP];
+    if (tid < TP) {
+        long long pp = p0 + tid;
+        if (pp >= p.P) pp = p.P - 1;
+        long long lrow, rrow;
+        if (p.matN > 0) {
+            const long long qd = pp / p.matN;
+            lrow = p.mat_row0 + qd;
+            rrow = pp - qd * p.matN;
+        } else {
+            lrow = p.li ? (long long)p.li[pp] : pp;
+            rrow = p.ri ? (long long)p.ri[pp] : pp;
+        }
+        s_lrow[tid] = lrow;
+        s_rrow[tid] = rrow;
+    }
     for (int k0 = 0; k0 < D; k0 += KC) {
         const int kc = min(KC, D - k0), nk8 = kc >> 3;
         __syncthreads();
         for (int idx = tid; idx < TP * nk8; idx += 256) {
             const int row = idx / nk8, k8 = idx - row * nk8;
-            long long pp = p0 + row;
-            if (pp >= p.P) pp = p.P - 1;
-            const long long lrow = p.li ? (long long)p.li[pp] : pp;
-            const long long rrow = p.ri ? (long long)p.ri[pp] : pp;
+            const long long lrow = s_lrow[row], rrow = s_rrow[row];
             const float* lp = p.L + lrow * D + k0 + k8 * 8;
             const float* rp = p.R + rrow * D + k0 + k8 * 8;
             const f32x4 l0 = *(const f32x4*)lp, l1 = *(const f32x4*)(lp + 4);
@@ -182,8 +199,8 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const HeadFwd p) {
         const float e = expf(z - m), eo = expf(zo - m);
         float pr = e / (e + eo);
         const long long pp = p0 + row;
-        if (pp < p.P) {
-            float* o = p.probs + pp * 2 + cls;
+        if (pp < p.P && (p.out_col < 0 || p.out_col == cls)) {
+            float* o = p.out_col < 0 ? p.probs + pp * 2 + cls : p.probs + pp;
             if (p.accumulate) pr += *o;
             if (p.final_div > 0.f) pr = pr / p.final_div;
             *o = pr;
@@ -440,7 +457,8 @@ size_t fwd_lds_bytes(int h1) {
 }
 
 int launch_fwd(alink_head* h, const float* L, const float* R, const int32_t* li, const int32_t* ri,
-               long long P, float* probs, int accumulate, float final_div, hipStream_t st) {
+               long long P, float* probs, int accumulate, float final_div, hipStream_t st, int matN = 0,
+               int mat_row0 = 0, int out_col = -1) {
     int rc = ensure_packed(h, st);
     if (rc) return rc;
     HeadFwd p{};
@@ -448,6 +466,7 @@ int launch_fwd(alink_head* h, const float* L, const float* R, const int32_t* li,
     p.w1p = h->d_w1p; p.b1 = h->d_params + h->ob1; p.w2p = h->d_w2p; p.b2 = h->d_params + h->ob2;
     p.w3 = h->d_params + h->oW3; p.b3 = h->d_params + h->ob3; p.probs = probs;
     p.D = h->D; p.h1 = h->h1; p.h2 = h->h2; p.accumulate = accumulate; p.final_div = final_div;
+    p.matN = matN; p.mat_row0 = mat_row0; p.out_col = out_col;
     const size_t lds = fwd_lds_bytes(h->h1);
     const dim3 grid((unsigned)((P + TP - 1) / TP)), block(256);
     switch (h->h1 / 128) {
@@ -584,6 +603,23 @@ int alink_committee_forward(alink_head_t* const* heads, int n_heads, const float
         // np.sum over members then / len(models) (code/committee.py:18): sequential f32 adds, one divide
         const int rc = launch_fwd(heads[m], dev_L, dev_R, dev_li, dev_ri, P, dev_probs, m > 0,
                                   m == n_heads - 1 ? (float)n_heads : 0.f, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return ALINK_OK;
+}
+
+int alink_pair_scores_matrix(alink_head_t* const* heads, int n_heads, const float* dev_emb, int n, int row0,
+                             int nrows, int col, float* dev_scores, void* stream) {
+    ALINK_REQUIRE(heads && n_heads > 0 && dev_emb && dev_scores, ALINK_EINVAL, "bad argument");
+    ALINK_REQUIRE(n > 0 && row0 >= 0 && nrows >= 0 && row0 + nrows <= n, ALINK_EINVAL,
+                  "rows [%d, %d) outside a %d x %d matrix", row0, row0 + nrows, n, n);
+    ALINK_REQUIRE(col == 0 || col == 1, ALINK_EINVAL, "col=%d must be 0 or 1", col);
+    if (nrows == 0) return ALINK_OK;
+    for (int m = 0; m < n_heads; ++m) {
+        ALINK_REQUIRE(heads[m], ALINK_EINVAL, "NULL committee member %d", m);
+        const int rc = launch_fwd(heads[m], dev_emb, dev_emb, nullptr, nullptr, (long long)nrows * n, dev_scores,
+                                  m > 0, (n_heads > 1 && m == n_heads - 1) ? (float)n_heads : 0.f,
+                                  (hipStream_t)stream, n, row0, col);
         if (rc) return rc;
     }
     return ALINK_OK;

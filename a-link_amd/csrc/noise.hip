@@ -1,0 +1,495 @@
+// noise.hip — the A2-LINK perturbation stage on device (HBM-bound elementwise / scatter work).
+//
+// Replaces the host NumPy of reference code/noise.py (Gaussian :33-45, SaltPepper :48-65, Poisson
+// :68-76, Speckle :79-88, Perlin :91-150), code/attack.py:5-29 (perturb_image) and the cv2.resize of
+// code/committee.py:22-26.  The reference draws from the unseeded global np.random stream
+// (SURVEY.md §5), so there is no stream contract to keep: random numbers here come from a
+// counter-based Philox4x32-10 generator keyed by (seed, element), which makes every kernel
+// independent of its launch shape and lets the CPU oracle reproduce the exact same draws.
+//
+// Every kernel streams its input once and writes its output once (4 B + 4 B per element, 16-B lane
+// accesses); nothing is staged through LDS because nothing is reused.
+#include "alink_common.h"
+
+namespace alink {
+namespace {
+
+// ---- Philox4x32-10 (Salmon et al., SC'11) -------------------------------------------------------
+struct U4 { unsigned int x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned int k0, unsigned int k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = (unsigned int)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (unsigned int)p1;
+        n.z = (unsigned int)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (unsigned int)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// stream ids (counter word 3) keep the draws of different kernels disjoint under one seed
+enum { ST_NORMAL = 0, ST_POISSON = 1, ST_SALTPEPPER = 2, ST_PERLIN = 3 };
+
+__device__ __forceinline__ U4 draw(unsigned long long seed, unsigned long long idx, unsigned int sub, unsigned int st) {
+    U4 c{(unsigned int)idx, (unsigned int)(idx >> 32), sub, st};
+    return philox4x32_10(c, (unsigned int)seed, (unsigned int)(seed >> 32));
+}
+
+// 24-bit uniform in the open interval (0, 1)
+__device__ __forceinline__ float u01(unsigned int x) {
+    return (float)(x >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
+}
+// 53-bit-ish uniform in (0, 1) from two words (double precision consumers: Poisson)
+__device__ __forceinline__ double u01d(unsigned int hi, unsigned int lo) {
+    const unsigned long long v = ((unsigned long long)(hi >> 5) << 26) | (lo >> 6);   // 27 + 26 bits
+    return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ void box_muller(unsigned int a, unsigned int b, float& z0, float& z1) {
+    const float r = sqrtf(-2.f * logf(u01(a)));
+    const float th = 6.283185307179586f * u01(b);
+    z0 = r * cosf(th);
+    z1 = r * sinf(th);
+}
+
+// ---- Gaussian / Speckle ---------------------------------------------------------------------------
+// mode 0 (code/noise.py:40-44):  out = x + (mean + sigma * z)
+// mode 1 (code/noise.py:84-87):  out = x + x * (z / div)
+// Element e (= offset + i) takes normal number (e & 3) of Philox block e >> 2.
+struct AffineNoise {
+    const float* in;
+    float* out;
+    long long count;
+    unsigned long long seed, offset;
+    float p0, p1;
+    int mode;
+};
+
+__device__ __forceinline__ float apply_noise(const AffineNoise& p, float x, float z) {
+    return p.mode == 0 ? x + (p.p0 + p.p1 * z) : x + x * (z / p.p0);
+}
+
+__global__ __launch_bounds__(256) void affine_noise_kernel(const AffineNoise p) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;     // group of 4 elements
+    const long long i0 = g * 4;
+    if (i0 >= p.count) return;
+    const U4 r = draw(p.seed, (p.offset >> 2) + (unsigned long long)g, 0, ST_NORMAL);
+    float z[4];
+    box_muller(r.x, r.y, z[0], z[1]);
+    box_muller(r.z, r.w, z[2], z[3]);
+    if (i0 + 4 <= p.count) {
+        const f32x4 x = *(const f32x4*)(p.in + i0);
+        f32x4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = apply_noise(p, x[j], z[j]);
+        *(f32x4*)(p.out + i0) = y;
+    } else {
+        for (int j = 0; i0 + j < p.count; ++j) p.out[i0 + j] = apply_noise(p, p.in[i0 + j], z[j]);
+    }
+}
+
+// ---- Salt & pepper (code/noise.py:54-65, tuple-index semantics of NumPy < 1.23) --------------------
+// One workgroup per image: copy, then n_salt writes of 1 at (r, c, ch) with r in [0, H-2],
+// c in [0, W-2], ch in [0, C-2] (np.random.randint(0, i - 1) excludes the high end), then n_pepper
+// writes of 0 — pepper wins where both land, as in the reference's statement order.
+struct SaltPepperP {
+    const float* in;
+    float* out;
+    int H, W, C, n_salt, n_pepper;
+    unsigned long long seed;
+};
+
+__device__ __forceinline__ int bounded(unsigned int x, int range) {
+    return (int)(((unsigned long long)x * (unsigned long long)(unsigned int)range) >> 32);
+}
+
+__global__ __launch_bounds__(256) void saltpepper_kernel(const SaltPepperP p) {
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const long long per = (long long)p.H * p.W * p.C;
+    const float* src = p.in + img * per;
+    float* dst = p.out + img * per;
+    if (src != dst)
+        for (long long i = tid; i < per; i += 256) dst[i] = src[i];
+    __syncthreads();
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+        const int n = phase == 0 ? p.n_salt : p.n_pepper;
+        for (int k = tid; k < n; k += 256) {
+            const U4 r = draw(p.seed, ((unsigned long long)img << 32) | (unsigned int)k, (unsigned int)phase, ST_SALTPEPPER);
+            const int rr = bounded(r.x, p.H - 1), cc = bounded(r.y, p.W - 1), ch = bounded(r.z, p.C - 1);
+            dst[((long long)rr * p.W + cc) * p.C + ch] = phase == 0 ? 1.f : 0.f;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- Perlin (code/noise.py:95-150) --------------------------------------------------------------------
+// noise(y, x) = sum over 3 octaves ns of  sum_{r,s in {0,1}} wa[r] * wb[s] * <offset_rs, v[i + r][j + s]>
+//   i = y / ns, a = y % ns, j = x / ns, b = x % ns, wa = (1 - q(a/ns), q(a/ns)), wb likewise for b,
+//   offset_rs = (b - s*ns, a - r*ns), q(t) = t^3 (t (6 t - 15) + 10), v = unit vectors on a
+//   (size/ns + 1)^2 grid (:100-107).  The same noise is added to every channel (:148).
+struct PerlinP {
+    const float* in;
+    float* out;
+    const float* vec;     // [n_images][nodes_total][2] unit vectors, octave after octave
+    int size, C, ns[3], goff[3], nodes_total;
+};
+
+__device__ __forceinline__ float quintic(float t) { return t * t * t * (t * (t * 6.f - 15.f) + 10.f); }
+
+__global__ __launch_bounds__(256) void perlin_kernel(const PerlinP p) {
+    const int img = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= p.size * p.size) return;
+    const int y = pix / p.size, x = pix - y * p.size;
+    const float* vimg = p.vec + (size_t)img * p.nodes_total * 2;
+    float noise = 0.f;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const int ns = p.ns[o], gs = p.size / ns + 1;
+        const int i = y / ns, a = y - i * ns, j = x / ns, b = x - j * ns;
+        const float qa = quintic((float)a / (float)ns), qb = quintic((float)b / (float)ns);
+        const float* v = vimg + (size_t)p.goff[o] * 2;
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float* node = v + ((size_t)(i + r) * gs + (j + s)) * 2;
+                const float d = (float)(b - s * ns) * node[0] + (float)(a - r * ns) * node[1];
+                acc += (r ? qa : 1.f - qa) * (s ? qb : 1.f - qb) * d;
+            }
+        noise += acc;
+    }
+    const size_t base = ((size_t)img * p.size * p.size + pix) * p.C;
+    for (int c = 0; c < p.C; ++c) p.out[base + c] = p.in[base + c] + noise;
+}
+
+__global__ void perlin_vectors_kernel(float* __restrict__ vec, long long n, unsigned long long seed) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;      // 4 nodes per Philox block
+    if (g * 4 >= n) return;
+    const U4 r = draw(seed, (unsigned long long)g, 0, ST_PERLIN);
+    const unsigned int w[4] = {r.x, r.y, r.z, r.w};
+    for (int j = 0; j < 4 && g * 4 + j < n; ++j) {
+        const float phi = 6.283185307179586f * u01(w[j]);       // np.random.uniform(0, 2 pi) (:102)
+        vec[(g * 4 + j) * 2 + 0] = cosf(phi);
+        vec[(g * 4 + j) * 2 + 1] = sinf(phi);
+    }
+}
+
+// ---- Poisson (code/noise.py:72-76) -------------------------------------------------------------------
+// vals = 2^ceil(log2(number of unique values of the image)); out = Poisson(x * vals) / vals.
+// Pass 1 counts the unique values of every image exactly with an open-addressing hash set of the
+// float bit patterns in caller scratch (one table per image); pass 2 samples: lam < 10 by the
+// product-of-uniforms method, lam >= 10 by Hörmann's transformed rejection (PTRS) — the two methods
+// numpy's legacy generator uses — in double precision (lam reaches 255 * 65536).
+struct UniqueP {
+    const float* in;
+    unsigned int* table;      // [n_images][slots], 0xFFFFFFFF = empty
+    unsigned int* count;      // [n_images]
+    long long per;
+    unsigned int slots;       // power of two >= 2 * per
+};
+
+__global__ __launch_bounds__(256) void unique_count_kernel(const UniqueP p) {
+    const int img = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.per) return;
+    float x = p.in[img * p.per + i];
+    if (x == 0.f) x = 0.f;                                   // -0.0 == 0.0 for np.unique
+    unsigned int key = __float_as_uint(x);
+    if (key == 0xFFFFFFFFu) key = 0x7FC00000u;               // a NaN pattern that collides with "empty"
+    unsigned int* tab = p.table + (size_t)img * p.slots;
+    unsigned int h = (key * 2654435761u) >> 7;
+    for (;;) {
+        h &= p.slots - 1;
+        const unsigned int old = atomicCAS(&tab[h], 0xFFFFFFFFu, key);
+        if (old == 0xFFFFFFFFu) { atomicAdd(&p.count[img], 1u); return; }
+        if (old == key) return;
+        ++h;
+    }
+}
+
+__device__ __forceinline__ double loggam(double x) { return lgamma(x); }
+
+struct PoissonP {
+    const float* in;
+    float* out;
+    const unsigned int* count;   // unique values per image
+    float* vals_out;             // optional [n_images]
+    long long per;
+    unsigned long long seed;
+};
+
+__device__ double poisson_sample(double lam, unsigned long long seed, unsigned long long elem) {
+    if (!(lam >= 0.0)) return __longlong_as_double(0x7FF8000000000000ll);     // numpy raises for lam < 0
+    if (lam == 0.0) return 0.0;
+    unsigned int sub = 0;
+    if (lam < 10.0) {
+        // product of uniforms until it falls below exp(-lam)
+        const double enlam = exp(-lam);
+        double prod = 1.0;
+        long long k = 0;
+        for (;;) {
+            const U4 r = draw(seed, elem, sub++, ST_POISSON);
+            prod *= u01d(r.x, r.y);
+            if (prod <= enlam) return (double)k;
+            ++k;
+            prod *= u01d(r.z, r.w);
+            if (prod <= enlam) return (double)k;
+            ++k;
+        }
+    }
+    const double slam = sqrt(lam), loglam = log(lam);
+    const double b = 0.931 + 2.53 * slam;
+    const double a = -0.059 + 0.02483 * b;
+    const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+    const double vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (;;) {
+        const U4 r = draw(seed, elem, sub++, ST_POISSON);
+        const double U = u01d(r.x, r.y) - 0.5;
+        const double V = u01d(r.z, r.w);
+        const double us = 0.5 - fabs(U);
+        const double k = floor((2.0 * a / us + b) * U + lam + 0.43);
+        if (us >= 0.07 && V <= vr) return k;
+        if (k < 0.0 || (us < 0.013 && V > us)) continue;
+        if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + k * loglam - loggam(k + 1.0)) return k;
+    }
+}
+
+__global__ __launch_bounds__(256) void poisson_kernel(const PoissonP p) {
+    const int img = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.per) return;
+    // vals = 2 ** np.ceil(np.log2(n_unique))
+    const double vals = exp2(ceil(log2((double)p.count[img])));
+    if (i == 0 && p.vals_out) p.vals_out[img] = (float)vals;
+    const long long e = img * p.per + i;
+    const double lam = (double)p.in[e] * vals;
+    p.out[e] = (float)(poisson_sample(lam, p.seed, (unsigned long long)e) / vals);
+}
+
+// ---- bilinear resize (cv2.resize INTER_LINEAR, code/committee.py:22-26) -------------------------------
+// OpenCV's pixel-centre mapping: f = (d + 0.5) * (src / dst) - 0.5, s = floor(f), f -= s, clamped so
+// that s in [0, src - 1] with weight 0 on the clamped side; horizontal pass then vertical pass.
+struct ResizeP {
+    const float* in;
+    float* out;
+    int N, H, W, C, Ho, Wo;
+};
+
+__device__ __forceinline__ void src_coord(int d, int src, int dst, int& s0, int& s1, float& w) {
+    float f = (float)(((double)d + 0.5) * ((double)src / (double)dst) - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= src - 1) { s = src - 1; f = 0.f; }
+    s0 = s;
+    s1 = s + 1 < src ? s + 1 : src - 1;
+    w = f;
+}
+
+__global__ __launch_bounds__(256) void resize_kernel(const ResizeP p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)p.N * p.Ho * p.Wo * p.C;
+    if (i >= total) return;
+    const int c = (int)(i % p.C);
+    long long t = i / p.C;
+    const int ox = (int)(t % p.Wo); t /= p.Wo;
+    const int oy = (int)(t % p.Ho);
+    const int n = (int)(t / p.Ho);
+    int x0, x1, y0, y1;
+    float fx, fy;
+    src_coord(ox, p.W, p.Wo, x0, x1, fx);
+    src_coord(oy, p.H, p.Ho, y0, y1, fy);
+    const float* im = p.in + (size_t)n * p.H * p.W * p.C;
+    const float a00 = im[((size_t)y0 * p.W + x0) * p.C + c], a01 = im[((size_t)y0 * p.W + x1) * p.C + c];
+    const float a10 = im[((size_t)y1 * p.W + x0) * p.C + c], a11 = im[((size_t)y1 * p.W + x1) * p.C + c];
+    const float r0 = a00 * (1.f - fx) + a01 * fx;
+    const float r1 = a10 * (1.f - fx) + a11 * fx;
+    p.out[i] = r0 * (1.f - fy) + r1 * fy;
+}
+
+// ---- perturb_image (code/attack.py:5-29) -----------------------------------------------------------------
+// n candidates, each k x (x, y, r, g, b): copy the base image, then img[int(x), int(y)] = (r, g, b)
+// in list order (a later pixel overwrites an earlier one at the same position).  With split != 0
+// the output is laid out [2][n][Hc/2][W][3] — all top halves, then all bottom halves — which is what
+// noise.PredictionWrappedModel.predict (code/noise.py:158-168) slices before embedding.
+struct PerturbP {
+    const float* img;      // [Hc][W][3]
+    const double* xs;      // [n][5k]
+    float* out;
+    int n, k, Hc, W, split;
+};
+
+__global__ __launch_bounds__(256) void perturb_kernel(const PerturbP p) {
+    const int cand = blockIdx.x, tid = threadIdx.x;
+    const long long per = (long long)p.Hc * p.W * 3, half = per / 2;
+    float* top = p.split ? p.out + (size_t)cand * half : p.out + (size_t)cand * per;
+    float* bot = p.split ? p.out + ((size_t)p.n + cand) * half : top + half;
+    for (long long i = tid; i < half; i += 256) { top[i] = p.img[i]; bot[i] = p.img[half + i]; }
+    if ((per & 1) && tid == 0) bot[half] = p.img[per - 1];      // odd Hc never splits (host refuses)
+    __syncthreads();
+    if (tid == 0) {
+        const double* x = p.xs + (size_t)cand * 5 * p.k;
+        for (int j = 0; j < p.k; ++j) {
+            const long long r = (long long)x[5 * j], c = (long long)x[5 * j + 1];     // astype(int): truncation
+            if (r < 0 || r >= p.Hc || c < 0 || c >= p.W) continue;
+            const long long o = (r * p.W + c) * 3;
+            float* d = o < half ? top + o : bot + (o - half);
+            d[0] = (float)(long long)x[5 * j + 2];
+            d[1] = (float)(long long)x[5 * j + 3];
+            d[2] = (float)(long long)x[5 * j + 4];
+        }
+    }
+}
+
+inline dim3 g1(long long n) { return dim3((unsigned)((n + 255) / 256), 1, 1); }
+
+}  // namespace
+}  // namespace alink
+
+using namespace alink;
+
+extern "C" {
+
+int alink_noise_gaussian(const float* dev_in, float* dev_out, int64_t count, float mean, float sigma,
+                         uint64_t seed, uint64_t offset, void* stream) {
+    ALINK_REQUIRE(dev_in && dev_out && count >= 0, ALINK_EINVAL, "bad argument");
+    ALINK_REQUIRE((offset & 3) == 0, ALINK_EINVAL, "offset must be a multiple of 4");
+    if (count == 0) return ALINK_OK;
+    AffineNoise p{dev_in, dev_out, count, seed, offset, mean, sigma, 0};
+    hipLaunchKernelGGL(affine_noise_kernel, g1((count + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+int alink_noise_speckle(const float* dev_in, float* dev_out, int64_t count, float divisor, uint64_t seed,
+                        uint64_t offset, void* stream) {
+    ALINK_REQUIRE(dev_in && dev_out && count >= 0 && divisor != 0.f, ALINK_EINVAL, "bad argument");
+    ALINK_REQUIRE((offset & 3) == 0, ALINK_EINVAL, "offset must be a multiple of 4");
+    if (count == 0) return ALINK_OK;
+    AffineNoise p{dev_in, dev_out, count, seed, offset, divisor, 0.f, 1};
+    hipLaunchKernelGGL(affine_noise_kernel, g1((count + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+int alink_noise_saltpepper(const float* dev_in, float* dev_out, int n_images, int H, int W, int C, int n_salt,
+                           int n_pepper, uint64_t seed, void* stream) {
+    ALINK_REQUIRE(dev_in && dev_out && n_images >= 0, ALINK_EINVAL, "bad argument");
+    // np.random.randint(0, i - 1) needs i - 1 > 0 for every axis (code/noise.py:59,63)
+    ALINK_REQUIRE(H >= 2 && W >= 2 && C >= 2, ALINK_EINVAL, "low >= high: image %dx%dx%d has an axis shorter than 2", H, W, C);
+    ALINK_REQUIRE(n_salt >= 0 && n_pepper >= 0, ALINK_EINVAL, "negative counts");
+    if (n_images == 0) return ALINK_OK;
+    SaltPepperP p{dev_in, dev_out, H, W, C, n_salt, n_pepper, seed};
+    hipLaunchKernelGGL(saltpepper_kernel, dim3(n_images), dim3(256), 0, (hipStream_t)stream, p);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+/* number of grid nodes per image for the three octaves: sum (size/ns + 1)^2 */
+int alink_perlin_nodes(int size, const int* ns3) {
+    if (!ns3 || size <= 0) return -1;
+    int t = 0;
+    for (int o = 0; o < 3; ++o) {
+        if (ns3[o] <= 0) return -1;
+        const int gs = size / ns3[o] + 1;
+        t += gs * gs;
+    }
+    return t;
+}
+
+int alink_perlin_vectors(int n_images, int nodes_total, uint64_t seed, float* dev_vec, void* stream) {
+    ALINK_REQUIRE(dev_vec && n_images >= 0 && nodes_total > 0, ALINK_EINVAL, "bad argument");
+    const long long n = (long long)n_images * nodes_total;
+    if (n == 0) return ALINK_OK;
+    hipLaunchKernelGGL(perlin_vectors_kernel, g1((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dev_vec, n, seed);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+int alink_noise_perlin(const float* dev_in, float* dev_out, int n_images, int size, int C, const int* ns3,
+                       const float* dev_vec, void* stream) {
+    ALINK_REQUIRE(dev_in && dev_out && dev_vec && ns3 && n_images >= 0 && size > 0 && C > 0, ALINK_EINVAL, "bad argument");
+    PerlinP p{};
+    p.in = dev_in; p.out = dev_out; p.vec = dev_vec; p.size = size; p.C = C;
+    int off = 0;
+    for (int o = 0; o < 3; ++o) {
+        // m.reshape(nc, ns, nc, ns) (code/noise.py:130) needs size == int(size/ns) * ns
+        ALINK_REQUIRE(ns3[o] > 0 && (size / ns3[o]) * ns3[o] == size, ALINK_EINVAL,
+                      "cannot reshape array of size %d into shape (%d,%d,%d,%d)", size * size, size / ns3[o], ns3[o],
+                      size / ns3[o], ns3[o]);
+        p.ns[o] = ns3[o];
+        p.goff[o] = off;
+        const int gs = size / ns3[o] + 1;
+        off += gs * gs;
+    }
+    p.nodes_total = off;
+    if (n_images == 0) return ALINK_OK;
+    hipLaunchKernelGGL(perlin_kernel, dim3((size * size + 255) / 256, n_images), dim3(256), 0, (hipStream_t)stream, p);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+size_t alink_noise_poisson_scratch_bytes(int n_images, int64_t per_image) {
+    if (n_images <= 0 || per_image <= 0) return 0;
+    unsigned long long slots = 1;
+    while (slots < 2ull * (unsigned long long)per_image) slots <<= 1;
+    return (size_t)n_images * slots * 4 + (size_t)n_images * 4;
+}
+
+int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64_t per_image, uint64_t seed,
+                        void* dev_scratch, size_t scratch_bytes, float* dev_vals, void* stream) {
+    ALINK_REQUIRE(dev_in && dev_out && n_images >= 0 && per_image > 0, ALINK_EINVAL, "bad argument");
+    ALINK_REQUIRE(per_image < (1ll << 30), ALINK_EINVAL, "image of %lld elements too large", (long long)per_image);
+    if (n_images == 0) return ALINK_OK;
+    const size_t need = alink_noise_poisson_scratch_bytes(n_images, per_image);
+    ALINK_REQUIRE(dev_scratch && scratch_bytes >= need, ALINK_ENOMEM, "scratch %zu < %zu bytes", scratch_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned int slots = 1;
+    while (slots < 2ull * (unsigned long long)per_image) slots <<= 1;
+    unsigned int* table = (unsigned int*)dev_scratch;
+    unsigned int* count = table + (size_t)n_images * slots;
+    ALINK_HIP(hipMemsetAsync(table, 0xFF, (size_t)n_images * slots * 4, st));
+    ALINK_HIP(hipMemsetAsync(count, 0, (size_t)n_images * 4, st));
+    const dim3 grid((unsigned)((per_image + 255) / 256), n_images);
+    UniqueP u{dev_in, table, count, per_image, slots};
+    hipLaunchKernelGGL(unique_count_kernel, grid, dim3(256), 0, st, u);
+    PoissonP p{dev_in, dev_out, count, dev_vals, per_image, seed};
+    hipLaunchKernelGGL(poisson_kernel, grid, dim3(256), 0, st, p);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+int alink_resize_bilinear(const float* dev_in, float* dev_out, int n, int H, int W, int C, int Ho, int Wo,
+                          void* stream) {
+    ALINK_REQUIRE(dev_in && dev_out && n >= 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, ALINK_EINVAL, "bad argument");
+    const long long total = (long long)n * Ho * Wo * C;
+    if (total == 0) return ALINK_OK;
+    ALINK_REQUIRE(total < (1ll << 39), ALINK_EINVAL, "output too large");
+    ResizeP p{dev_in, dev_out, n, H, W, C, Ho, Wo};
+    hipLaunchKernelGGL(resize_kernel, g1(total), dim3(256), 0, (hipStream_t)stream, p);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+int alink_perturb_images(const float* dev_img, const double* dev_xs, int n, int k, int Hc, int W, int split,
+                         float* dev_out, void* stream) {
+    ALINK_REQUIRE(dev_img && dev_xs && dev_out && n >= 0 && k >= 0 && Hc > 0 && W > 0, ALINK_EINVAL, "bad argument");
+    ALINK_REQUIRE(!split || (Hc % 2) == 0, ALINK_EINVAL, "split needs an even number of rows, got %d", Hc);
+    if (n == 0) return ALINK_OK;
+    PerturbP p{dev_img, dev_xs, dev_out, n, k, Hc, W, split};
+    hipLaunchKernelGGL(perturb_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, p);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+}  // extern "C"

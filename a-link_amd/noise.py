@@ -1,0 +1,253 @@
+"""noise — drop-in for reference code/noise.py: the A2-LINK perturbations, computed on the GPU.
+
+    Noise / Gaussian / SaltPepper / Poisson / Speckle / Perlin      code/noise.py:10-150
+    PredictionWrappedModel                                          code/noise.py:153-168
+    AdversarialNoise                                                code/noise.py:171-188
+    get_relevant_noise(name)                                        code/noise.py:191-205
+
+Same class names, constructor keywords and methods (addIndividualNoise / addNoise / addPairNoise).
+Differences, all deliberate:
+  * a whole batch is one kernel launch (the reference loops images on the host, code/noise.py:20-24);
+  * random numbers come from a counter-based Philox stream on the device (csrc/noise.hip); the
+    reference's np.random global stream is unseeded, so only the distributions are
+    contractual.  Every object takes an optional `seed`; successive calls use successive streams;
+  * outputs are float32 (the reference's are float64 because np.random returns doubles; the models
+    cast to float32 on entry anyway: code/face_model.py:88);
+  * SaltPepper uses the tuple-index meaning the reference's list index had under its NumPy
+    (SURVEY.md §0); Perlin raises the reference's ValueError for sizes its reshape cannot take
+    (112 x 112: code/noise.py:96,130).
+NumPy in -> NumPy out; CUDA tensor in -> CUDA tensor out.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+def _as_device(images, device):
+    import torch
+    if isinstance(images, torch.Tensor):
+        return images.to("cuda:%d" % device, torch.float32).contiguous(), True
+    a = np.ascontiguousarray(np.asarray(images), dtype=np.float32)
+    return torch.from_numpy(a).to("cuda:%d" % device), False
+
+
+def _ret(t, as_torch):
+    return t if as_torch else t.cpu().numpy()
+
+
+class Noise(object):
+    def __init__(self, model=None, sess=None, feature_model=None, seed=None, device=0):
+        self.model = model
+        self.sess = sess
+        self.feature_model = feature_model
+        self.device = device
+        self._seed = int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else int(seed)
+        self._calls = 0
+
+    def _next_seed(self):
+        s = (self._seed + 0x9E3779B97F4A7C15 * self._calls) & 0xFFFFFFFFFFFFFFFF
+        self._calls += 1
+        return s
+
+    # batch hook: subclasses implement _apply(dev_images (n,H,W,C) f32) -> dev tensor
+    def _apply(self, x):
+        return x.clone()
+
+    def addIndividualNoise(self, image, target_labels=None):
+        import torch
+        if isinstance(image, torch.Tensor):
+            return self.addNoise(image[None], None)[0]
+        return self.addNoise(np.asarray(image)[None], None)[0]
+
+    def addNoise(self, images, target_labels):
+        if len(images) == 0:
+            return np.array(images)
+        x, as_torch = _as_device(images if not isinstance(images, (list, tuple)) else np.stack(images), self.device)
+        if x.ndim != 4:
+            raise ValueError("expected images of shape (n, H, W, C), got %s" % (tuple(x.shape),))
+        return _ret(self._apply(x), as_torch)
+
+    def addPairNoise(self, image_pairs, target_labels):
+        left_half = self.addNoise(image_pairs[0], target_labels)
+        right_half = self.addNoise(image_pairs[1], target_labels)
+        return [left_half, right_half]
+
+
+class Gaussian(Noise):
+    def __init__(self, mean=10, var=10, model=None, sess=None, feature_model=None, seed=None, device=0):
+        super(Gaussian, self).__init__(seed=seed, device=device)
+        self.mean = mean
+        self.var = var
+        self.sigma = self.var ** 0.5
+
+    def _apply(self, x):
+        import torch
+        lib = _abi.init(self.device)
+        out = torch.empty_like(x)
+        _abi.check(lib.alink_noise_gaussian(_abi.ptr(x), _abi.ptr(out), x.numel(), float(self.mean), float(self.sigma),
+                                            self._next_seed(), 0, _abi.current_stream()), "alink_noise_gaussian")
+        return out
+
+
+class Speckle(Noise):
+    def __init__(self, model=None, sess=None, feature_model=None, seed=None, device=0):
+        super(Speckle, self).__init__(seed=seed, device=device)
+
+    def _apply(self, x):
+        import torch
+        lib = _abi.init(self.device)
+        out = torch.empty_like(x)
+        _abi.check(lib.alink_noise_speckle(_abi.ptr(x), _abi.ptr(out), x.numel(), 15.0, self._next_seed(), 0,
+                                           _abi.current_stream()), "alink_noise_speckle")
+        return out
+
+
+class SaltPepper(Noise):
+    def __init__(self, s_vs_p=0.5, amount=0.004, model=None, sess=None, feature_model=None, seed=None, device=0):
+        super(SaltPepper, self).__init__(seed=seed, device=device)
+        self.s_vs_p = s_vs_p
+        self.amount = amount
+
+    def counts(self, shape):
+        size = int(np.prod(shape))
+        return (int(np.ceil(self.amount * size * self.s_vs_p)), int(np.ceil(self.amount * size * (1. - self.s_vs_p))))
+
+    def _apply(self, x):
+        import torch
+        lib = _abi.init(self.device)
+        n, H, W, Cc = x.shape
+        if min(H, W, Cc) < 2:
+            raise ValueError("low >= high")                   # np.random.randint(0, i - 1) (code/noise.py:59)
+        n_salt, n_pepper = self.counts((H, W, Cc))
+        out = torch.empty_like(x)
+        _abi.check(lib.alink_noise_saltpepper(_abi.ptr(x), _abi.ptr(out), n, H, W, Cc, n_salt, n_pepper,
+                                              self._next_seed(), _abi.current_stream()), "alink_noise_saltpepper")
+        return out
+
+
+class Poisson(Noise):
+    def __init__(self, model=None, sess=None, feature_model=None, seed=None, device=0):
+        super(Poisson, self).__init__(seed=seed, device=device)
+        self.last_vals = None
+
+    def _apply(self, x):
+        import torch
+        lib = _abi.init(self.device)
+        n = x.shape[0]
+        per = x[0].numel()
+        if bool((x < 0).any()):
+            raise ValueError("lam < 0")                        # np.random.poisson (code/noise.py:75)
+        nbytes = lib.alink_noise_poisson_scratch_bytes(n, per)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        vals = torch.empty(n, dtype=torch.float32, device=x.device)
+        out = torch.empty_like(x)
+        _abi.check(lib.alink_noise_poisson(_abi.ptr(x), _abi.ptr(out), n, per, self._next_seed(), _abi.ptr(scratch),
+                                           nbytes, _abi.ptr(vals), _abi.current_stream()), "alink_noise_poisson")
+        self.last_vals = vals
+        return out
+
+
+class Perlin(Noise):
+    def __init__(self, model=None, sess=None, feature_model=None, seed=None, device=0):
+        super(Perlin, self).__init__(seed=seed, device=device)
+
+    @staticmethod
+    def octaves(row):
+        return [56, 32, 16] if row % 56 == 0 else [50, 30, 15]  # code/noise.py:144-147
+
+    def _apply(self, x, vectors=None):
+        import torch
+        lib = _abi.init(self.device)
+        n, row, col, Cc = x.shape
+        assert row == col                                         # code/noise.py:143
+        ns = self.octaves(row)
+        for s in ns:
+            nc = int(row / s)
+            if nc * s != row:                                     # m.reshape(nc, ns, nc, ns) (code/noise.py:130)
+                raise ValueError("cannot reshape array of size %d into shape (%d,%d,%d,%d)" % (row * row, nc, s, nc, s))
+        ns3 = (C.c_int * 3)(*ns)
+        nodes = lib.alink_perlin_nodes(row, ns3)
+        if vectors is None:
+            vectors = torch.empty((n, nodes, 2), dtype=torch.float32, device=x.device)
+            _abi.check(lib.alink_perlin_vectors(n, nodes, self._next_seed(), _abi.ptr(vectors), _abi.current_stream()),
+                       "alink_perlin_vectors")
+        else:
+            vectors = vectors.to(x.device, torch.float32).contiguous()
+            assert tuple(vectors.shape) == (n, nodes, 2)
+        out = torch.empty_like(x)
+        _abi.check(lib.alink_noise_perlin(_abi.ptr(x), _abi.ptr(out), n, row, Cc, ns3, _abi.ptr(vectors),
+                                          _abi.current_stream()), "alink_noise_perlin")
+        return out
+
+
+def resize_images(images, new_size, device=0):
+    """cv2.resize(image, new_size) per image (code/committee.py:22-26; readMTP.resizeImages,
+    code/readMTP.py:116-119): new_size = (width, height), bilinear."""
+    import torch
+    if len(images) == 0:
+        return np.array(images)
+    x, as_torch = _as_device(images if not isinstance(images, (list, tuple)) else np.stack(images), device)
+    n, H, W, Cc = x.shape
+    Wo, Ho = int(new_size[0]), int(new_size[1])
+    if (Ho, Wo) == (H, W):
+        return _ret(x.clone(), as_torch)
+    lib = _abi.init(device)
+    out = torch.empty((n, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+    _abi.check(lib.alink_resize_bilinear(_abi.ptr(x), _abi.ptr(out), n, H, W, Cc, Ho, Wo, _abi.current_stream()),
+               "alink_resize_bilinear")
+    return _ret(out, as_torch)
+
+
+class PredictionWrappedModel:
+    """code/noise.py:153-168: X = stacked pair images (2H, W, 3); split, embed both halves, score."""
+
+    def __init__(self, model, feature_model):
+        self.model = model
+        self.feature_model = feature_model
+
+    def predict(self, X):
+        half = X[0].shape[0] // 2                                # Python-2 integer division (code/noise.py:160)
+        left_half = [p[:half] for p in X]
+        right_half = [p[half:] for p in X]
+        if self.feature_model:
+            left_features = self.feature_model.process(left_half)
+            right_features = self.feature_model.process(right_half)
+        else:
+            left_features = left_half
+            right_features = right_half
+        return self.model.predict([left_features, right_features])
+
+
+class AdversarialNoise(Noise):
+    def __init__(self, model, sess, feature_model, seed=None, device=0):
+        super(AdversarialNoise, self).__init__(model, sess, feature_model, seed=seed, device=device)
+        from . import attack
+        self.e2e_model = PredictionWrappedModel(model, feature_model)
+        self.attacker = attack.PixelAttacker(self.e2e_model)
+
+    def addPairNoise(self, image_pairs, target_labels):
+        concat_data = [np.concatenate((image_pairs[0][i], image_pairs[1][i]), axis=0)
+                       for i in range(len(image_pairs[0]))]
+        img_shape = image_pairs[0][0].shape
+        perturbed = self.attacker.attack_all(concat_data, target_labels, dimensions=(2 * img_shape[0], img_shape[1]))
+        left_half = [p[:p.shape[0] // 2] for p in perturbed]
+        right_half = [p[p.shape[0] // 2:] for p in perturbed]
+        return [left_half, right_half]
+
+
+def get_relevant_noise(noise_string):
+    noise_mapping = {
+        'gaussian': Gaussian,
+        'saltpepper': SaltPepper,
+        'poisson': Poisson,
+        'speckle': Speckle,
+        'plain': Noise,
+        'perlin': Perlin,
+        'adversarial': AdversarialNoise,
+    }
+    if noise_string.lower() in noise_mapping:
+        return noise_mapping[noise_string.lower()]
+    else:
+        raise NotImplementedError("%s noise is not implemented!" % (noise_string))

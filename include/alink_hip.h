@@ -140,6 +140,13 @@ int alink_committee_forward(alink_head_t* const* heads, int n_heads, const float
                             const float* dev_R, const int32_t* dev_li, const int32_t* dev_ri,
                             int64_t P, float* dev_probs, void* dev_scratch, void* stream);
 
+/* The N x N verification score matrix of utilities/generateMatrixDFW.py:25-36:
+ *   scores[r][j] = mean_m softmax(head_m(|E[row0 + r] - E[j]|))[col],  r < nrows, j < n
+ * (the reference keeps out[0], i.e. col = 0, of one model: n_heads = 1).  Pairs are enumerated by the
+ * kernel; nothing is materialised.  dev_scores is nrows x n float32. */
+int alink_pair_scores_matrix(alink_head_t* const* heads, int n_heads, const float* dev_emb, int n,
+                             int row0, int nrows, int col, float* dev_scores, void* stream);
+
 /* One Keras train_on_batch: forward, binary_crossentropy (clip 1e-7, mean over the 2 outputs,
  * sample-weighted mean over the batch), backward, [grads left in alink_head_grads_dev],
  * then Adadelta.  dev_y is (n,2) one-hot, dev_sw (n) sample weights or NULL.
@@ -206,6 +213,60 @@ int alink_score(int kind, const float* dev_probs, const float* dev_b, int col, i
 size_t alink_topk_scratch_bytes(int64_t P, int k);
 int alink_topk(const float* dev_scores, int64_t P, int k, int largest, int32_t* dev_idx,
                float* dev_vals, void* dev_scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DFW protocol evaluation (utilities/ROC_precompute.py:19-63): over the strict upper triangle of an
+ * n x n score matrix, pairs are genuine / impostor by the protocol mask (codes 1,2 genuine; 3,4
+ * impostor) and roc_case (1: codes 1 vs 3; 2: 2 vs 4; 3: {1,2} vs {3,4}).  dev_hist receives
+ * [2][n_thr+1] counts: hist[k][c] = number of class-k (0 genuine, 1 impostor) scores with exactly c
+ * of the ASCENDING thresholds <= score.  True/false positives at the threshold of rank t are the
+ * suffix sums over c > t (a-link_amd/evaluation.py); the call zeroes dev_hist itself.
+ * ---------------------------------------------------------------------------------------------- */
+int alink_roc_counts(const float* dev_scores, const uint8_t* dev_mask, int n,
+                     const double* dev_thr_sorted, int n_thr, int roc_case,
+                     unsigned long long* dev_hist, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A2-LINK perturbation stage (code/noise.py, code/attack.py:5-29, code/committee.py:22-37).
+ * Images are float32 (n, H, W, C) as everywhere upstream of the models.  Random draws come from a
+ * counter-based Philox4x32-10 keyed by (seed, element index): results do not depend on the launch
+ * shape, and `offset` (multiple of 4 elements) lets a caller process one logical array in chunks.
+ * The reference draws from the unseeded np.random global stream, so only the distributions are
+ * contractual.  In-place (dev_out == dev_in) is allowed for every call except alink_resize_bilinear.
+ * ---------------------------------------------------------------------------------------------- */
+/* noise.Gaussian.addIndividualNoise (code/noise.py:40-45): out = x + N(mean, sigma) */
+int alink_noise_gaussian(const float* dev_in, float* dev_out, int64_t count, float mean, float sigma,
+                         uint64_t seed, uint64_t offset, void* stream);
+/* noise.Speckle.addIndividualNoise (code/noise.py:83-88): out = x + x * N(0,1) / divisor (15) */
+int alink_noise_speckle(const float* dev_in, float* dev_out, int64_t count, float divisor,
+                        uint64_t seed, uint64_t offset, void* stream);
+/* noise.SaltPepper.addIndividualNoise (code/noise.py:54-65), tuple-index semantics: per image n_salt
+ * elements (r,c,ch) <- 1 then n_pepper elements <- 0, r in [0,H-2], c in [0,W-2], ch in [0,C-2]. */
+int alink_noise_saltpepper(const float* dev_in, float* dev_out, int n_images, int H, int W, int C,
+                           int n_salt, int n_pepper, uint64_t seed, void* stream);
+/* noise.Poisson.addIndividualNoise (code/noise.py:72-76): per image vals = 2^ceil(log2(#unique)),
+ * out = Poisson(x * vals) / vals.  dev_vals (optional, n_images) receives vals. */
+size_t alink_noise_poisson_scratch_bytes(int n_images, int64_t per_image);
+int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64_t per_image,
+                        uint64_t seed, void* dev_scratch, size_t scratch_bytes, float* dev_vals,
+                        void* stream);
+/* noise.Perlin (code/noise.py:95-150): three octaves ns3[0..2] of gradient noise on square
+ * size x size images, the same noise added to every channel.  dev_vec holds the unit gradient
+ * vectors [n_images][alink_perlin_nodes(size, ns3)][2], octave after octave, row-major grids of
+ * (size/ns + 1)^2 nodes (code/noise.py:100-107); alink_perlin_vectors fills it with random ones. */
+int alink_perlin_nodes(int size, const int* ns3);
+int alink_perlin_vectors(int n_images, int nodes_total, uint64_t seed, float* dev_vec, void* stream);
+int alink_noise_perlin(const float* dev_in, float* dev_out, int n_images, int size, int C,
+                       const int* ns3, const float* dev_vec, void* stream);
+/* committee.Bagging.resize (code/committee.py:22-26): cv2.resize(image, (Wo, Ho)), INTER_LINEAR */
+int alink_resize_bilinear(const float* dev_in, float* dev_out, int n, int H, int W, int C, int Ho,
+                          int Wo, void* stream);
+/* attack.perturb_image (code/attack.py:5-29): n candidates x k pixels (x, y, r, g, b) as float64
+ * (the DE population, truncated like astype(int)) written into n copies of dev_img (Hc, W, 3).
+ * split = 0: dev_out is (n, Hc, W, 3); split = 1: dev_out is [2][n][Hc/2][W][3], the top and
+ * bottom halves as two contiguous batches (noise.PredictionWrappedModel.predict, code/noise.py:158-168). */
+int alink_perturb_images(const float* dev_img, const double* dev_xs, int n, int k, int Hc, int W,
+                         int split, float* dev_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,214 @@
+"""GPU: the perturbation stage (csrc/noise.hip) against the oracle fed from the same Philox stream,
+distribution checks against the reference's np.random semantics, perturb_image / resize exactness,
+and the few-pixel attack's fused device objective against the generic route."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _imgs(n, h, w, seed, integer=True):
+    rng = np.random.RandomState(seed)
+    x = rng.randint(0, 256, (n, h, w, 3)).astype(np.float32)
+    return x if integer else (x * 0.37 + 1.25).astype(np.float32)
+
+
+def test_gaussian_and_speckle_match_philox_oracle(gpu):
+    from a_link_amd import noise as N
+    from oracle import noise as ON
+    x = _imgs(5, 13, 11, 0, integer=False)                 # 5*13*11*3 = 2145 elements: not a multiple of 4
+    g = N.Gaussian(seed=42)
+    s0 = g._seed
+    got = g.addNoise(x, None)
+    np.testing.assert_allclose(got, ON.philox_gaussian(x, s0, 10.0, 10 ** 0.5), rtol=0, atol=2e-4)
+    got2 = g.addNoise(x, None)                             # next call, next stream
+    assert np.abs(got2 - got).max() > 1.0
+    sp = N.Speckle(seed=7)
+    got = sp.addNoise(x, None)
+    np.testing.assert_allclose(got, ON.philox_speckle(x, sp._seed, 15.0), rtol=0, atol=2e-4)
+    # chunked calls with `offset` continue one stream
+    lib = gpu.load()
+    xd = torch.from_numpy(x.ravel()).cuda()
+    whole, parts = torch.empty_like(xd), torch.empty_like(xd)
+    gpu.check(lib.alink_noise_gaussian(gpu.ptr(xd), gpu.ptr(whole), xd.numel(), 10.0, 3.0, 5, 0, None))
+    cut = 1000
+    gpu.check(lib.alink_noise_gaussian(gpu.ptr(xd), gpu.ptr(parts), cut, 10.0, 3.0, 5, 0, None))
+    gpu.check(lib.alink_noise_gaussian(gpu.ptr(xd[cut:]), gpu.ptr(parts[cut:]), xd.numel() - cut, 10.0, 3.0, 5, cut, None))
+    torch.cuda.synchronize()
+    assert torch.equal(whole, parts)
+
+
+def test_gaussian_speckle_distribution(gpu):
+    """np.random.normal(10, sqrt(10)) / randn()/15 (code/noise.py:41,85): moments and tails at scale."""
+    from scipy import stats
+    from a_link_amd import noise as N
+    x = np.full((64, 112, 112, 3), 100.0, np.float32)
+    d = (N.Gaussian(seed=1).addNoise(x, None) - x).ravel().astype(np.float64)
+    assert abs(d.mean() - 10.0) < 0.01 and abs(d.var() - 10.0) < 0.03
+    assert stats.kstest((d[:200000] - 10) / np.sqrt(10), "norm").pvalue > 1e-3
+    r = ((N.Speckle(seed=2).addNoise(x, None) - x) / x).ravel().astype(np.float64) * 15
+    assert abs(r.mean()) < 0.01 and abs(r.var() - 1.0) < 0.01
+    assert stats.kstest(r[:200000], "norm").pvalue > 1e-3
+
+
+def test_saltpepper_matches_philox_oracle_and_reference_semantics(gpu):
+    from a_link_amd import noise as N
+    from oracle import noise as ON
+    x = _imgs(6, 112, 112, 3) + 2.0                          # no pixel is 0 or 1 beforehand
+    sp = N.SaltPepper(seed=9)
+    got = sp.addNoise(x, None)
+    assert np.array_equal(got, ON.philox_saltpepper(x, sp._seed))
+    n_salt, n_pepper = sp.counts(x.shape[1:])
+    assert (n_salt, n_pepper) == (76, 76) == ON.salt_pepper_counts(x.shape[1:])
+    for i in range(len(x)):
+        ch = np.argwhere(got[i] != x[i])
+        assert 0 < len(ch) <= 152
+        assert ch[:, 0].max() <= 110 and ch[:, 1].max() <= 110 and ch[:, 2].max() <= 1     # randint(0, i - 1)
+        assert set(np.unique(got[i][got[i] != x[i]])) <= {0.0, 1.0}
+    with pytest.raises(ValueError):
+        sp.addNoise(np.zeros((1, 1, 5, 3), np.float32), None)
+
+
+def test_perlin_matches_reference_field_given_same_vectors(gpu):
+    """Feed the unit vectors the reference drew (np.random.seed(4321)) and compare with its output."""
+    from a_link_amd import noise as N
+    from oracle import noise as ON
+    with np.load(os.path.join(GOLD, "noise.npz")) as g:
+        for size in (224, 150):
+            np.random.seed(4321)
+            vec = []
+            for ns in ON.perlin_octaves(size):
+                gs = int(size / ns + 1)
+                phi = np.random.uniform(0, 2 * np.pi, (gs, gs)).ravel()
+                vec.append(np.stack([np.cos(phi), np.sin(phi)], axis=1))
+            vec = np.concatenate(vec)[None].astype(np.float32)
+            p = N.Perlin(seed=0)
+            x = torch.zeros((1, size, size, 3), device="cuda")
+            z = p._apply(x, vectors=torch.from_numpy(vec).cuda()).cpu().numpy()[0]
+            assert np.array_equal(z[..., 0], z[..., 1]) and np.array_equal(z[..., 0], z[..., 2])
+            np.testing.assert_allclose(z[::7, ::5, 0], g["perlin%d_sub" % size], rtol=0, atol=2e-3)
+            m = g["perlin%d_moments" % size]
+            assert abs(z[..., 0].astype(np.float64).sum() - m[0]) < 1e-4 * size * size * 10
+            assert abs(z[..., 0].min() - m[2]) < 2e-3 and abs(z[..., 0].max() - m[3]) < 2e-3
+
+
+def test_perlin_random_vectors_and_errors(gpu):
+    from a_link_amd import noise as N
+    from oracle import noise as ON
+    p = N.Perlin(seed=3)
+    x = _imgs(3, 150, 150, 4)
+    got = p.addNoise(x, None)
+    nodes = sum((150 // ns + 1) ** 2 for ns in (50, 30, 15))
+    vec = ON.philox_perlin_vectors(3, nodes, p._seed)
+    np.testing.assert_allclose(np.linalg.norm(vec, axis=2), 1.0, atol=1e-6)
+    want = ON.perlin_from_vectors(x, vec)
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-3)
+    with pytest.raises(ValueError):                         # the reference cannot run at 112 x 112 either
+        p.addNoise(np.zeros((1, 112, 112, 3), np.float32), None)
+
+
+def test_poisson_matches_philox_oracle(gpu):
+    from a_link_amd import noise as N
+    from oracle import noise as ON
+    x = np.concatenate([_imgs(2, 12, 12, 5), _imgs(2, 12, 12, 6, integer=False)])
+    x[0, :2] = 0.0
+    x[1] = np.round(x[1] / 64)                              # few unique values: vals = 4, lam < 10 branch
+    p = N.Poisson(seed=11)
+    got = p.addNoise(x, None)
+    vals = p.last_vals.cpu().numpy()
+    assert np.array_equal(vals, [ON.poisson_vals(im) for im in x])
+    want = ON.philox_poisson(x, p._seed)
+    assert np.mean(got != want) < 1e-3                       # accept/reject flips on libm ulps are rare
+    np.testing.assert_allclose(got, want, rtol=0, atol=0.5)
+    with pytest.raises(ValueError):
+        p.addNoise(-np.ones((1, 4, 4, 3), np.float32), None)
+
+
+def test_poisson_distribution_at_image_scale(gpu):
+    """Poisson(x vals)/vals has mean x and variance x/vals (code/noise.py:75)."""
+    from a_link_amd import noise as N
+    x = np.tile(np.linspace(0, 255, 112 * 112 * 3, dtype=np.float32).reshape(1, 112, 112, 3), (32, 1, 1, 1))
+    x = np.round(x * 4) / 4                                  # 1021 unique values -> vals = 1024
+    p = N.Poisson(seed=5)
+    y = p.addNoise(x, None).astype(np.float64)
+    assert np.all(p.last_vals.cpu().numpy() == 1024.0)
+    d = (y - x)
+    assert abs(d.mean()) < 2e-3
+    sel = x > 50
+    assert abs((d[sel] ** 2 / (x[sel] / 1024.0)).mean() - 1.0) < 0.01
+    assert np.all(y * 1024 == np.round(y * 1024))            # integer counts / vals
+
+
+def test_perturb_image_matches_reference_golden(gpu):
+    from a_link_amd import attack as A
+    with np.load(os.path.join(GOLD, "noise.npz")) as g:
+        got = A.perturb_image(g["perturb_xs"], g["img"])
+        assert got.dtype == np.float32 and np.array_equal(got, g["perturb_out"])
+        assert np.array_equal(A.perturb_image(g["perturb_xs"][0], g["img"]), g["perturb_one"])
+    from oracle import noise as ON
+    rng = np.random.RandomState(0)
+    img = _imgs(1, 224, 112, 1)[0]
+    xs = rng.rand(200, 200) * np.tile([224, 112, 256, 256, 256], 40)
+    xs[:, 5:7] = xs[:, 0:2]                                   # same position twice: the later pixel wins
+    assert np.array_equal(A.perturb_image(xs, img), ON.perturb_image(xs, img))
+    halves = A._perturb_device(xs, torch.from_numpy(img).cuda(), True).cpu().numpy()
+    full = ON.perturb_image(xs, img)
+    assert np.array_equal(halves[0], full[:, :112]) and np.array_equal(halves[1], full[:, 112:])
+    with pytest.raises(IndexError):
+        A.perturb_image(np.array([[224.0, 0, 1, 2, 3]]), img)
+
+
+def test_resize_bilinear(gpu):
+    from a_link_amd import committee, noise as N
+    from oracle import noise as ON
+    x = _imgs(4, 150, 150, 2, integer=False)
+    for size in ((32, 32), (48, 48), (224, 224), (150, 150), (40, 64)):
+        got = N.resize_images(x, size)
+        want = ON.resize_bilinear(x, size)
+        assert got.shape == (4, size[1], size[0], 3)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
+    assert np.array_equal(N.resize_images(x, (150, 150)), x)
+    c = np.full((2, 9, 7, 3), 3.5, np.float32)
+    np.testing.assert_allclose(N.resize_images(c, (20, 31)), np.full((2, 31, 20, 3), 3.5, np.float32), rtol=2e-7)
+    ramp = np.tile(np.arange(8, dtype=np.float32)[None, None, :, None], (1, 4, 1, 3))
+    np.testing.assert_allclose(N.resize_images(ramp, (4, 4))[0, 0, :, 0], [0.5, 2.5, 4.5, 6.5])   # 2x: pixel-pair means
+    bag = committee.Bagging([], [N.Gaussian(seed=1), N.Noise()])
+    out = bag.attackModel([x[:2], x[2:]], (32, 32), None)
+    assert np.asarray(out[0]).shape == (2, 2, 32, 32, 3)
+    assert np.array_equal(out[1][1], N.resize_images(x[2:], (32, 32)))           # 'plain' noise = resize only
+
+
+def test_pixel_attack_device_objective_equals_generic_route(gpu):
+    """One DE generation's objective through the fused path (perturb -> two embed batches -> head)
+    equals PredictionWrappedModel.predict on host-perturbed images; a short attack lowers 1 - P[0]."""
+    from a_link_amd import attack as A, noise as N, siamese
+    size = (32, 32)
+    fm = siamese.ArcFace(size, "synthetic:r18:3")
+    pm = siamese.SiameseNetwork((512,), "m2", 0.1, seed=4)
+    wrapped = N.PredictionWrappedModel(pm, fm)
+    rng = np.random.RandomState(0)
+    img = _imgs(1, 64, 32, 8)[0]
+    xs = rng.rand(50, 25) * np.tile([64, 32, 256, 256, 256], 5)
+    sc = A._DevicePairScorer(wrapped, img)
+    fused = sc.predict(xs)
+    generic = wrapped.predict(A.perturb_image(xs, img))
+    np.testing.assert_allclose(fused, generic, rtol=0, atol=1e-6)
+    att = A.PixelAttacker(wrapped, seed=np.random.RandomState(1))
+    before = wrapped.predict(img[None])[0]
+    out = att.attack(img, 1, 0, pixel_count=5, dimensions=(64, 32), maxiter=4, popsize=50)
+    after = wrapped.predict(out[None])[0]
+    assert out.shape == img.shape and (out != img).any(axis=2).sum() <= 5
+    assert after[0] >= before[0] - 1e-6
+    assert abs((1 - after[0]) - att.last_result.fun) < 1e-5
+    # AdversarialNoise end to end on two pairs
+    adv = N.AdversarialNoise(pm, None, fm)
+    adv.attacker = A.PixelAttacker(adv.e2e_model, seed=np.random.RandomState(2))
+    orig_all = adv.attacker.attack_all
+    adv.attacker.attack_all = lambda data, t, dimensions: orig_all(data, t, dimensions, pixel_count=3, maxiter=2, popsize=15)
+    pairs = [_imgs(2, 32, 32, 10), _imgs(2, 32, 32, 11)]
+    l, r = adv.addPairNoise(pairs, np.array([[1], [0]]))
+    assert np.asarray(l).shape == (2, 32, 32, 3) and np.asarray(r).shape == (2, 32, 32, 3)
