@@ -14,7 +14,7 @@ from . import weights as W
 
 class IRBackbone(object):
     def __init__(self, params, image_size=(112, 112), emb=512, dtype="bf16", device=0, max_batch=256,
-                 widths=W.WIDTHS, streams=4, shards_per_call=1):
+                 widths=W.WIDTHS, streams=4, shards_per_call=1, bn_eps=2e-5):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
@@ -31,7 +31,7 @@ class IRBackbone(object):
         cfg.height, cfg.width = int(image_size[0]), int(image_size[1])
         cfg.emb = emb
         cfg.dtype = {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16}[dtype]
-        cfg.bn_eps = 2e-5
+        cfg.bn_eps = float(bn_eps)
         self.dtype = dtype
         self.h = self.lib.alink_backbone_create(C.byref(cfg))
         if not self.h:

@@ -5,8 +5,9 @@
     FaceModel.get_input(face_img)                  code/face_model.py:70-84  (HWC -> CHW only)
     FaceModel.get_feature(aligned)                 code/face_model.py:86-93  (forward + L2 normalise)
 
-Differences, all deliberate: the executor is batched (`get_features`), the checkpoint is an .npz
-with MXNet tensor names (or `synthetic:<arch>`), and the MTCNN detector / gender-age model that the
+Differences, all deliberate: the executor is batched (`get_features`), the checkpoint is the MXNet
+pair `<prefix>-symbol.json` + `<prefix>-%04d.params` read without MXNet (mxnet_format.py), an .npz
+with the same tensor names, or `synthetic:<arch>`, and the MTCNN detector / gender-age model that the
 reference constructs but never uses (code/face_model.py:52-67,95-107) are not built.
 """
 import numpy as np
@@ -17,9 +18,10 @@ from .backbone import IRBackbone
 
 def get_model(ctx, image_size, model_str, layer, dtype="bf16", max_batch=256):
     assert layer == "fc1", "the reference slices the symbol at fc1_output (code/face_model.py:36,53)"
-    params = W.resolve_model(model_str, image_size)
+    params, cfg = W.resolve_model_config(model_str, image_size)
     device = ctx if isinstance(ctx, int) else 0
-    return IRBackbone(params, image_size=image_size, dtype=dtype, device=device, max_batch=max_batch)
+    return IRBackbone(params, image_size=image_size, emb=cfg["emb"], dtype=dtype, device=device, max_batch=max_batch,
+                      widths=cfg["widths"], bn_eps=cfg["bn_eps"])
 
 
 class FaceModel(object):

@@ -185,18 +185,50 @@ class DenseHead(KerasFitMixin):
     def set_lr(self, lr):
         _abi.check(self.lib.alink_head_set_lr(self.h, float(lr)))
 
-    def save_weights(self, path):
-        """Side format: <path>.npz with Keras' layer/weight names (no h5py in this environment)."""
-        ws = self.get_weights()
-        names = ["dense_1/kernel", "dense_1/bias", "dense_2/kernel", "dense_2/bias", "dense_3/kernel", "dense_3/bias"]
-        np.savez(path + ".npz" if not path.endswith(".npz") else path, **dict(zip(names, ws)))
+    # Keras' own layer / weight names for the graph built at reference code/siamese.py:24-35 (first model
+    # of a session): Input, Input, Lambda, Dense x3, Activation
+    _KERAS_LAYERS = ["input_1", "input_2", "lambda_1", "dense_1", "dense_2", "dense_3", "activation_1"]
 
-    def load_weights(self, path):
-        p = path if path.endswith(".npz") else path + ".npz"
-        with np.load(p) as z:
+    def save_weights(self, path):
+        """Keras Model.save_weights (reference code/siamese.py:121-125): an HDF5 file in Keras 2.1.2's
+        layout, written by hdf5_lite.py (a path ending in .npz selects NumPy's format instead)."""
+        ws = self.get_weights()
+        if path.endswith(".npz"):
             names = ["dense_1/kernel", "dense_1/bias", "dense_2/kernel", "dense_2/bias", "dense_3/kernel",
                      "dense_3/bias"]
-            self.set_weights([z[n] for n in names])
+            np.savez(path, **dict(zip(names, ws)))
+            return
+        from . import hdf5_lite
+        layers, i = [], 0
+        for name in self._KERAS_LAYERS:
+            if name.startswith("dense"):
+                layers.append((name, [("%s/kernel:0" % name, ws[i]), ("%s/bias:0" % name, ws[i + 1])]))
+                i += 2
+            else:
+                layers.append((name, []))
+        hdf5_lite.save_keras_weights(path, layers)
+
+    def load_weights(self, path):
+        """Keras Model.load_weights (code/siamese.py:116), topological: the weighted layers of the file,
+        in file order, must match this model's (keras/engine/topology.py load_weights_from_hdf5_group)."""
+        with open(path, "rb") as f:
+            magic = f.read(8)
+        if magic[:4] == b"PK\x03\x04":
+            with np.load(path) as z:
+                names = ["dense_1/kernel", "dense_1/bias", "dense_2/kernel", "dense_2/bias", "dense_3/kernel",
+                         "dense_3/bias"]
+                self.set_weights([z[n] for n in names])
+            return
+        from . import hdf5_lite
+        layers = [(n, ws) for n, ws in hdf5_lite.load_keras_weights(path) if ws]
+        if len(layers) != 3:
+            raise ValueError("You are trying to load a weight file containing %d layers into a model with 3 layers."
+                             % len(layers))
+        flat = [a for _, ws in layers for _, a in ws]
+        for a, shp in zip(flat, self._shapes()):
+            if tuple(a.shape) != tuple(shp):
+                raise ValueError("weight of shape %s in the file does not fit %s" % (a.shape, shp))
+        self.set_weights(flat)
 
     # -- device helpers ----------------------------------------------------------------------------
     def _dev(self, a, dtype=None):

@@ -86,11 +86,35 @@ class SmallResNet(KerasFitMixin):
         _abi.check(self.lib.alink_smallres_set_lr(self.h, float(lr)))
 
     def save_weights(self, path):
-        np.savez(path if path.endswith(".npz") else path + ".npz", *self.get_weights())
+        """Keras save_weights of the graph at reference code/siamese.py:139-168: the shared tower is
+        one nested layer `sequential_1` holding conv2d_1..4 and dense_1; the head is dense_2..4."""
+        ws = self.get_weights()
+        if path.endswith(".npz"):
+            np.savez(path, *ws)
+            return
+        from . import hdf5_lite
+        tower = []
+        for i, n in enumerate(["conv2d_1", "conv2d_2", "conv2d_3", "conv2d_4", "dense_1"]):
+            tower += [("%s/kernel:0" % n, ws[2 * i]), ("%s/bias:0" % n, ws[2 * i + 1])]
+        layers = [("input_1", []), ("input_2", []), ("sequential_1", tower), ("lambda_1", [])]
+        for j, n in enumerate(["dense_2", "dense_3", "dense_4"]):
+            layers.append((n, [("%s/kernel:0" % n, ws[10 + 2 * j]), ("%s/bias:0" % n, ws[11 + 2 * j])]))
+        layers.append(("activation_7", []))
+        hdf5_lite.save_keras_weights(path, layers)
 
     def load_weights(self, path):
-        with np.load(path if path.endswith(".npz") else path + ".npz") as z:
-            self.set_weights([z["arr_%d" % i] for i in range(len(self._shapes()))])
+        with open(path, "rb") as f:
+            magic = f.read(4)
+        if magic == b"PK\x03\x04":
+            with np.load(path) as z:
+                self.set_weights([z["arr_%d" % i] for i in range(len(self._shapes()))])
+            return
+        from . import hdf5_lite
+        flat = [a for _, ws in hdf5_lite.load_keras_weights(path) for _, a in ws]
+        shapes = self._shapes()
+        if len(flat) != len(shapes) or any(tuple(a.shape) != tuple(s) for a, s in zip(flat, shapes)):
+            raise ValueError("weight file does not match this SmallRes (%d tensors, expected %d)" % (len(flat), len(shapes)))
+        self.set_weights(flat)
 
     def _dev(self, a):
         torch = self.torch

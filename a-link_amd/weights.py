@@ -99,19 +99,37 @@ def load_npz(path):
         return out
 
 
-def resolve_model(model_str, image_size=(112, 112)):
-    """`args.model` of FaceModel ("prefix,epoch", reference code/face_model.py:29-33) -> params dict.
+def resolve_model_config(model_str, image_size=(112, 112)):
+    """`args.model` of FaceModel ("prefix,epoch", reference code/face_model.py:29-33) ->
+    (params dict, config dict with widths / bn_eps / emb).
 
     prefix forms:  synthetic:<arch>[:seed]   synthetic weights (bench / tests)
-                   <path>                    <path>-%04d.npz (epoch) holding MXNet-named tensors
+                   <path>                    an MXNet checkpoint <path>-symbol.json + <path>-%04d.params
+                                             (what the reference loads, code/face_model.py:34), read by
+                                             mxnet_format.py; else <path>-%04d.npz with the same names
     """
+    import os
     vec = model_str.split(",")
     assert len(vec) == 2, "model must be 'prefix,epoch' (reference code/face_model.py:29-30)"
     prefix, epoch = vec[0], int(vec[1])
+    cfg = {"widths": WIDTHS, "bn_eps": 2e-5, "emb": 512}
     if prefix.startswith("synthetic:"):
         parts = prefix.split(":")
         arch = parts[1]
         seed = int(parts[2]) if len(parts) > 2 else 1
-        return synthetic_ir_params(ARCH_UNITS[arch], size=image_size, seed=seed)
+        return synthetic_ir_params(ARCH_UNITS[arch], size=image_size, seed=seed), cfg
+    if os.path.exists("%s-symbol.json" % prefix) and os.path.exists("%s-%04d.params" % (prefix, epoch)):
+        from . import mxnet_format as MX
+        sym, arg, aux = MX.load_checkpoint(prefix, epoch)
+        got = MX.ir_config_from_symbol(sym, "fc1_output")          # code/face_model.py:35-36
+        params = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in list(arg.items()) + list(aux.items())}
+        if infer_units(params) != got["units"]:
+            raise ValueError("symbol describes units %s but the .params file holds %s" % (got["units"], infer_units(params)))
+        cfg.update(widths=got["widths"], bn_eps=got["bn_eps"], emb=got["emb"])
+        return params, cfg
     path = "%s-%04d.npz" % (prefix, epoch)
-    return load_npz(path)
+    return load_npz(path), cfg
+
+
+def resolve_model(model_str, image_size=(112, 112)):
+    return resolve_model_config(model_str, image_size)[0]

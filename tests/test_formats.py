@@ -1,0 +1,161 @@
+"""CPU: checkpoint formats either side of the hot path — MXNet .params / -symbol.json
+(a-link_amd/mxnet_format.py) and Keras .h5 weight files (a-link_amd/hdf5_lite.py).  The HDF5 code is
+cross-checked against the real libhdf5 when the image has one (tests/h5ref.py)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import a_link_amd  # noqa: F401
+from a_link_amd import hdf5_lite as H5
+from a_link_amd import mxnet_format as MX
+from a_link_amd import weights as W
+
+import h5ref
+
+
+def _head_layers(seed, d=512):
+    rng = np.random.RandomState(seed)
+    mk = lambda *s: rng.randn(*s).astype(np.float32)
+    return [("input_1", []), ("input_2", []), ("lambda_1", []),
+            ("dense_1", [("dense_1/kernel:0", mk(d, 512)), ("dense_1/bias:0", mk(512))]),
+            ("dense_2", [("dense_2/kernel:0", mk(512, 64)), ("dense_2/bias:0", mk(64))]),
+            ("dense_3", [("dense_3/kernel:0", mk(64, 2)), ("dense_3/bias:0", mk(2))]),
+            ("activation_1", [])]
+
+
+def _same(a, b):
+    assert [n for n, _ in a] == [n for n, _ in b]
+    for (_, wa), (_, wb) in zip(a, b):
+        assert [n for n, _ in wa] == [n for n, _ in wb]
+        for (_, x), (_, y) in zip(wa, wb):
+            assert x.dtype == np.float32 and x.shape == y.shape and np.array_equal(x, y)
+
+
+def test_h5_roundtrip_own_writer(tmp_path):
+    layers = _head_layers(0)
+    p = str(tmp_path / "m.h5")
+    H5.save_keras_weights(p, layers)
+    _same(H5.load_keras_weights(p), layers)
+    f = H5.File(p)
+    assert f.attrs["backend"] == b"tensorflow" and f.attrs["keras_version"] == b"2.1.2"
+    assert sorted(f.keys()) == sorted(n for n, _ in layers)
+    assert f["dense_1"]["dense_1"]["kernel:0"].shape == (512, 512)
+    assert "nope" not in f and "dense_2/dense_2/bias:0" in f
+    with pytest.raises(KeyError):
+        f["dense_1/missing"]
+
+
+def test_h5_many_layers_and_names(tmp_path):
+    rng = np.random.RandomState(1)
+    layers = [("conv2d_%d" % i, [("conv2d_%d/kernel:0" % i, rng.randn(3, 3, 2, 4).astype(np.float32)),
+                                 ("conv2d_%d/bias:0" % i, rng.randn(4).astype(np.float32))]) for i in range(1, 40)]
+    layers.insert(3, ("dropout_1", []))
+    p = str(tmp_path / "many.h5")
+    H5.save_keras_weights(p, layers)
+    _same(H5.load_keras_weights(p), layers)
+
+
+@pytest.mark.skipif(h5ref.lib() is None, reason="no libhdf5 in this image")
+def test_h5_reader_on_files_written_by_libhdf5(tmp_path):
+    for seed, d in ((2, 512), (3, 2048)):
+        layers = _head_layers(seed, d)
+        p = str(tmp_path / ("ref%d.h5" % seed))
+        h5ref.write_keras_like(p, layers)
+        _same(H5.load_keras_weights(p), layers)
+        f = H5.File(p)
+        assert f.attrs["backend"] == b"tensorflow"
+        assert [bytes(x) for x in f.attrs["layer_names"]] == [n.encode() for n, _ in layers]
+
+
+@pytest.mark.skipif(h5ref.lib() is None, reason="no libhdf5 in this image")
+def test_h5_writer_output_is_readable_by_libhdf5(tmp_path):
+    layers = _head_layers(4)
+    p = str(tmp_path / "ours.h5")
+    H5.save_keras_weights(p, layers)
+    assert h5ref.read_string_attr(p, "/", "layer_names") == [n.encode() for n, _ in layers]
+    assert h5ref.read_string_attr(p, "/", "backend") == [b"tensorflow"]
+    assert h5ref.read_string_attr(p, "/dense_2", "weight_names") == [b"dense_2/kernel:0", b"dense_2/bias:0"]
+    for lname, ws in layers:
+        for wn, arr in ws:
+            assert np.array_equal(h5ref.read_dataset(p, "/%s/%s" % (lname, wn)), arr)
+
+
+def test_h5_rejects_garbage(tmp_path):
+    p = str(tmp_path / "bad.h5")
+    open(p, "wb").write(b"not hdf5 at all" * 10)
+    with pytest.raises(H5.H5Error):
+        H5.File(p)
+    q = str(tmp_path / "trunc.h5")
+    H5.save_keras_weights(q, _head_layers(5))
+    data = open(q, "rb").read()
+    open(q, "wb").write(data[:len(data) // 3])
+    with pytest.raises((H5.H5Error, KeyError)):
+        H5.load_keras_weights(q)
+
+
+# ---- MXNet ------------------------------------------------------------------------------------------
+def test_params_roundtrip_and_legacy_layouts(tmp_path):
+    params = W.synthetic_ir_params((1, 1, 1, 1), size=(16, 16), seed=2)
+    prefix = str(tmp_path / "model")
+    MX.save_checkpoint(prefix, 0, params)
+    sym, arg, aux = MX.load_checkpoint(prefix, 0)
+    assert set(aux) == {k for k in params if k.endswith("_moving_mean") or k.endswith("_moving_var")}
+    for k, v in params.items():
+        got = aux[k] if k in aux else arg[k]
+        assert got.dtype == np.float32 and np.array_equal(got, v)
+    # V1 and pre-1.0 records decode to the same array
+    a = np.arange(6, dtype=np.float32).reshape(2, 3)
+    v1 = struct.pack("<II2q", MX.V1_MAGIC, 2, 2, 3) + struct.pack("<iii", 1, 0, 0) + a.tobytes()
+    old = struct.pack("<I2I", 2, 2, 3) + struct.pack("<iii", 1, 0, 0) + a.tobytes()
+    for rec in (v1, old):
+        p = str(tmp_path / "x.params")
+        name = b"arg:w"
+        open(p, "wb").write(struct.pack("<QQQ", MX.LIST_MAGIC, 0, 1) + rec + struct.pack("<QQ", 1, len(name)) + name)
+        assert np.array_equal(MX.load_ndarray_file(p)["arg:w"], a)
+    with pytest.raises(ValueError):
+        open(p, "wb").write(b"\0" * 64)
+        MX.load_ndarray_file(p)
+
+
+@pytest.mark.parametrize("arch", ["r100", "r50", "r18"])
+def test_symbol_describes_the_architecture(tmp_path, arch):
+    units = W.ARCH_UNITS[arch]
+    path = str(tmp_path / "m-symbol.json")
+    sym = MX.write_ir_symbol(path, units)
+    cfg = MX.ir_config_from_symbol(MX.load_symbol(path))
+    assert cfg["units"] == tuple(units) and cfg["widths"] == W.WIDTHS and cfg["emb"] == 512
+    assert cfg["bn_eps"] == 2e-5 and cfg["fix_gamma"] == ["fc1"]
+    # every learnable tensor the C library expects is an argument of the graph, and nothing else
+    args = {sym["nodes"][i]["name"] for i in sym["arg_nodes"]} - {"data"}
+    assert args == set(W.tensor_shapes(units))
+
+
+def test_symbol_checks(tmp_path):
+    path = str(tmp_path / "m-symbol.json")
+    sym = MX.write_ir_symbol(path, (1, 1, 1, 1))
+    with pytest.raises(ValueError):
+        MX.ir_config_from_symbol(sym, "fc7_output")
+    bad = MX.load_symbol(path)
+    [n for n in bad["nodes"] if n["name"] == "stage2_unit1_conv2"][0]["attrs"]["stride"] = "(1, 1)"
+    with pytest.raises(ValueError):
+        MX.ir_config_from_symbol(bad)
+    bad = MX.load_symbol(path)
+    [n for n in bad["nodes"] if n["name"] == "_mulscalar0"][0]["attrs"]["scalar"] = "1.0"
+    with pytest.raises(ValueError):
+        MX.ir_config_from_symbol(bad)
+    old = MX.load_symbol(path)                      # MXNet < 1.0 called the attribute dict "param"/"attr"
+    for n in old["nodes"]:
+        if "attrs" in n:
+            n["attr"] = n.pop("attrs")
+    assert MX.ir_config_from_symbol(old)["units"] == (1, 1, 1, 1)
+
+
+def test_resolve_model_prefers_mxnet_pair(tmp_path):
+    params = W.synthetic_ir_params((1, 1, 1, 1), size=(16, 16), seed=5)
+    prefix = str(tmp_path / "model")
+    MX.save_checkpoint(prefix, 0, params)
+    got, cfg = W.resolve_model_config(prefix + ",0", (16, 16))
+    assert cfg["bn_eps"] == 2e-5 and tuple(cfg["widths"]) == W.WIDTHS
+    assert set(got) == set(params) and all(np.array_equal(got[k], params[k]) for k in params)

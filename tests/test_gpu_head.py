@@ -128,6 +128,29 @@ def test_save_load_roundtrip(gpu, tmp_path):
     assert b.maybeLoadFromMemory()
     L, R = _data(10, 512, 0)
     assert np.array_equal(a.predict([L, R]), b.predict([L, R]))
+    # the file is Keras 2.1.2's HDF5 layout (code/siamese.py:121-125): readable by the real libhdf5,
+    # and a file written by libhdf5 the way Keras/h5py would loads back (pretrained disguisedModel.h5)
+    path = str(tmp_path / "model_a.h5")
+    assert open(path, "rb").read(8) == b"\x89HDF\r\n\x1a\n"
+    import h5ref
+    if h5ref.lib() is not None:
+        ws = a.siamese_net.get_weights()
+        assert np.array_equal(h5ref.read_dataset(path, "/dense_1/dense_1/kernel:0"), ws[0])
+        assert np.array_equal(h5ref.read_dataset(path, "/dense_3/dense_3/bias:0"), ws[5])
+        rng = np.random.RandomState(3)
+        layers = [("input_5", []), ("input_6", []), ("lambda_3", []),
+                  ("dense_7", [("dense_7/kernel:0", rng.randn(512, 512).astype(np.float32)), ("dense_7/bias:0", rng.randn(512).astype(np.float32))]),
+                  ("dense_8", [("dense_8/kernel:0", rng.randn(512, 64).astype(np.float32)), ("dense_8/bias:0", rng.randn(64).astype(np.float32))]),
+                  ("dense_9", [("dense_9/kernel:0", rng.randn(64, 2).astype(np.float32)), ("dense_9/bias:0", rng.randn(2).astype(np.float32))]),
+                  ("activation_3", [])]
+        h5ref.write_keras_like(str(tmp_path / "pretrained.h5"), layers)
+        c = siamese.SiameseNetwork((512,), str(tmp_path / "pretrained"), 0.1, seed=9)
+        assert c.maybeLoadFromMemory()
+        got = c.siamese_net.get_weights()
+        want = [w for _, ws_ in layers for _, w in ws_]
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    d = siamese.SiameseNetwork((2048,), str(tmp_path / "model_a"), 0.1, seed=2)
+    assert not d.maybeLoadFromMemory()          # shape mismatch -> any exception -> False (code/siamese.py:114-119)
 
 
 def test_dp_train_step_single_rank_group(gpu):
