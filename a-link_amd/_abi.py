@@ -44,6 +44,16 @@ PROTOTYPES = {
     "alink_embed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "alink_embed_profile": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "alink_conv_nhwc": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
+    "alink_resnet50_create": (_vp, [_i, _i, _i, _f]),
+    "alink_resnet50_destroy": (None, [_vp]),
+    "alink_resnet50_num_tensors": (_i, [_vp]),
+    "alink_resnet50_tensor_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_sz)]),
+    "alink_resnet50_load": (_i, [_vp, C.c_char_p, _vp, _sz]),
+    "alink_resnet50_finalize": (_i, [_vp]),
+    "alink_resnet50_workspace_bytes": (_sz, [_vp, _i]),
+    "alink_resnet50_embed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "alink_resnet50_profile": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp, _vp, _vp, C.POINTER(_i)]),
+    "alink_resnet50_op_name": (C.c_char_p, [_vp, _i]),
     "alink_head_create": (_vp, [_i, _i, _i, _f, _f, _f]),
     "alink_head_destroy": (None, [_vp]),
     "alink_head_num_params": (_sz, [_vp]),

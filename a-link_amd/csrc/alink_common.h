@@ -49,6 +49,7 @@ struct ConvParams {
     int border_cls;       // bias class chosen by output position (3x3, stride 1, pad 1 only)
     int splitk;           // 1 = fused epilogue; >1 = f32 partial slabs
     int ksteps_per_split;
+    int post_relu;        // ReLU after the residual add (bottleneck units: relu(conv + bias + shortcut))
     int ablate;           // diagnostic timing-only modes of conv3x3_direct (0 = normal)
     void* stamps;         // diagnostic: 4 x u64 s_memtime stamps per workgroup, or nullptr
 };

@@ -305,6 +305,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv3x3_direct_kernel(const ConvP
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[8 * h + i] += (float)res[u][h][i];
         }
+        if (p.post_relu) {
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
         if (ok[u]) {
 #pragma unroll
             for (int h = 0; h < CPL / 8; ++h) {

@@ -276,6 +276,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                 v[8 + i] += (float)res[u][1][i];
             }
         }
+        if (p.post_relu) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
         if (ok[u]) {
             vec8 o0, o1;
 #pragma unroll

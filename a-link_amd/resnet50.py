@@ -1,0 +1,167 @@
+"""VGGResNet50 — host-side owner of one alink_resnet50_t handle: the keras-vggface ResNet-50 the
+reference builds at code/siamese.py:203-209, with the slice of the Keras Model API it uses (`predict`).
+
+Weights: a Keras weight file (the `rcmalli_vggface_tf_notop_resnet50.h5` keras-vggface downloads; read
+with hdf5_lite.py), a dict of arrays with Keras names, or synthetic (He-normal convs, BN statistics
+as in weights.synthetic_ir_params) when nothing is given — there is no network here to fetch the
+pretrained file.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+UNITS = (3, 4, 6, 3)
+MID = (64, 128, 256, 512)
+MEAN_BGR = (91.4953, 103.8827, 131.0912)
+
+
+def tensor_shapes():
+    """Ordered {name: shape}: "<layer>/kernel" (kh, kw, in, out) and "<layer>/bn/<stat>" (out,)."""
+    t = {}
+
+    def conv(name, k, cin, cout):
+        t[name + "/kernel"] = (k, k, cin, cout)
+        for s in ("gamma", "beta", "moving_mean", "moving_variance"):
+            t[name + "/bn/" + s] = (cout,)
+    conv("conv1/7x7_s2", 7, 3, 64)
+    cin = 64
+    for s in range(4):
+        mid, out = MID[s], 4 * MID[s]
+        for u in range(1, UNITS[s] + 1):
+            p = "conv%d_%d_" % (s + 2, u)
+            conv(p + "1x1_reduce", 1, cin, mid)
+            conv(p + "3x3", 3, mid, mid)
+            conv(p + "1x1_increase", 1, mid, out)
+            if u == 1:
+                conv(p + "1x1_proj", 1, cin, out)
+            cin = out
+    return t
+
+
+def synthetic_params(seed=1):
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, shape in tensor_shapes().items():
+        if name.endswith("/kernel"):
+            v = rng.standard_normal(shape) * np.sqrt(2.0 / (shape[0] * shape[1] * shape[2]))
+        elif name.endswith("gamma"):
+            # the last BN of a unit small, as trained residual nets have it: keeps activations bounded over 16 units
+            v = rng.uniform(0.2, 0.5, shape) if "increase" in name else rng.uniform(0.5, 1.5, shape)
+        elif name.endswith("beta") or name.endswith("moving_mean"):
+            v = rng.standard_normal(shape) * 0.1
+        else:
+            v = rng.uniform(0.5, 1.5, shape)
+        p[name] = np.ascontiguousarray(v, dtype=np.float32)
+    return p
+
+
+def load_keras_h5(path):
+    """Keras weight file -> {"<layer>/kernel": ..., "<layer>/bn/gamma": ...} (the C library's names)."""
+    from . import hdf5_lite
+    out = {}
+    for lname, ws in hdf5_lite.load_keras_weights(path):
+        for wname, arr in ws:
+            leaf = wname.rsplit("/", 1)[-1].split(":")[0]      # kernel | gamma | beta | moving_mean | moving_variance
+            out[lname + "/" + leaf] = np.ascontiguousarray(arr, dtype=np.float32)
+    return out
+
+
+def save_keras_h5(path, params):
+    from . import hdf5_lite
+    layers = []
+    for name in tensor_shapes():
+        if name.endswith("/kernel"):
+            l = name[:-len("/kernel")]
+            layers.append((l, [(l + "/kernel:0", params[name])]))
+            layers.append((l + "/bn", [(l + "/bn/%s:0" % s, params[l + "/bn/" + s])
+                                       for s in ("gamma", "beta", "moving_mean", "moving_variance")]))
+    hdf5_lite.save_keras_weights(path, layers)
+
+
+class VGGResNet50(object):
+    def __init__(self, image_size=(224, 224), weights=None, dtype="bf16", device=0, max_batch=128, bn_eps=1e-3,
+                 seed=1):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _abi.AlinkError("no ROCm device visible: a-link_amd computes only on the GPU (no CPU fallback)")
+        self.device = device
+        self.lib = _abi.init(device)
+        self.image_size = tuple(image_size)
+        self.max_batch = int(max_batch)
+        if weights is None:
+            params = synthetic_params(seed)
+        elif isinstance(weights, str):
+            params = load_keras_h5(weights)
+        else:
+            params = weights
+        self.h = self.lib.alink_resnet50_create(int(image_size[0]), int(image_size[1]),
+                                                {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16}[dtype], float(bn_eps))
+        if not self.h:
+            raise _abi.AlinkError("alink_resnet50_create: " + self.lib.alink_last_error().decode())
+        name, cnt = C.c_char_p(), C.c_size_t()
+        for i in range(self.lib.alink_resnet50_num_tensors(self.h)):
+            _abi.check(self.lib.alink_resnet50_tensor_info(self.h, i, C.byref(name), C.byref(cnt)))
+            key = name.value.decode()
+            if key not in params:
+                raise KeyError("weights are missing tensor %s" % key)
+            a = np.ascontiguousarray(params[key], dtype=np.float32)
+            _abi.check(self.lib.alink_resnet50_load(self.h, name.value, _abi.ptr(a), a.size), "load " + key)
+        _abi.check(self.lib.alink_resnet50_finalize(self.h), "alink_resnet50_finalize")
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.alink_resnet50_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _workspace(self, n):
+        if self._ws is None or n > self._ws[1]:
+            nbytes = self.lib.alink_resnet50_workspace_bytes(self.h, n)
+            self._ws = (self.torch.empty(nbytes + 256, dtype=self.torch.uint8, device="cuda:%d" % self.device), n)
+        t = self._ws[0]
+        off = (-t.data_ptr()) % 256
+        return t.data_ptr() + off, t.numel() - off
+
+    def embed_device(self, x, preprocessed=False, out=None):
+        """x: CUDA (N, H, W, 3) float32 — raw RGB 0..255, or preprocess()'d when preprocessed=True."""
+        torch = self.torch
+        if x.ndim != 4 or tuple(x.shape[1:]) != self.image_size + (3,):
+            raise ValueError("expected images of shape (N,%d,%d,3), got %s" % (self.image_size + (tuple(x.shape),)))
+        x = x.to(torch.float32).contiguous()
+        n = x.shape[0]
+        if out is None:
+            out = torch.empty((n, 2048), dtype=torch.float32, device=x.device)
+        for i in range(0, n, self.max_batch):
+            m = min(self.max_batch, n - i)
+            ws, wsb = self._workspace(m)
+            _abi.check(self.lib.alink_resnet50_embed(self.h, _abi.ptr(x[i:i + m]), m, 1 if preprocessed else 0,
+                                                     _abi.ptr(out[i:i + m]), C.c_void_p(ws), wsb, _abi.current_stream()),
+                       "alink_resnet50_embed")
+        return out
+
+    def predict(self, X, batch_size=128, verbose=0, preprocessed=True):
+        """Keras Model.predict on PREPROCESSED input (what RESNET50.process passes, code/siamese.py:216)."""
+        torch = self.torch
+        if isinstance(X, torch.Tensor):
+            return self.embed_device(X.to("cuda:%d" % self.device), preprocessed)
+        X = np.ascontiguousarray(np.asarray(X), dtype=np.float32)
+        if len(X) == 0:
+            return np.zeros((0, 2048), np.float32)
+        return self.embed_device(torch.from_numpy(X).to("cuda:%d" % self.device), preprocessed).cpu().numpy()
+
+    def profile(self, x):
+        """One profiled forward on raw pixels: list of (op name, ms, flops)."""
+        n = x.shape[0]
+        out = self.torch.empty((n, 2048), dtype=self.torch.float32, device=x.device)
+        ws, wsb = self._workspace(n)
+        cap = 128
+        ms, fl, k = (C.c_float * cap)(), (C.c_double * cap)(), C.c_int(cap)
+        _abi.check(self.lib.alink_resnet50_profile(self.h, _abi.ptr(x), n, _abi.ptr(out), C.c_void_p(ws), wsb,
+                                                   _abi.current_stream(), ms, fl, C.byref(k)), "alink_resnet50_profile")
+        return [(self.lib.alink_resnet50_op_name(self.h, i).decode(), ms[i], fl[i]) for i in range(k.value)]

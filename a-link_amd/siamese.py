@@ -2,6 +2,7 @@
 
     SiameseNetwork(shape, modelName, learningRate=1.0)      code/siamese.py:19-131
     ArcFace(shape, model_path)                              code/siamese.py:219-234
+    RESNET50(shape)                                         code/siamese.py:203-216  (see resnet50.py)
     SmallRes(imageShape, featureShape, name, learningRate)  code/siamese.py:134-184  (see smallres.py)
 
 Same constructor signatures, attributes (`siamese_net`, `modelName`, `shape`, `learningRate`) and
@@ -138,6 +139,34 @@ class SmallRes(SiameseNetwork, object):
 
     def predict(self, X):
         return self.siamese_net.predict(self.preprocess(X), batch_size=1024)
+
+
+class RESNET50:
+    """code/siamese.py:203-216: VGGFace2 ResNet-50 features (2048-d) at 224 x 224.  `weights`: path of
+    the keras-vggface weight file (`rcmalli_vggface_tf_notop_resnet50.h5`), a dict, or None for
+    synthetic weights (keras-vggface downloads its file; there is no network here)."""
+
+    def __init__(self, shape, weights=None, dtype="bf16", max_batch=128, seed=1):
+        from .resnet50 import VGGResNet50
+        self.shape = shape + (3,)
+        self.model = VGGResNet50(image_size=tuple(shape), weights=weights, dtype=dtype, max_batch=max_batch, seed=seed)
+
+    def preprocess(self, X):
+        """utils.preprocess_input(np.copy(X), version=2): RGB -> BGR, subtract the VGGFace2 channel means."""
+        from .resnet50 import MEAN_BGR
+        X_temp = np.array(X, dtype=np.float32, copy=True)[..., ::-1]
+        X_temp = np.ascontiguousarray(X_temp)
+        X_temp[..., 0] -= MEAN_BGR[0]
+        X_temp[..., 1] -= MEAN_BGR[1]
+        X_temp[..., 2] -= MEAN_BGR[2]
+        return X_temp
+
+    def process(self, X):
+        """model.predict(preprocess(X), batch_size=128); here the flip and mean subtraction run in the
+        stem kernel's loader, so raw pixels go to the device once."""
+        if isinstance(X, (list, tuple)):
+            X = np.stack(X)
+        return self.model.predict(X, batch_size=128, preprocessed=False)
 
 
 class ArcFace:

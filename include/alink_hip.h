@@ -108,6 +108,32 @@ int alink_conv_nhwc(int dtype, const void* dev_in, const void* dev_w, const floa
                     int border_cls, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * VGGFace2 ResNet-50 feature extractor: siamese.RESNET50 (code/siamese.py:203-216) =
+ * keras_vggface VGGFace(model='resnet50', include_top=False) cut at 'avg_pool', flattened (2048-d),
+ * fed through utils.preprocess_input(version=2).  Tensors are handed over with Keras names and
+ * layouts: "<layer>/kernel" (kh, kw, in, out), "<layer>/bn/{gamma,beta,moving_mean,moving_variance}",
+ * layers conv1/7x7_s2 and conv{2..5}_{u}_{1x1_reduce,3x3,1x1_increase,1x1_proj}.
+ * alink_resnet50_embed: dev_in (n, H, W, 3) float32; preprocessed = 0: raw RGB 0..255 pixels (the
+ * BGR flip and mean subtraction of preprocess_input happen in the stem kernel's loader);
+ * preprocessed = 1: the caller already applied RESNET50.preprocess.  dev_out (n, 2048) float32.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct alink_resnet50 alink_resnet50_t;
+alink_resnet50_t* alink_resnet50_create(int height, int width, int dtype, float bn_eps);
+void alink_resnet50_destroy(alink_resnet50_t* r);
+int alink_resnet50_num_tensors(const alink_resnet50_t* r);
+int alink_resnet50_tensor_info(const alink_resnet50_t* r, int i, const char** name, size_t* count);
+int alink_resnet50_load(alink_resnet50_t* r, const char* name, const float* host, size_t count);
+int alink_resnet50_finalize(alink_resnet50_t* r);
+size_t alink_resnet50_workspace_bytes(const alink_resnet50_t* r, int n_images);
+int alink_resnet50_embed(alink_resnet50_t* r, const float* dev_in, int n_images, int preprocessed,
+                         float* dev_out, void* dev_workspace, size_t workspace_bytes, void* stream);
+/* per-op HIP-event timing of one forward (synchronous): ms[i] / flops[i] for op i, name via op_name */
+int alink_resnet50_profile(alink_resnet50_t* r, const float* dev_in, int n_images, float* dev_out,
+                           void* dev_workspace, size_t workspace_bytes, void* stream, float* ms,
+                           double* flops, int* n_ops);
+const char* alink_resnet50_op_name(const alink_resnet50_t* r, int i);
+
+/* ------------------------------------------------------------------------------------------------
  * Siamese pair head: |l - r| -> Dense(h1) ReLU -> Dense(h2) ReLU -> Dense(2) -> softmax.
  * Replaces SiameseNetwork.__init__/predict/finetune/customTrainModel's Keras calls
  * (code/siamese.py:19-35, 52-58, 81-112, 130-131) and committee.Bagging.predict

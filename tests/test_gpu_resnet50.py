@@ -1,0 +1,86 @@
+"""GPU: the VGGFace2 ResNet-50 feature model (csrc/resnet50.hip, siamese.RESNET50) against the
+unfused torch-CPU oracle with identical synthetic weights; preprocess fold, Keras .h5 weights,
+chunking."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos_dist(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+@pytest.fixture(scope="module")
+def net(gpu):
+    from a_link_amd import resnet50 as R, siamese
+    params = R.synthetic_params(3)
+    return siamese.RESNET50((224, 224), weights=params, max_batch=3), params
+
+
+def test_features_match_oracle(net):
+    from oracle import vgg_resnet50 as O
+    m, params = net
+    x = np.random.default_rng(0).integers(0, 256, (5, 224, 224, 3)).astype(np.float32)
+    x[4] = 255.0 - x[0]
+    got = m.process(x)                                  # 5 images through chunks of 3 + 2
+    want = O.process(params, x)
+    assert got.shape == (5, 2048) and got.dtype == np.float32
+    assert _cos_dist(got, want).max() < 1e-3            # bf16 storage, f32 accumulation vs f32 oracle
+    rel = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+    assert rel.max() < 3e-2, rel
+    # f16 storage is tighter on the same weights
+    from a_link_amd import siamese
+    m16 = siamese.RESNET50((224, 224), weights=params, dtype="f16")
+    g16 = m16.process(x[:2] / 8.0 + 100.0)
+    w16 = O.process(params, x[:2] / 8.0 + 100.0)
+    assert _cos_dist(g16, w16).max() < 2e-5
+
+
+def test_preprocess_fold_and_api(net):
+    from oracle import vgg_resnet50 as O
+    m, params = net
+    x = np.random.default_rng(1).integers(0, 256, (2, 224, 224, 3)).astype(np.float32)
+    pre = m.preprocess(x)
+    assert np.array_equal(pre, O.preprocess_input_v2(x)) and pre is not x and x.max() > 200   # np.copy semantics
+    a = m.process(x)                                    # flip + means inside the stem loader
+    b = m.model.predict(pre, batch_size=128)            # the reference's call: predict(preprocess(X))
+    assert np.array_equal(a, b)
+    xd = torch.from_numpy(x).cuda()
+    assert np.array_equal(m.model.embed_device(xd).cpu().numpy(), a)
+    assert m.process(np.zeros((0, 224, 224, 3), np.float32)).shape == (0, 2048)
+    with pytest.raises(ValueError):
+        m.process(np.zeros((1, 112, 112, 3), np.float32))
+    from a_link_amd import _abi, siamese
+    with pytest.raises(_abi.AlinkError):
+        siamese.RESNET50((112, 112))                    # avg_pool((7,7)) needs the 224 x 224 geometry
+
+
+def test_keras_weight_file_roundtrip(net, tmp_path):
+    from a_link_amd import resnet50 as R, siamese
+    m, params = net
+    path = str(tmp_path / "rcmalli_vggface_tf_notop_resnet50.h5")
+    R.save_keras_h5(path, params)
+    back = R.load_keras_h5(path)
+    assert set(back) == set(params) and all(np.array_equal(back[k], params[k]) for k in params)
+    m2 = siamese.RESNET50((224, 224), weights=path)
+    x = np.random.default_rng(2).integers(0, 256, (2, 224, 224, 3)).astype(np.float32)
+    assert np.array_equal(m2.process(x), m.process(x))
+    bad = dict(params)
+    del bad["conv3_1_1x1_proj/kernel"]
+    with pytest.raises(KeyError):
+        siamese.RESNET50((224, 224), weights=bad)
+
+
+def test_alink_py_shape_pipeline(net):
+    """ALINK.py's shapes: RESNET50 features (2048) -> SiameseNetwork((2048,)) -> Bagging mean."""
+    from a_link_amd import committee, siamese
+    m, _ = net
+    x = np.random.default_rng(5).integers(0, 256, (4, 224, 224, 3)).astype(np.float32)
+    f = m.process(x)
+    f = f / np.linalg.norm(f, axis=1, keepdims=True)
+    heads = [siamese.SiameseNetwork((2048,), "e%d" % i, 0.1, seed=i) for i in range(2)]
+    p = committee.Bagging(heads, []).predict([f[:2], f[2:]])
+    assert p.shape == (2, 2) and np.allclose(p.sum(1), 1.0, atol=1e-6)
