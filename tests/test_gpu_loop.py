@@ -1,0 +1,151 @@
+"""GPU: the A-LINK framework loop as library code (a-link_amd/alink_loop.py) against a literal,
+reference-shaped restatement of code/ALINK_arc.py:142-254 on the same models, data and noise seeds:
+identical oracle-query counts, identical fine-tune sets, identical student weights afterwards."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SIZE = (32, 32)
+
+
+def _people(n, seed, lo=2, hi=3):
+    rng = np.random.RandomState(seed)
+    return [rng.randint(0, 256, (rng.randint(lo, hi + 1),) + SIZE + (3,)).astype(np.float32) for _ in range(n)]
+
+
+def _build(seed, noises=("gaussian", "speckle")):
+    from a_link_amd import committee, noise, siamese
+    conv = siamese.ArcFace(SIZE, "synthetic:r18:3")
+    student = siamese.SiameseNetwork((512,), "student", 0.1, seed=seed)
+    ens = [siamese.SiameseNetwork((512,), "ens%d" % i, 0.1, seed=100 + i) for i in range(2)]
+    nz = [noise.get_relevant_noise(n)(model=student, sess=None, feature_model=conv) for n in noises]
+    for i, z in enumerate(nz):
+        z._seed, z._calls = 1000 + i, 0
+    return conv, student, ens, committee.Bagging(ens, nz), nz
+
+
+def _literal_loop(flags, conv, bag, nz, student, X_plain_raw, X_dig_post, dataGen, col):
+    """code/ALINK_arc.py:142-254, line for line (np.argsort made stable; Set -> sorted set)."""
+    from a_link_amd import helpers, pairs
+    tl, tr, ty = np.array([]), np.array([]), np.array([])
+    ACTIVE, UN, sets, fts = 0, 0, [], 0
+    for ii in range(0, len(X_dig_post), flags.alink_bs):
+        batch_x, batch_y = pairs.createMiniBatch(X_plain_raw[ii:ii + flags.alink_bs], X_dig_post[ii:ii + flags.alink_bs])
+        UN += len(batch_x[0])
+        feats = [conv.process(p) for p in batch_x]                       # every pair occurrence embedded
+        ens = bag.predict(feats)
+        noisy = bag.attackModel(batch_x, SIZE, np.argmax(ens, axis=1))
+        noisy = [[conv.process(p) for p in part] for part in noisy]
+        dps = [student.predict([noisy[0][j], noisy[1][j]]) for j in range(len(nz))]
+        mis = []
+        for dp in dps:
+            d = [-np.absolute(dp[j][col] - ens[j][col]) for j in range(len(dp))]
+            mis.append(np.argsort(d, kind="stable")[:int(len(d) * flags.disparity_ratio)])
+        works = set(mis[0].tolist())
+        for m in mis[1:]:
+            works &= set(m.tolist())
+        q = []
+        for j in sorted(works):
+            e = ens[j][col]
+            if e <= 0.5 - flags.eps or e >= 0.5 + flags.eps:
+                ACTIVE += 1
+                if (e >= 0.5) == (batch_y[j][0] >= 0.5):
+                    q.append(j)
+        sets.append(list(q))
+        if not q:
+            continue
+        inter = np.array([ens[i][col] for i in q])
+        mp = int(len(inter) / float(len(nz)))
+        parts_l = [noisy[0][i][q[i * mp:(i + 1) * mp]] for i in range(len(nz))]
+        parts_r = [noisy[1][i][q[i * mp:(i + 1) * mp]] for i in range(len(nz))]
+        parts_y = [helpers.roundoff(inter)[i * mp:(i + 1) * mp] for i in range(len(nz))]
+        tl = np.concatenate(([tl] if ty.shape[0] > 0 else []) + parts_l)
+        tr = np.concatenate(([tr] if ty.shape[0] > 0 else []) + parts_r)
+        ty = np.concatenate(([ty] if ty.shape[0] > 0 else []) + parts_y)
+        if ty.shape[0] >= flags.batch_send:
+            (ol, orr), oy = next(dataGen)
+            for _ in range(flags.mixture_ratio - 1):
+                t, yy = next(dataGen)
+                ol, orr, oy = np.concatenate((ol, t[0])), np.concatenate((orr, t[1])), np.concatenate((oy, yy))
+            tl = np.concatenate((tl, feats[0][q], ol))
+            tr = np.concatenate((tr, feats[1][q], orr))
+            ty = np.concatenate((ty, helpers.roundoff(inter), oy))
+            student.finetune([tl, tr], ty, flags.ft_epochs, 16, 0)
+            fts += 1
+            tl, tr, ty = np.array([]), np.array([]), np.array([])
+        if int(flags.active_ratio * UN) <= ACTIVE:
+            break
+    return ACTIVE, UN, sets, fts
+
+
+@pytest.mark.parametrize("col", [0, 1])
+def test_loop_equals_reference_shaped_loop(gpu, col, tmp_path):
+    from a_link_amd import alink_loop as AL, pairs
+    flags = AL.Flags(alink_bs=3, batch_send=6, disparity_ratio=0.6, eps=0.0005, ft_epochs=2, mixture_ratio=2,
+                     out_model=str(tmp_path / "post"))
+    X_plain, X_dig = _people(6, 1), _people(6, 2)
+    results = []
+    for which in ("library", "literal"):
+        conv, student, ens, bag, nz = _build(7)
+        feats_plain = [conv.process(p) for p in X_plain]
+        gen = pairs.getGenerator(pairs.getNormalGenerator(feats_plain, 8), pairs.getNormalGenerator(feats_plain, 8),
+                                 pairs.getImposterGenerator(feats_plain, feats_plain, 8), 8)
+        np.random.seed(5)                                      # balanced sampling + fit() shuffles
+        if which == "library":
+            sets = []
+            orig = AL.selection.select_queries
+
+            def spy(*a, **k):
+                r = orig(*a, **k)
+                sets.append(list(r[0]))
+                return r
+            AL.selection.select_queries = spy
+            try:
+                st = AL.run_alink_dfw(flags, conv, bag, nz, student, X_plain, X_dig, gen, SIZE, col=col, verbose=0)
+            finally:
+                AL.selection.select_queries = orig
+            results.append((st.active_count, st.un_size, sets, st.finetunes, student.siamese_net.get_weights()))
+            assert (tmp_path / "post.h5").exists()
+        else:
+            a, u, sets, fts = _literal_loop(flags, conv, bag, nz, student, X_plain, X_dig, gen, col)
+            results.append((a, u, sets, fts, student.siamese_net.get_weights()))
+    lib, lit = results
+    assert lib[0] == lit[0] and lib[1] == lit[1] and lib[3] == lit[3]
+    assert lib[2] == lit[2]
+    assert lib[3] >= 1, "test data must trigger at least one fine-tune"
+    for a, b in zip(lib[4], lit[4]):
+        assert np.array_equal(a, b)
+
+
+def test_mtp_loop_runs_and_trains_smallres(gpu, tmp_path):
+    """ALINK_MTP shape (config 1 scaled): high-res teacher features, SmallRes student on low-res pixels."""
+    from a_link_amd import alink_loop as AL, committee, noise, pairs, siamese
+    conv = siamese.ArcFace(SIZE, "synthetic:r18:3")                      # stands in for RESNET50(224) (test_gpu_resnet50 covers it)
+    low = (16, 16)
+    student = siamese.SmallRes(low + (3,), (64,), str(tmp_path / "lowres"), 0.1, seed=2)
+    ens = [siamese.SiameseNetwork((512,), "e%d" % i, 0.1, seed=50 + i) for i in range(2)]
+    nz = [noise.Gaussian(seed=1), noise.Noise()]
+    bag = committee.Bagging(ens, nz)
+    rng = np.random.RandomState(3)
+    people = [rng.randint(0, 256, (2, 40, 40, 3)).astype(np.float32) for _ in range(6)]
+    gen = pairs.getGeneratorMTP(pairs.getNormalGenerator(people, 16), 8, resize_res=low)
+    flags = AL.Flags(alink_bs=3, batch_send=4, disparity_ratio=1.0, eps=0.0, ft_epochs=1, active_ratio=2.0,
+                     out_model=str(tmp_path / "post"))
+    w0 = student.siamese_net.get_weights()
+    np.random.seed(0)
+    st = AL.run_alink_mtp(flags, conv, bag, nz, student, people, gen, SIZE, low, verbose=0)
+    assert st.iterations == 2 and st.un_size == 72 and st.active_count > 0
+    assert st.finetunes >= 1 and any(not np.array_equal(a, b) for a, b in zip(w0, student.siamese_net.get_weights()))
+    acc = AL.top1_identification(student, [np.asarray(noise.resize_images(p, low)) for p in people])
+    assert 0.0 <= acc <= 1.0
+
+
+def test_flags_match_reference_defaults():
+    import argparse
+    from a_link_amd import alink_loop as AL
+    f = AL.add_flags(argparse.ArgumentParser()).parse_args([])
+    assert (f.ft_epochs, f.batch_size, f.batch_send, f.mixture_ratio, f.alink_bs) == (3, 16, 64, 2, 16)
+    assert (f.active_ratio, f.split_ratio, f.disparity_ratio, f.eps) == (1.0, 0.5, 0.25, 0.05)
+    assert f.noise == 'gaussian,saltpepper,poisson,perlin,speckle,adversarial' and f.blind_strategy is False
+    with pytest.raises(AttributeError):
+        AL.Flags(nope=1)
