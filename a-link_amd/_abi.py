@@ -55,6 +55,7 @@ PROTOTYPES = {
     "alink_resnet50_profile": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp, _vp, _vp, C.POINTER(_i)]),
     "alink_resnet50_op_name": (C.c_char_p, [_vp, _i]),
     "alink_head_create": (_vp, [_i, _i, _i, _f, _f, _f]),
+    "alink_head_create_ex": (_vp, [_i, _i, _i, _i, _f, _f, _f]),
     "alink_head_destroy": (None, [_vp]),
     "alink_head_num_params": (_sz, [_vp]),
     "alink_head_set_params": (_i, [_vp, _vp, _sz]),

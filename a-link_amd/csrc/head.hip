@@ -28,6 +28,7 @@ using namespace alink;
 
 struct alink_head {
     int D, h1, h2;
+    int od = 2;                  // outputs: 2 = Dense(2)+softmax (code/siamese.py:31-32), 1 = Dense(1, sigmoid) (code/siamese3.py:25)
     float lr, rho, eps;
     size_t nparams;
     size_t oW1, ob1, oW2, ob2, oW3, ob3;
@@ -63,7 +64,8 @@ struct HeadFwd {
     float final_div;    // > 0: divide by it after adding (last committee member)
     int matN;           // > 0: score-matrix mode, pair p = (mat_row0 + p / matN, p % matN) of one matrix L == R
     int mat_row0;
-    int out_col;        // >= 0: write only this softmax column, probs is [P] (else [P][2])
+    int out_col;        // >= 0: write only this softmax column, probs is [P] (else [P][od])
+    int od;             // 2: softmax over Dense(2); 1: sigmoid of Dense(1)
 };
 
 // out-of-place repack W (in,out) row-major -> [in/8][out][2][4]:  k = 8*k8 + 2*s + h
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const HeadFwd p) {
         a2[i] = fmaxf(s + p.b2[i % h2], 0.f);
     }
     __syncthreads();
-    if (tid < 2 * TP) {
+    if (tid < 2 * TP && p.od == 2) {
         const int row = tid >> 1, cls = tid & 1;
         float z = 0.f;
         for (int c = 0; c < h2; ++c) z = fmaf(a2[row * h2 + c], p.w3[c * 2 + cls], z);
@@ -201,6 +203,19 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const HeadFwd p) {
         const long long pp = p0 + row;
         if (pp < p.P && (p.out_col < 0 || p.out_col == cls)) {
             float* o = p.out_col < 0 ? p.probs + pp * 2 + cls : p.probs + pp;
+            if (p.accumulate) pr += *o;
+            if (p.final_div > 0.f) pr = pr / p.final_div;
+            *o = pr;
+        }
+    } else if (tid < TP && p.od == 1) {
+        const int row = tid;
+        float z = 0.f;
+        for (int c = 0; c < h2; ++c) z = fmaf(a2[row * h2 + c], p.w3[c], z);
+        z += p.b3[0];
+        float pr = 1.f / (1.f + expf(-z));
+        const long long pp = p0 + row;
+        if (pp < p.P) {
+            float* o = p.probs + pp;
             if (p.accumulate) pr += *o;
             if (p.final_div > 0.f) pr = pr / p.final_div;
             *o = pr;
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(512) void dense_fwd_tiled_kernel(const float* __res
 struct HeadLoss {
     const float *z2, *w3, *b3, *y, *sw;
     float *probs, *dz3, *dz2, *gw3, *gb3, *metrics;
-    int n, h2, want_grads;
+    int n, h2, want_grads, od;
     float grad_scale;   // <= 0: 1 / count(sw != 0)
 };
 
@@ -299,8 +314,29 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const HeadLoss p) {
     const float scale = p.grad_scale > 0.f ? p.grad_scale : 1.f / cnt;
 
     float lsum = 0.f, asum = 0.f;
+    const int od = p.od;
     for (int i = tid; i < n; i += 256) {
         const float* a = p.z2 + (size_t)i * h2;
+        const float w = p.sw ? p.sw[i] : 1.f;
+        if (od == 1) {
+            // Dense(1, sigmoid) + binary_crossentropy over one output (code/siamese3.py:25-28)
+            float z = 0.f;
+            for (int c = 0; c < h2; ++c) z = fmaf(fmaxf(a[c], 0.f), p.w3[c], z);
+            z += p.b3[0];
+            const float pr = 1.f / (1.f + expf(-z));
+            p.probs[i] = pr;
+            const float y = p.y[i];
+            const float pc = fminf(fmaxf(pr, 1e-7f), 1.f - 1e-7f);
+            const float x = logf(pc / (1.f - pc));
+            lsum += (fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)))) * w;
+            asum += (rintf(pr) == y) ? 1.f : 0.f;
+            if (p.want_grads) {
+                const bool inside = pr >= 1e-7f && pr <= 1.f - 1e-7f;
+                const float dp = inside ? w * scale * (pc - y) / (pc * (1.f - pc)) : 0.f;
+                p.dz3[i] = dp * pr * (1.f - pr);
+            }
+            continue;
+        }
         float z0 = 0.f, z1 = 0.f;
         for (int c = 0; c < h2; ++c) {
             const float v = fmaxf(a[c], 0.f);
@@ -314,7 +350,6 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const HeadLoss p) {
         const float pr[2] = {e0 / (e0 + e1), e1 / (e0 + e1)};
         p.probs[i * 2 + 0] = pr[0];
         p.probs[i * 2 + 1] = pr[1];
-        const float w = p.sw ? p.sw[i] : 1.f;
         float li = 0.f, acc = 0.f, dp[2];
         for (int c = 0; c < 2; ++c) {
             const float y = p.y[i * 2 + c];
@@ -344,22 +379,23 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const HeadLoss p) {
     if (!p.want_grads) return;
     __syncthreads();   // dz3 written by this block (global, same block -> visible after barrier)
     // dW3[c][j] = sum_i relu(z2[i][c]) * dz3[i][j];  db3[j] = sum_i dz3[i][j]
-    for (int t = tid; t < h2 * 2 + 2; t += 256) {
+    for (int t = tid; t < h2 * od + od; t += 256) {
         float s = 0.f;
-        if (t < h2 * 2) {
-            const int c = t >> 1, j = t & 1;
-            for (int i = 0; i < n; ++i) s = fmaf(fmaxf(p.z2[(size_t)i * h2 + c], 0.f), p.dz3[i * 2 + j], s);
+        if (t < h2 * od) {
+            const int c = t / od, j = t - c * od;
+            for (int i = 0; i < n; ++i) s = fmaf(fmaxf(p.z2[(size_t)i * h2 + c], 0.f), p.dz3[i * od + j], s);
             p.gw3[t] = s;
         } else {
-            const int j = t - h2 * 2;
-            for (int i = 0; i < n; ++i) s += p.dz3[i * 2 + j];
+            const int j = t - h2 * od;
+            for (int i = 0; i < n; ++i) s += p.dz3[i * od + j];
             p.gb3[j] = s;
         }
     }
     // dZ2[i][c] = (z2 > 0) * sum_j dz3[i][j] * w3[c][j]
     for (int t = tid; t < n * h2; t += 256) {
         const int i = t / h2, c = t - i * h2;
-        const float g = p.dz3[i * 2] * p.w3[c * 2] + p.dz3[i * 2 + 1] * p.w3[c * 2 + 1];
+        float g = 0.f;
+        for (int j = 0; j < od; ++j) g = fmaf(p.dz3[i * od + j], p.w3[c * od + j], g);
         p.dz2[t] = p.z2[t] > 0.f ? g : 0.f;
     }
 }
@@ -466,7 +502,7 @@ int launch_fwd(alink_head* h, const float* L, const float* R, const int32_t* li,
     p.w1p = h->d_w1p; p.b1 = h->d_params + h->ob1; p.w2p = h->d_w2p; p.b2 = h->d_params + h->ob2;
     p.w3 = h->d_params + h->oW3; p.b3 = h->d_params + h->ob3; p.probs = probs;
     p.D = h->D; p.h1 = h->h1; p.h2 = h->h2; p.accumulate = accumulate; p.final_div = final_div;
-    p.matN = matN; p.mat_row0 = mat_row0; p.out_col = out_col;
+    p.matN = matN; p.mat_row0 = mat_row0; p.out_col = out_col; p.od = h->od;
     const size_t lds = fwd_lds_bytes(h->h1);
     const dim3 grid((unsigned)((P + TP - 1) / TP)), block(256);
     switch (h->h1 / 128) {
@@ -495,7 +531,7 @@ int small_pass(alink_head* h, const float* L, const float* R, const float* y, co
     HeadLoss lp{};
     lp.z2 = h->d_z2; lp.w3 = P + h->oW3; lp.b3 = P + h->ob3; lp.y = y; lp.sw = sw; lp.probs = h->d_p;
     lp.dz3 = h->d_dz3; lp.dz2 = h->d_dz2; lp.gw3 = G + h->oW3; lp.gb3 = G + h->ob3; lp.metrics = metrics;
-    lp.n = n; lp.h2 = h2; lp.want_grads = want_grads ? 1 : 0; lp.grad_scale = grad_scale;
+    lp.n = n; lp.h2 = h2; lp.want_grads = want_grads ? 1 : 0; lp.grad_scale = grad_scale; lp.od = h->od;
     hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(256), 0, st, lp);
     if (want_grads) {
         hipLaunchKernelGGL(dense_wgrad_kernel, g1((long long)h1 * h2 + h2), dim3(256), 0, st, h->d_z1, h->d_dz2,
@@ -526,14 +562,19 @@ int head_init_attrs() {
 extern "C" {
 
 alink_head_t* alink_head_create(int d_in, int h1, int h2, float lr, float rho, float eps) {
+    return alink_head_create_ex(d_in, h1, h2, 2, lr, rho, eps);
+}
+
+alink_head_t* alink_head_create_ex(int d_in, int h1, int h2, int out_dim, float lr, float rho, float eps) {
+    if (out_dim != 1 && out_dim != 2) { set_error("out_dim=%d must be 1 (sigmoid) or 2 (softmax)", out_dim); return nullptr; }
     if (d_in <= 0 || d_in % 8) { set_error("d_in=%d must be a positive multiple of 8", d_in); return nullptr; }
     if (h1 < 128 || h1 > 512 || h1 % 128) { set_error("h1=%d must be 128, 256, 384 or 512", h1); return nullptr; }
     if (h2 != 32 && h2 != 64) { set_error("h2=%d must be 32 or 64", h2); return nullptr; }
     if (head_init_attrs()) return nullptr;
     alink_head* h = new alink_head();
-    h->D = d_in; h->h1 = h1; h->h2 = h2; h->lr = lr; h->rho = rho; h->eps = eps;
+    h->D = d_in; h->h1 = h1; h->h2 = h2; h->od = out_dim; h->lr = lr; h->rho = rho; h->eps = eps;
     h->oW1 = 0; h->ob1 = (size_t)d_in * h1; h->oW2 = h->ob1 + h1; h->ob2 = h->oW2 + (size_t)h1 * h2;
-    h->oW3 = h->ob2 + h2; h->ob3 = h->oW3 + (size_t)h2 * 2; h->nparams = h->ob3 + 2;
+    h->oW3 = h->ob2 + h2; h->ob3 = h->oW3 + (size_t)h2 * out_dim; h->nparams = h->ob3 + out_dim;
     int rc = 0;
     rc |= head_alloc(h, &h->d_params, h->nparams);
     rc |= head_alloc(h, &h->d_grads, h->nparams);
@@ -613,13 +654,13 @@ int alink_pair_scores_matrix(alink_head_t* const* heads, int n_heads, const floa
     ALINK_REQUIRE(heads && n_heads > 0 && dev_emb && dev_scores, ALINK_EINVAL, "bad argument");
     ALINK_REQUIRE(n > 0 && row0 >= 0 && nrows >= 0 && row0 + nrows <= n, ALINK_EINVAL,
                   "rows [%d, %d) outside a %d x %d matrix", row0, row0 + nrows, n, n);
-    ALINK_REQUIRE(col == 0 || col == 1, ALINK_EINVAL, "col=%d must be 0 or 1", col);
+    ALINK_REQUIRE(col >= 0 && col < heads[0]->od, ALINK_EINVAL, "col=%d outside the model's %d output(s)", col, heads[0]->od);
     if (nrows == 0) return ALINK_OK;
     for (int m = 0; m < n_heads; ++m) {
         ALINK_REQUIRE(heads[m], ALINK_EINVAL, "NULL committee member %d", m);
         const int rc = launch_fwd(heads[m], dev_emb, dev_emb, nullptr, nullptr, (long long)nrows * n, dev_scores,
                                   m > 0, (n_heads > 1 && m == n_heads - 1) ? (float)n_heads : 0.f,
-                                  (hipStream_t)stream, n, row0, col);
+                                  (hipStream_t)stream, n, row0, heads[m]->od == 1 ? -1 : col);
         if (rc) return rc;
     }
     return ALINK_OK;

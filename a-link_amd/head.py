@@ -127,26 +127,43 @@ class KerasFitMixin(object):
         return history
 
 
-class DenseHead(KerasFitMixin):
-    """abs(l - r) -> Dense(h1, relu) -> Dense(h2, relu) -> Dense(2) -> softmax; BCE + Adadelta."""
+def _evaluate(self, x, y, batch_size=32, verbose=0):
+    """Keras Model.evaluate: batch-size-weighted means of test_on_batch -> [loss, acc]."""
+    L, R, y = np.asarray(x[0], np.float32), np.asarray(x[1], np.float32), np.asarray(y, np.float32)
+    tot, seen = np.zeros(2), 0
+    for s in range(0, len(y), batch_size):
+        k = len(y[s:s + batch_size])
+        tot += np.asarray(self.test_on_batch([L[s:s + batch_size], R[s:s + batch_size]], y[s:s + batch_size])) * k
+        seen += k
+    return list(tot / max(seen, 1))
 
-    def __init__(self, d_in, h1=512, h2=64, lr=1.0, rho=0.95, eps=1e-8, seed=None, device=0):
+
+KerasFitMixin.evaluate = _evaluate
+
+
+class DenseHead(KerasFitMixin):
+    """abs(l - r) -> Dense(h1, relu) -> Dense(h2, relu) -> Dense(2) -> softmax; BCE + Adadelta.
+    out_dim=1 is the baseline scripts' variant: Dense(1, sigmoid) (reference code/siamese3.py:25)."""
+
+    def __init__(self, d_in, h1=512, h2=64, lr=1.0, rho=0.95, eps=1e-8, seed=None, device=0, out_dim=2):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
             raise _abi.AlinkError("no ROCm device visible: a-link_amd computes only on the GPU (no CPU fallback)")
         self.device = "cuda:%d" % device
         self.lib = _abi.init(device)
-        self.d_in, self.h1, self.h2 = int(d_in), int(h1), int(h2)
-        self.h = self.lib.alink_head_create(self.d_in, self.h1, self.h2, lr, rho, eps)
+        self.d_in, self.h1, self.h2, self.out_dim = int(d_in), int(h1), int(h2), int(out_dim)
+        self.h = self.lib.alink_head_create_ex(self.d_in, self.h1, self.h2, self.out_dim, lr, rho, eps)
         if not self.h:
             raise _abi.AlinkError("alink_head_create: " + self.lib.alink_last_error().decode())
+        self.loss = "binary_crossentropy"               # what keras_wrapper reads off model.loss
+        self.metrics_names = ["loss", "acc"]
         self.stop_training = False
         rng = np.random.RandomState(seed) if seed is not None else np.random
         # Keras Dense default init: glorot_uniform kernel, zero bias (SURVEY.md §8 row a8)
         self.set_weights([glorot_uniform(rng, d_in, h1), np.zeros(h1, np.float32),
                           glorot_uniform(rng, h1, h2), np.zeros(h2, np.float32),
-                          glorot_uniform(rng, h2, 2), np.zeros(2, np.float32)])
+                          glorot_uniform(rng, h2, self.out_dim), np.zeros(self.out_dim, np.float32)])
         self._metrics = torch.zeros(2, dtype=torch.float32, device=self.device)
 
     def __del__(self):
@@ -159,7 +176,8 @@ class DenseHead(KerasFitMixin):
 
     # -- parameters --------------------------------------------------------------------------------
     def _shapes(self):
-        return [(self.d_in, self.h1), (self.h1,), (self.h1, self.h2), (self.h2,), (self.h2, 2), (2,)]
+        return [(self.d_in, self.h1), (self.h1,), (self.h1, self.h2), (self.h2,), (self.h2, self.out_dim),
+                (self.out_dim,)]
 
     def set_weights(self, ws):
         shapes = self._shapes()
@@ -273,7 +291,7 @@ class DenseHead(KerasFitMixin):
             P = L.shape[0]
         assert L.shape[1] == self.d_in and R.shape[1] == self.d_in
         if out is None:
-            out = torch.empty((P, 2), dtype=torch.float32, device=self.device)
+            out = torch.empty((P, self.out_dim), dtype=torch.float32, device=self.device)
         if P == 0:
             return out
         _abi.check(self.lib.alink_head_forward(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(li), _abi.ptr(ri), P,
@@ -294,7 +312,9 @@ class DenseHead(KerasFitMixin):
         if sample_weight is not None:
             return np.asarray(sample_weight, np.float32)
         if class_weight is not None:
-            cls = np.asarray(y).argmax(axis=1)
+            ya = np.asarray(y)
+            # keras/engine/training.py _standardize_weights: argmax for one-hot targets, the value itself for (n, 1)
+            cls = ya.argmax(axis=1) if ya.shape[1] > 1 else ya[:, 0].astype(int)
             return np.asarray([class_weight[c] for c in cls if c in class_weight], dtype=np.float32)
         return None
 

@@ -2,7 +2,7 @@
 and Committee (code/learners.py:239-416).  BayesianOptimizer / CommitteeRegressor are regression
 tools no reference driver uses and are not provided.
 
-KerasClassifier is the minimal scikit-learn facade the baseline driver wraps around
+KerasClassifier (keras_wrapper.py) is the scikit-learn facade the baseline driver wraps around
 `model.siamese_net` (reference code/existing_al.py:91-101, code/keras_wrapper.py:187-308).
 """
 import numpy as np
@@ -82,46 +82,4 @@ class Committee(BaseCommittee):
         return float(np.sum(w * (np.asarray(y).ravel() == y_pred.ravel())) / np.sum(w))
 
 
-class KerasClassifier(object):
-    """fit / predict / predict_proba / score over a Keras-like model factory (code/keras_wrapper.py)."""
-
-    def __init__(self, build_fn, **sk_params):
-        self.build_fn = build_fn
-        self.sk_params = sk_params
-        self.model = None
-
-    def fit(self, x, y, **kwargs):
-        if self.model is None:
-            self.model = self.build_fn()
-        y = np.asarray(y)
-        if y.ndim == 2 and y.shape[1] > 1:
-            self.classes_ = np.arange(y.shape[1])
-            y_fit = y
-        else:
-            self.classes_ = np.unique(y)
-            from .head import to_categorical
-            y_fit = to_categorical(np.searchsorted(self.classes_, y.ravel()), max(2, len(self.classes_)))
-        self.n_classes_ = len(self.classes_)
-        fit_args = dict(self.sk_params)
-        fit_args.update(kwargs)
-        return self.model.fit(x, y_fit, **fit_args)
-
-    def predict_proba(self, x, **kwargs):
-        if self.model is None:
-            from .uncertainty import NotFittedError
-            raise NotFittedError("KerasClassifier has not been fitted")
-        probs = self.model.predict(x)
-        if probs.shape[1] == 1:
-            probs = np.hstack([1 - probs, probs])
-        return probs
-
-    def predict(self, x, **kwargs):
-        proba = self.predict_proba(x)
-        cls = proba.argmax(axis=-1)
-        return self.classes_[cls] if hasattr(self, "classes_") else cls
-
-    def score(self, x, y, **kwargs):
-        y = np.asarray(y)
-        if y.ndim == 2 and y.shape[1] > 1:
-            y = y.argmax(axis=1)
-        return float(np.mean(self.predict(x) == y.ravel()))
+from .keras_wrapper import KerasClassifier  # noqa: E402,F401  (code/existing_al.py:5 imports it from keras_wrapper)

@@ -142,6 +142,10 @@ const char* alink_resnet50_op_name(const alink_resnet50_t* r, int i);
 typedef struct alink_head alink_head_t;
 
 alink_head_t* alink_head_create(int d_in, int h1, int h2, float lr, float rho, float eps);
+/* out_dim = 2: Dense(2) + softmax (code/siamese.py:31-32); out_dim = 1: Dense(1, sigmoid), the pair
+ * scorer of the baseline scripts (code/siamese3.py:25, used by code/existing_al.py) — probabilities,
+ * labels and metrics are then (n, 1). */
+alink_head_t* alink_head_create_ex(int d_in, int h1, int h2, int out_dim, float lr, float rho, float eps);
 void alink_head_destroy(alink_head_t* h);
 size_t alink_head_num_params(const alink_head_t* h);   /* W1,b1,W2,b2,W3,b3 flattened */
 /* Parameters in Keras order and layout: kernel (in,out) row-major then bias, per layer. */

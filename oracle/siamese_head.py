@@ -22,10 +22,10 @@ def glorot_uniform(rng, fan_in, fan_out):
     return rng.uniform(-lim, lim, (fan_in, fan_out)).astype(np.float32)
 
 
-def init_weights(d_in, h1=512, h2=64, seed=0):
+def init_weights(d_in, h1=512, h2=64, seed=0, out_dim=2):
     rng = np.random.RandomState(seed)
     return [glorot_uniform(rng, d_in, h1), np.zeros(h1, np.float32), glorot_uniform(rng, h1, h2),
-            np.zeros(h2, np.float32), glorot_uniform(rng, h2, 2), np.zeros(2, np.float32)]
+            np.zeros(h2, np.float32), glorot_uniform(rng, h2, out_dim), np.zeros(out_dim, np.float32)]
 
 
 def softmax(z):
@@ -42,7 +42,8 @@ def forward(ws, L, R, dtype=np.float32, cache=False):
     z2 = a1 @ W2 + b2
     a2 = np.maximum(z2, 0)
     z3 = a2 @ W3 + b3
-    p = softmax(z3)
+    # Dense(2) + softmax (code/siamese.py:31-32) or Dense(1, sigmoid) (code/siamese3.py:25)
+    p = softmax(z3) if z3.shape[1] > 1 else (1 / (1 + np.exp(-z3))).astype(z3.dtype)
     if cache:
         return p, (d, z1, a1, z2, a2)
     return p
@@ -83,8 +84,9 @@ def gradients(ws, L, R, y, sw=None, dtype=np.float32):
     eps = dtype(1e-7)
     pc = np.clip(p, eps, 1 - eps)
     inside = (p >= eps) & (p <= 1 - eps)
-    dp = np.where(inside, 0.5 * (pc - y) / (pc * (1 - pc)), 0) * (w / denom)[:, None]
-    dz3 = p * (dp - (dp * p).sum(axis=1, keepdims=True))
+    od = p.shape[1]
+    dp = np.where(inside, (pc - y) / (pc * (1 - pc)) / dtype(od), 0) * (w / denom)[:, None]
+    dz3 = p * (dp - (dp * p).sum(axis=1, keepdims=True)) if od > 1 else dp * p * (1 - p)
     gW3, gb3 = a2.T @ dz3, dz3.sum(axis=0)
     dz2 = (dz3 @ W3.T) * (z2 > 0)
     gW2, gb2 = a1.T @ dz2, dz2.sum(axis=0)
@@ -116,9 +118,9 @@ class Adadelta(object):
 class HeadModel(object):
     """The slice of keras.models.Model used on `siamese_net`."""
 
-    def __init__(self, d_in, h1=512, h2=64, lr=1.0, rho=0.95, epsilon=1e-8, seed=0, dtype=np.float32):
+    def __init__(self, d_in, h1=512, h2=64, lr=1.0, rho=0.95, epsilon=1e-8, seed=0, dtype=np.float32, out_dim=2):
         self.dtype = dtype
-        self.ws = [w.astype(dtype) for w in init_weights(d_in, h1, h2, seed)]
+        self.ws = [w.astype(dtype) for w in init_weights(d_in, h1, h2, seed, out_dim)]
         self.opt = Adadelta([w.shape for w in self.ws], lr, rho, epsilon, dtype)
         self.stop_training = False
 
