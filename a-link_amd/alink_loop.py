@@ -82,8 +82,13 @@ class LoopState(object):
         self.history = []
 
 
+def _np(x):
+    """host ndarray of a NumPy array or a (CUDA) torch tensor"""
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+
 def _concat(old, parts):
-    parts = [np.asarray(p) for p in parts]
+    parts = [_np(p) for p in parts]
     return np.concatenate(([old] if np.asarray(old).shape[0] > 0 else []) + parts)
 
 
@@ -103,14 +108,14 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
     log = print if verbose else (lambda *a, **k: None)
     state.iterations += 1
     state.un_size += len(batch_x[0])
-    ensemblePredictions = np.asarray(bag.predict(batch_x_features))
+    ensemblePredictions = _np(bag.predict(batch_x_features))
     m1_labels = np.argmax(ensemblePredictions, axis=1)
     if labels_one_hot:                      # ALINK_MTP.py:174 passes keras.utils.to_categorical(..., 2)
         m1_labels = helpers.one_hot(m1_labels, 2)
     noisy_data = bag.attackModel(batch_x, image_res, m1_labels)
     noisy_data = [[noisy_for_student(p) for p in part] for part in noisy_data]
     n_noise = len(ensembleNoise)
-    disguisedPredictions = [np.asarray(student.predict([noisy_data[0][jj], noisy_data[1][jj]])) for jj in range(n_noise)]
+    disguisedPredictions = [_np(student.predict([noisy_data[0][jj], noisy_data[1][jj]])) for jj in range(n_noise)]
     queryIndices, active, labels = selection.select_queries(
         ensemblePredictions, disguisedPredictions, batch_y, col=col, disparity_ratio=flags.disparity_ratio,
         eps=flags.eps, blind_strategy=flags.blind_strategy)
@@ -120,8 +125,8 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
         return -1
     q = np.asarray(queryIndices)
     mp = int(len(q) / float(n_noise))
-    state.left = _concat(state.left, [np.asarray(noisy_data[0][i])[q[i * mp:(i + 1) * mp]] for i in range(n_noise)])
-    state.right = _concat(state.right, [np.asarray(noisy_data[1][i])[q[i * mp:(i + 1) * mp]] for i in range(n_noise)])
+    state.left = _concat(state.left, [_np(noisy_data[0][i])[q[i * mp:(i + 1) * mp]] for i in range(n_noise)])
+    state.right = _concat(state.right, [_np(noisy_data[1][i])[q[i * mp:(i + 1) * mp]] for i in range(n_noise)])
     state.y = _concat(state.y, [labels[i * mp:(i + 1) * mp] for i in range(n_noise)])
     added = n_noise * mp
     if state.y.shape[0] >= flags.batch_send:
@@ -134,8 +139,8 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
         if flags.augment:
             raise NotImplementedError("--augment (tf.contrib rotations + imgaug, code/helpers.py:114-141) is outside "
                                       "the hot path and not built")
-        left = np.concatenate((state.left, np.asarray(clean_for_student[0])[q], X_old_left))
-        right = np.concatenate((state.right, np.asarray(clean_for_student[1])[q], X_old_right))
+        left = np.concatenate((state.left, _np(clean_for_student[0])[q], X_old_left))
+        right = np.concatenate((state.right, _np(clean_for_student[1])[q], X_old_right))
         y = np.concatenate((state.y, labels, Y_old))
         hist = student.finetune([left, right], y, flags.ft_epochs, 16, 1 if verbose else 0)
         state.history.append(hist)
@@ -144,18 +149,24 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
     return added
 
 
-def _embed_pairs_unique(conversionModel, plain_part, disguise_part):
-    """Teacher features of createMiniBatch(plain_part, disguise_part) with every image embedded once."""
+def _embed_pairs_unique(conversionModel, plain_part, disguise_part, on_device):
+    """Teacher features of createMiniBatch(plain_part, disguise_part) with every image embedded once.
+    on_device: keep pixels, pair gathers and features as CUDA tensors, so that the P pair occurrences
+    (hundreds of MB of pixels per side) never cross PCIe — noise, resize and embedding all take tensors."""
     n_plain = [len(p) for p in plain_part]
     n_dig = [len(d) for d in disguise_part]
     li, ri, y = pairs.createMiniBatchIndices(n_plain, n_dig)
     unique = np.concatenate([np.asarray(p) for p in plain_part] + [np.asarray(d) for d in disguise_part])
-    feats = np.asarray(conversionModel.process(unique))
+    if on_device:
+        import torch
+        unique = torch.from_numpy(np.ascontiguousarray(unique, dtype=np.float32)).cuda()
+        li, ri = torch.from_numpy(li).long().cuda(), torch.from_numpy(ri).long().cuda()
+    feats = conversionModel.process(unique)
     return unique, li, ri, y, feats
 
 
 def run_alink_dfw(flags, conversionModel, bag, ensembleNoise, disguisedFacesModel, X_plain_raw, X_dig_post, dataGen,
-                  image_res, col=0, verbose=1, state=None):
+                  image_res, col=0, verbose=1, state=None, on_device=True):
     """The framework loop of ALINK_arc.py (col = 0) / ALINK.py (col = 1): code/ALINK_arc.py:139-260.
     X_plain_raw / X_dig_post: per-person lists of raw images (k_i, H, W, 3).  Returns LoopState."""
     log = print if verbose else (lambda *a, **k: None)
@@ -166,7 +177,7 @@ def run_alink_dfw(flags, conversionModel, bag, ensembleNoise, disguisedFacesMode
         log("\nIteration #%d" % ((ii // flags.alink_bs) + 1))
         plain_part = X_plain_raw[ii: ii + flags.alink_bs]
         disguise_part = X_dig_post[ii: ii + flags.alink_bs]
-        unique, li, ri, batch_y, feats = _embed_pairs_unique(conversionModel, plain_part, disguise_part)
+        unique, li, ri, batch_y, feats = _embed_pairs_unique(conversionModel, plain_part, disguise_part, on_device)
         batch_x = [unique[li], unique[ri]]
         batch_x_features = [feats[li], feats[ri]]
         added = alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensembleNoise,

@@ -47,7 +47,8 @@ class Bagging:
     def resize(self, images, new_size):
         """cv2.resize(image, new_size) per image (code/committee.py:22-26); new_size = (width, height)."""
         from . import noise as _noise
-        return np.array(_noise.resize_images(images, new_size))
+        out = _noise.resize_images(images, new_size)
+        return out if hasattr(out, "detach") else np.array(out)      # CUDA tensors stay on the device
 
     def attackModel(self, image_pairs, target_size, target_labels=None):
         perturbed_l, perturbed_r = [], []

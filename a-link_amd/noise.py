@@ -228,6 +228,7 @@ class AdversarialNoise(Noise):
         self.attacker = attack.PixelAttacker(self.e2e_model)
 
     def addPairNoise(self, image_pairs, target_labels):
+        image_pairs = [p.detach().cpu().numpy() if hasattr(p, "detach") else p for p in image_pairs]
         concat_data = [np.concatenate((image_pairs[0][i], image_pairs[1][i]), axis=0)
                        for i in range(len(image_pairs[0]))]
         img_shape = image_pairs[0][0].shape

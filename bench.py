@@ -112,15 +112,37 @@ def main():
 
     if rank == 0 and not args.no_extras:
         # ---- roofline of the dominant kernel (conv_igemm_kernel): HIP events around every launch
-        conv_ms, conv_fl, other_ms = [], [], []
+        conv_ms, conv_fl, other_ms, profs = [], [], [], []
         for _ in range(3):
             prof = bb.profile(x[:args.chunk])
+            profs.append(prof)
             conv_ms.append(sum(ms for k, ms, f in prof if k == 1))
             conv_fl.append(sum(f for k, ms, f in prof if k == 1))
             other_ms.append(sum(ms for k, ms, f in prof if k != 1))
         n_conv = sum(1 for k, _, _ in prof if k == 1)
         cms = float(np.median(conv_ms))
-        achieved = conv_fl[0] / (cms * 1e-3) / 1e12
+        achieved_all = conv_fl[0] / (cms * 1e-3) / 1e12
+        # the DOMINANT kernel: conv launches of one forward grouped by their algorithmic FLOPs (= same
+        # shape = same kernel instantiation); the group with the most time.  For r100/r50 that is the
+        # 14x14x256->256 stage-3 convolution (conv3x3_direct_kernel, 4-wave variant, 2 workgroups/CU).
+        # launch order of the chain: per stage s, unit u: conv1, [shortcut], conv2 (csrc/backbone.hip)
+        shape_of = []
+        for s_ in range(4):
+            for u_ in range(units[s_]):
+                shape_of.append("stage%d %s" % (s_ + 1, "unit1 conv1" if u_ == 0 else "3x3 s1 C->C"))
+                if u_ == 0:
+                    shape_of.append("stage%d unit1 shortcut" % (s_ + 1))
+                shape_of.append("stage%d %s" % (s_ + 1, "unit1 conv2 (stride 2)" if u_ == 0 else "3x3 s1 C->C"))
+        groups = {}
+        for run in profs:
+            convs = [(ms, f) for k, ms, f in run if k == 1]
+            assert len(convs) == len(shape_of)
+            for name, (ms, f) in zip(shape_of, convs):
+                g = groups.setdefault(name, [f, []])
+                g[1].append(ms)
+        dom_name, (dom_f, dom_ms) = max(groups.items(), key=lambda kv: sum(kv[1][1]))
+        dom_avg = float(np.mean(dom_ms))
+        dom_achieved = dom_f / (dom_avg * 1e-3) / 1e12
         # HBM traffic per launch: PMC counters are collected in separate rocprofv3 --pmc passes
         # (tools/pmc_summary.py -> profiles/*pmc_hbm_traffic*.csv); read the newest committed summary
         traffic = None
@@ -134,16 +156,22 @@ def main():
                     if f[0] in ("conv3x3_direct_kernel", "conv_igemm_kernel"):
                         nl += float(f[1]); mb += float(f[2]) + float(f[3])
                 traffic = {"bytes_per_launch": mb * 1e6 / nl, "launches": nl, "per_images": 256,
-                           "source": os.path.basename(pm[-1])}
+                           "note": "mean over all conv launches of a 256-image forward", "source": os.path.basename(pm[-1])}
         except Exception:
             traffic = None
         line["roofline"] = {"bound": "mfma",
-                            "kernel": "conv3x3_direct_kernel + conv_igemm_kernel (all %d conv launches of one "
-                                      "%d-image forward, timed one by one on a single stream)" % (n_conv, args.chunk),
-                            "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
-                            "flops_per_forward": conv_fl[0], "kernel_ms_per_forward": cms,
-                            "avg_launch_ms": cms / n_conv, "non_conv_ms_per_forward": float(np.median(other_ms))}
+                            "kernel": "conv3x3_direct_kernel, %s: %d launches per %d-image forward, %.1f GFLOP each"
+                                      % (dom_name, len(dom_ms) // len(profs), args.chunk, dom_f / 1e9),
+                            "achieved": dom_achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": dom_achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                            "flops_per_launch": dom_f, "avg_launch_ms": dom_avg,
+                            "timing": "HIP events around every launch of the chain on its stream, kernels run one at a "
+                                      "time (alink_embed_profile); rocprofv3 --kernel-trace --stats of `bench.py --streams 1 "
+                                      "--batch %d` gives the same averages (profiles/)" % args.chunk,
+                            "all_conv_launches": {"launches": n_conv, "achieved": achieved_all,
+                                                  "frac": achieved_all / MFMA_PEAK_TFLOPS, "flops_per_forward": conv_fl[0],
+                                                  "kernel_ms_per_forward": cms,
+                                                  "non_conv_ms_per_forward": float(np.median(other_ms))}}
         # ---- fine-tune step (second half of BASELINE.json's metric): head-512, batch 16
         from a_link_amd.head import DenseHead
         hd = DenseHead(512, lr=0.1, seed=0)

@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""One-GPU measurements of BASELINE.json configs[2..4] (the per-GPU share of the 8-GPU shapes), one
+JSON object on stdout.  The headline config is bench.py's; this tool adds the surrounding workloads
+(SURVEY.md §8d synthetic inputs), each checked for finiteness, none of them a substitute for bench.py.
+
+  C3  committee of 3 IR-ResNet-50 backbones + 3 pair heads scoring a pool shard of 12,500 images
+      (100k / 8 GPUs) against a 16-image gallery: embed x3, 200k pairs x3 heads with the committee
+      mean fused, entropy, exact top-1024.
+  C4  one A-LINK iteration (code/ALINK_arc.py:142-254) with an IR-ResNet-100 teacher: 16 persons,
+      2 plain + 3 disguised images each (P = 3840 pairs, 80 unique images), noises
+      gaussian/saltpepper/poisson/speckle drawn per pair occurrence, selection, fine-tune.
+  C5  the A2-LINK adversarial noise: few-pixel differential-evolution attack (40 pixels, popsize 200,
+      <= 50 generations) on r100 pairs; reported per pair (an iteration has thousands of pairs).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def sync_time(fn, reps=1):
+    import torch
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / reps, r
+
+
+def config3(pool_n, out):
+    import numpy as np
+    import torch
+    from a_link_amd import committee, siamese, uncertainty as U
+    members = [siamese.ArcFace((112, 112), "synthetic:r50:%d" % s) for s in (1, 2, 3)]
+    heads = [siamese.SiameseNetwork((512,), "h%d" % i, 0.1, seed=i) for i in range(3)]
+    bag = committee.Bagging(heads, [])
+    g = torch.Generator().manual_seed(0)
+    pool = torch.randint(0, 256, (pool_n, 112, 112, 3), generator=g, dtype=torch.uint8).cuda()
+    gallery = pool[:16]
+    li = torch.arange(pool_n, dtype=torch.int32).repeat_interleave(16).cuda()
+    ri = torch.arange(16, dtype=torch.int32).repeat(pool_n).cuda()
+
+    def run():
+        probs = None
+        embs = []
+        for m in members:                                   # every member embeds the shard (no model parallelism)
+            bb = m.model.model
+            embs.append((bb.embed_device(pool), bb.embed_device(gallery)))
+        # each head scores its own backbone's embeddings; committee mean (code/committee.py:13-20)
+        for h, (ep, eg) in zip(heads, embs):
+            p = h.siamese_net.predict_device(ep, eg, li, ri)
+            probs = p if probs is None else probs + p
+        probs = probs / len(heads)
+        ent = U.score_device(probs, "entropy")
+        idx, vals = U.topk_device(ent, 1024, largest=True)
+        return probs, idx
+    run()
+    dt, (probs, idx) = sync_time(run, 2)
+    assert bool(torch.isfinite(probs).all()) and idx.numel() == 1024
+    out["config3_committee_pool_shard"] = {
+        "pool_images_per_gpu": pool_n, "members": 3, "arch": "r50", "gallery": 16, "pairs": pool_n * 16, "s": dt,
+        "pool_images_per_s": pool_n / dt, "backbone_forwards_per_s": 3 * (pool_n + 16) / dt}
+    del members, heads, bag
+
+
+def _people(n, k, seed):
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    return [rng.randint(0, 256, (k, 112, 112, 3)).astype(np.float32) for _ in range(n)]
+
+
+def config4(out, noises):
+    import numpy as np
+    import torch
+    from a_link_amd import alink_loop as AL, committee, noise, pairs, siamese
+    conv = siamese.ArcFace((112, 112), "synthetic:r100")
+    student = siamese.SiameseNetwork((512,), "/tmp/alink_student", 0.1, seed=1)
+    ens = [siamese.SiameseNetwork((512,), "e1", 0.1, seed=2)]
+    nz = [noise.get_relevant_noise(n)(model=student, sess=None, feature_model=conv) for n in noises]
+    bag = committee.Bagging(ens, nz)
+    X_plain, X_dig = _people(16, 2, 1), _people(16, 3, 2)
+    feats = [conv.process(p) for p in X_plain]
+    gen = pairs.getGenerator(pairs.getNormalGenerator(feats, 16), pairs.getNormalGenerator(feats, 16),
+                             pairs.getImposterGenerator(feats, feats, 16), 16)
+    flags = AL.Flags(out_model="", eps=0.0005)
+    np.random.seed(0)
+    AL.run_alink_dfw(flags, conv, bag, nz, student, X_plain, X_dig, gen, (112, 112), col=0, verbose=0)   # warm-up
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    st = AL.run_alink_dfw(flags, conv, bag, nz, student, X_plain, X_dig, gen, (112, 112), col=0, verbose=0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    P = st.un_size
+    out["config4_alink_iteration_r100"] = {
+        "persons": 16, "unique_images": 80, "pairs": P, "noises": list(noises), "s": dt,
+        "backbone_forwards": 80 + 2 * P * len(noises), "backbone_forwards_per_s": (80 + 2 * P * len(noises)) / dt,
+        "oracle_queries": st.active_count, "finetunes": st.finetunes,
+        "reference_shape_forwards": 2 * P * (1 + len(noises))}
+    return conv, student
+
+
+def config5(out, conv, student, n_pairs):
+    import numpy as np
+    from a_link_amd import attack as A, noise
+    wrapped = noise.PredictionWrappedModel(student, conv)
+    rng = np.random.RandomState(0)
+    imgs = [rng.randint(0, 256, (224, 112, 3)).astype(np.float32) for _ in range(n_pairs)]
+    att = A.PixelAttacker(wrapped, seed=np.random.RandomState(1))
+    # force every generation to run: a callback that never stops, as when the attack does not succeed
+    att.attack_success = lambda *a, **k: None
+    t = time.perf_counter()
+    gens = evals = 0
+    for im in imgs:
+        att.attack(im, 1, 0, pixel_count=40, dimensions=(224, 112), maxiter=50, popsize=250)
+        gens += int(att.last_result.nit)
+        evals += int(att.last_result.nfev)
+    dt = time.perf_counter() - t
+    out["config5_pixel_attack_r100"] = {
+        "pairs": n_pairs, "s_per_pair": dt / n_pairs, "generations_per_pair": gens / n_pairs,
+        "candidate_evaluations_per_pair": evals / n_pairs, "backbone_forwards_per_pair": 2 * evals / n_pairs,
+        "backbone_forwards_per_s": 2 * evals / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pool", type=int, default=12500)
+    ap.add_argument("--attack-pairs", type=int, default=3)
+    ap.add_argument("--noises", default="gaussian,saltpepper,poisson,speckle")
+    ap.add_argument("--skip", default="")
+    a = ap.parse_args()
+    import a_link_amd  # noqa: F401
+    out = {}
+    if "3" not in a.skip:
+        config3(a.pool, out)
+    conv = student = None
+    if "4" not in a.skip:
+        conv, student = config4(out, a.noises.split(","))
+    if "5" not in a.skip:
+        if conv is None:
+            from a_link_amd import siamese
+            conv = siamese.ArcFace((112, 112), "synthetic:r100")
+            student = siamese.SiameseNetwork((512,), "/tmp/alink_student", 0.1, seed=1)
+        config5(out, conv, student, a.attack_pairs)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
