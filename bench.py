@@ -148,15 +148,18 @@ def main():
         traffic = None
         try:
             import glob
-            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic_%s_*.csv" % args.model)))
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01d*pmc_hbm_traffic_%s_*.csv" % args.model)))
             if pm:
-                mb, nl = 0.0, 0.0
-                for ln in open(pm[-1]).read().splitlines()[1:]:
-                    f = ln.split(",")
-                    if f[0] in ("conv3x3_direct_kernel", "conv_igemm_kernel"):
-                        nl += float(f[1]); mb += float(f[2]) + float(f[3])
-                traffic = {"bytes_per_launch": mb * 1e6 / nl, "launches": nl, "per_images": 256,
-                           "note": "mean over all conv launches of a 256-image forward", "source": os.path.basename(pm[-1])}
+                rows = [ln.split(",") for ln in open(pm[-1]).read().splitlines()[1:]]
+                # the dominant instantiation is the conv3x3_direct row with the most launches per forward
+                rows = [r for r in rows if r[0] == "conv3x3_direct_kernel" and r[1]]
+                r = max(rows, key=lambda r: float(r[2]))
+                traffic = {"bytes_per_launch": (float(r[3]) + float(r[4])) * 1e6, "fetch_MB": float(r[3]),
+                           "write_MB": float(r[4]), "launches_per_forward": float(r[2]), "per_images": 256,
+                           "algorithmic_bytes_per_launch": 256 * 196 * 256 * 2 * 2.5 + 256 * 2304 * 2,
+                           "note": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) and WRITE_SIZE, separate passes; "
+                                   "algorithmic = input + output (+ residual on every second launch) + weights",
+                           "source": os.path.basename(pm[-1])}
         except Exception:
             traffic = None
         line["roofline"] = {"bound": "mfma",
@@ -165,9 +168,9 @@ def main():
                             "achieved": dom_achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": dom_achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                             "flops_per_launch": dom_f, "avg_launch_ms": dom_avg,
-                            "timing": "HIP events around every launch of the chain on its stream, kernels run one at a "
-                                      "time (alink_embed_profile); rocprofv3 --kernel-trace --stats of `bench.py --streams 1 "
-                                      "--batch %d` gives the same averages (profiles/)" % args.chunk,
+                            "timing": "HIP events on the launch stream around 4 back-to-back launches of every kernel of "
+                                      "the chain, kernels run one at a time (alink_embed_profile); rocprofv3 --kernel-trace of "
+                                      "`bench.py --streams 1 --batch %d` gives the same averages (profiles/)" % args.chunk,
                             "all_conv_launches": {"launches": n_conv, "achieved": achieved_all,
                                                   "frac": achieved_all / MFMA_PEAK_TFLOPS, "flops_per_forward": conv_fl[0],
                                                   "kernel_ms_per_forward": cms,

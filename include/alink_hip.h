@@ -92,7 +92,8 @@ int alink_embed(alink_backbone_t* bb, const void* dev_in, int layout, int n_imag
                 float* dev_out, void* dev_workspace, size_t workspace_bytes, void* stream);
 
 /* Per-launch timing of one alink_embed with HIP events on `stream` (synchronous; for bench.py's
- * roofline).  ms[i]/flops[i]/kind[i] describe launch i; kind: 0 stem, 1 implicit-GEMM conv,
+ * roofline).  Every kernel is launched 4 times back to back between its events and the mean is
+ * reported, so the events' own cost is not booked as kernel time.  ms[i]/flops[i]/kind[i] describe launch i; kind: 0 stem, 1 implicit-GEMM conv,
  * 2 FC split-K GEMM, 3 FC finish.  *n_launches in: capacity, out: count. */
 int alink_embed_profile(alink_backbone_t* bb, const void* dev_in, int layout, int n_images,
                         float* dev_out, void* dev_workspace, size_t workspace_bytes, void* stream,
