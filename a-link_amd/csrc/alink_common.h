@@ -87,8 +87,15 @@ static inline int perm32_row_of_channel(int c) {
     int q = c >> 3, t = (c >> 2) & 1, j = c & 3;
     return 16 * t + 4 * q + j;
 }
-// weight row of output channel co for a kernel whose lanes hold `cpl` (16 | 8) consecutive channels
+// conv3x3_direct with 4 MFMA tiles per wave: tile t = 2 th + tl, row 4q+j  <->  channel 32 th + 8q + 4 tl + j,
+// i.e. a lane holds two runs of 8 consecutive channels, 32 apart
+static inline int perm64b_row_of_channel(int c) {
+    int th = c >> 5, q = (c >> 3) & 3, tl = (c >> 2) & 1, j = c & 3;
+    return 16 * (2 * th + tl) + 4 * q + j;
+}
+// weight row of output channel co; cpl: 16 = perm64 (conv_igemm, stems), 17 = perm64b, 8 = perm32
 static inline int permuted_row(int co, int cpl) {
+    if (cpl == 17) return (co & ~63) + perm64b_row_of_channel(co & 63);
     return cpl == 16 ? (co & ~63) + perm64_row_of_channel(co & 63) : (co & ~31) + perm32_row_of_channel(co & 31);
 }
 

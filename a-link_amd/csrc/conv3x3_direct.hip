@@ -258,9 +258,16 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv3x3_direct_kernel(const ConvP
     if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
     // ---- epilogue ---------------------------------------------------------------------------------------
     // All residual loads are issued first (independent, one exposed latency), bias/alpha come from LDS.
-    constexpr int CPL = TCW * 4;                                   // consecutive channels per lane
-    const int cl = wco * (16 * TCW) + CPL * q;                     // channel offset inside the BN block
-    const int cbase = n0 + cl;
+    // A lane holds CPL = 4 TCW channels of each of its pixels, as runs of 8 consecutive channels
+    // (one 16-B store each).  TCW = 2: one run, channels 8q ..; the four q-lanes of a pixel write 64
+    // contiguous bytes.  TCW = 4: two runs, channels 32h + 8q .. (h = 0, 1) — the weight rows are
+    // permuted for exactly this (perm64b_row_of_channel) so that, per store instruction, the four
+    // q-lanes of a pixel again cover 64 CONTIGUOUS bytes instead of four 16-B pieces 32 B apart.
+    constexpr int CPL = TCW * 4;
+    const int wbase = wco * (16 * TCW);                            // wave's channel block inside BN
+    auto chan_t = [&](int t) { return wbase + (TCW == 4 ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) : 8 * q + 4 * t); };
+    auto chan_h = [&](int h) { return wbase + (TCW == 4 ? 32 * h + 8 * q : 8 * q); };
+    const int cbase = n0;
     size_t off[TPW];
     bool ok[TPW];
     int cls[TPW];
@@ -280,21 +287,21 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv3x3_direct_kernel(const ConvP
 #pragma unroll
         for (int u = 0; u < TPW; ++u)
 #pragma unroll
-            for (int h = 0; h < CPL / 8; ++h) res[u][h] = *(const vec8*)((const T*)p.resid + off[u] + 8 * h);
+            for (int h = 0; h < CPL / 8; ++h) res[u][h] = *(const vec8*)((const T*)p.resid + off[u] + chan_h(h));
     }
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
         float v[CPL];
 #pragma unroll
         for (int t = 0; t < TCW; ++t) {
-            const f32x4 b4 = *(const f32x4*)(ebias + cls[u] * BN + cl + 4 * t);
+            const f32x4 b4 = *(const f32x4*)(ebias + cls[u] * BN + chan_t(t));
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[4 * t + j] = acc[t][u][j] + b4[j];
         }
         if (p.alpha) {
 #pragma unroll
             for (int t = 0; t < TCW; ++t) {
-                const f32x4 a4 = *(const f32x4*)(ealpha + cl + 4 * t);
+                const f32x4 a4 = *(const f32x4*)(ealpha + chan_t(t));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[4 * t + j] = v[4 * t + j] > 0.f ? v[4 * t + j] : v[4 * t + j] * a4[j];
             }
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv3x3_direct_kernel(const ConvP
                 vec8 o8;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o8[i] = (T)v[8 * h + i];
-                *(vec8*)((T*)p.out + off[u] + 8 * h) = o8;
+                *(vec8*)((T*)p.out + off[u] + chan_h(h)) = o8;
             }
         }
     }
@@ -389,8 +396,8 @@ int direct_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout
     if (tr == 7 && pitch == 128 && W == 112 && D6::fits(Cin)) return 6;
     return 0;
 }
-// consecutive output channels per lane of a variant: 16 -> perm64 weight rows, 8 -> perm32
-int direct_variant_cpl(int v) { return (v == 1 || v == 2 || v == 7 || v == 8) ? 16 : 8; }
+// weight-row permutation code of a variant (permuted_row): 17 -> perm64b (TCW = 4), 8 -> perm32 (TCW = 2)
+int direct_variant_cpl(int v) { return (v == 1 || v == 2 || v == 7 || v == 8) ? 17 : 8; }
 
 hipError_t direct_set_attributes() {
     hipError_t e;
