@@ -7,11 +7,14 @@
 // (floor); Dropout(rate) in training multiplies kept units by 1/(1-rate); Flatten of NHWC is
 // (h, w, c)-major; Dense kernel (in,out).
 //
-// Sizes are tiny (32x32 or 48x48 inputs, batch 16 pairs = 32 tower passes, 24 MMAC each), the step is
-// latency-bound: plain f32 VALU kernels, one thread per output element, coalesced along channels.
+// Every convolution and the wide Dense layer — forward, input-gradient and weight-gradient — is an
+// exact-f32 GEMM on the f32-input matrix cores (sgemm.hip: implicit im2col gathers, flipped-kernel
+// gather for the input gradient, pixel-reduction with a ones row for weight + bias gradients,
+// deterministic split-K); pooling / dropout / ReLU masks are small elementwise kernels.
 // The pair head (|l-r| -> 128 -> 32 -> 2) is an alink_head handle (head.hip); this file adds the
 // tower forward/backward and ties the two Adadelta states together.
 #include "alink_common.h"
+#include "sgemm.h"
 
 #include <vector>
 
@@ -27,37 +30,6 @@ namespace {
 constexpr int MAXN = 256;           // pairs per call (host code chunks larger requests)
 
 inline dim3 g1(long long n) { return dim3((unsigned)((n + 255) / 256), 1, 1); }
-
-// out[n][oy][ox][co] = relu( b[co] + sum in[n][oy+ky-pad][ox+kx-pad][ci] * w[ky][kx][ci][co] )
-__global__ void conv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                const float* __restrict__ b, float* __restrict__ out, int N, int H, int W, int Ci,
-                                int Co, int pad, int prescale) {
-    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)N * Ho * Wo * Co) return;
-    const int co = (int)(i % Co);
-    long long r = i / Co;
-    const int ox = (int)(r % Wo); r /= Wo;
-    const int oy = (int)(r % Ho);
-    const int n = (int)(r / Ho);
-    float s = 0.f;
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy + ky - pad;
-        if ((unsigned)iy >= (unsigned)H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox + kx - pad;
-            if ((unsigned)ix >= (unsigned)W) continue;
-            const float* ip = in + (((size_t)n * H + iy) * W + ix) * Ci;
-            const float* wp = w + ((size_t)(ky * 3 + kx) * Ci) * Co + co;
-            for (int ci = 0; ci < Ci; ++ci) {
-                float x = ip[ci];
-                if (prescale) x = (x - 128.f) / 128.f;
-                s = fmaf(x, wp[(size_t)ci * Co], s);
-            }
-        }
-    }
-    out[i] = fmaxf(s + b[co], 0.f);
-}
 
 // 2x2/2 max pool (+ optional dropout: keep-mask u8, scale 1/(1-rate)); records the argmax (0..3)
 __global__ void pool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, uint8_t* __restrict__ arg,
@@ -105,114 +77,11 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dpool, const uint8_t* 
     dact[i] = act[i] > 0.f ? g : 0.f;          // relu of the conv that produced `act`
 }
 
-// din[n][iy][ix][ci] = sum_{ky,kx,co} dz[n][iy-ky+pad][ix-kx+pad][co] * w[ky][kx][ci][co];
-// if act != nullptr the result is additionally masked by relu'(act) (act = din's own forward value)
-__global__ void conv_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w,
-                                     const float* __restrict__ act, float* __restrict__ din, int N, int H, int W,
-                                     int Ci, int Co, int pad) {
-    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)N * H * W * Ci) return;
-    const int ci = (int)(i % Ci);
-    long long r = i / Ci;
-    const int ix = (int)(r % W); r /= W;
-    const int iy = (int)(r % H);
-    const int n = (int)(r / H);
-    float s = 0.f;
-    for (int ky = 0; ky < 3; ++ky) {
-        const int oy = iy - ky + pad;
-        if ((unsigned)oy >= (unsigned)Ho) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ox = ix - kx + pad;
-            if ((unsigned)ox >= (unsigned)Wo) continue;
-            const float* dp = dz + (((size_t)n * Ho + oy) * Wo + ox) * Co;
-            const float* wp = w + ((size_t)(ky * 3 + kx) * Ci + ci) * Co;
-            for (int co = 0; co < Co; ++co) s = fmaf(dp[co], wp[co], s);
-        }
-    }
-    if (act) s = act[i] > 0.f ? s : 0.f;
-    din[i] = s;
-}
-
-// dw[ky][kx][ci][co] += sum over a chunk of (n,oy,ox);  db[co] likewise.  grid.y = pixel chunks,
-// partial sums combined with float atomics (dw/db zeroed before the launch).
-__global__ void conv_bwd_weight_kernel(const float* __restrict__ in, const float* __restrict__ dz,
-                                       float* __restrict__ dw, float* __restrict__ db, int N, int H, int W,
-                                       int Ci, int Co, int pad, int prescale, int chunk) {
-    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int total = 9 * Ci * Co;
-    const long long P = (long long)N * Ho * Wo;
-    const long long p0 = (long long)blockIdx.y * chunk, p1 = min(P, p0 + chunk);
-    if (i < total) {
-        const int co = i % Co;
-        int r = i / Co;
-        const int ci = r % Ci; r /= Ci;
-        const int kx = r % 3, ky = r / 3;
-        float s = 0.f;
-        for (long long pp = p0; pp < p1; ++pp) {
-            const int ox = (int)(pp % Wo);
-            const long long q = pp / Wo;
-            const int oy = (int)(q % Ho), n = (int)(q / Ho);
-            const int iy = oy + ky - pad, ix = ox + kx - pad;
-            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
-            float x = in[(((size_t)n * H + iy) * W + ix) * Ci + ci];
-            if (prescale) x = (x - 128.f) / 128.f;
-            s = fmaf(x, dz[(size_t)pp * Co + co], s);
-        }
-        atomicAdd(dw + i, s);
-    } else if (i < total + Co) {
-        const int co = i - total;
-        float s = 0.f;
-        for (long long pp = p0; pp < p1; ++pp) s += dz[(size_t)pp * Co + co];
-        atomicAdd(db + co, s);
-    }
-}
-
-// z[r][c] = relu(sum_k a[r][k] w[k][c] + b[c])
-__global__ void dense_relu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
-                                      const float* __restrict__ b, float* __restrict__ z, int n, int K, int C) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n * C) return;
-    const int r = i / C, c = i - r * C;
-    const float* ar = a + (size_t)r * K;
-    float s = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < K; ++k) s = fmaf(ar[k], w[(size_t)k * C + c], s);
-    z[i] = fmaxf(s + b[c], 0.f);
-}
 // dz = dout * relu'(z);  gw[k][c] = sum_r a[r][k] dz[r][c];  gb[c] = sum_r dz[r][c]
 __global__ void relu_mask_kernel(const float* __restrict__ z, const float* __restrict__ d, float* __restrict__ dz,
                                  long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dz[i] = z[i] > 0.f ? d[i] : 0.f;
-}
-__global__ void dense_wgrad2_kernel(const float* __restrict__ a, const float* __restrict__ dz,
-                                    float* __restrict__ gw, float* __restrict__ gb, int n, int K, int C) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < (long long)K * C) {
-        const int k = (int)(i / C), c = (int)(i - (long long)k * C);
-        float s = 0.f;
-        for (int r = 0; r < n; ++r) s = fmaf(a[(size_t)r * K + k], dz[(size_t)r * C + c], s);
-        gw[i] = s;
-    } else if (i < (long long)K * C + C) {
-        const int c = (int)(i - (long long)K * C);
-        float s = 0.f;
-        for (int r = 0; r < n; ++r) s += dz[(size_t)r * C + c];
-        gb[c] = s;
-    }
-}
-// da[r][k] = sum_c dz[r][c] w[k][c]
-__global__ void dense_dgrad2_kernel(const float* __restrict__ dz, const float* __restrict__ w,
-                                    float* __restrict__ da, int n, int K, int C) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n * K) return;
-    const int r = i / K, k = i - r * K;
-    const float* wr = w + (size_t)k * C;
-    const float* dr = dz + (size_t)r * C;
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s = fmaf(dr[c], wr[c], s);
-    da[i] = s;
 }
 __global__ void adadelta2_kernel(float* __restrict__ prm, const float* __restrict__ g, float* __restrict__ a,
                                  float* __restrict__ d, size_t n, float lr, float rho, float eps) {
@@ -247,6 +116,8 @@ struct alink_smallres {
     float *dfeat = nullptr;
     uint8_t *arg1 = nullptr, *arg2 = nullptr;
     float* d_all_grads = nullptr;      // [tower grads | head grads] contiguous copy for all-reduce
+    float* ws = nullptr;               // split-K slabs of sgemm
+    size_t ws_floats = 0;
     std::vector<void*> allocs;
     ~alink_smallres() {
         for (void* p : allocs) (void)hipFree(p);
@@ -266,38 +137,76 @@ int sr_alloc(alink_smallres* m, V** p, size_t count) {
 
 const int CI[4] = {3, 32, 32, 64}, CO[4] = {32, 32, 64, 64}, PAD[4] = {1, 0, 1, 0};
 
+int run_gemm(alink_smallres* m, GemmP& g, int max_split, hipStream_t st) {
+    gemm32_plan_split(g, max_split);
+    ALINK_REQUIRE(gemm32_workspace_floats(g) <= m->ws_floats, ALINK_ENOMEM, "sgemm workspace too small (%zu floats)",
+                  gemm32_workspace_floats(g));
+    ALINK_HIP(launch_gemm32(g, m->ws, st));
+    return ALINK_OK;
+}
+
+// out = relu(conv3x3(in, w[layer]) + b[layer]); in is [nb][H][W][Ci]
+int conv_fwd(alink_smallres* m, const float* in, float* out, int layer, int nb, int H, int W, int prescale,
+             hipStream_t st) {
+    const int Ci = CI[layer], Co = CO[layer], pad = PAD[layer];
+    GemmP g{};
+    g.A = in; g.B = m->d_p + m->oW[layer]; g.C = out;
+    g.Ho = H + 2 * pad - 2; g.Wo = W + 2 * pad - 2;
+    g.M = nb * g.Ho * g.Wo; g.N = Co; g.K = 9 * Ci; g.ldb = Co; g.ldc = Co;
+    g.amode = A_CONV; g.bmode = B_ROW; g.H = H; g.W = W; g.Ci = Ci; g.pad = pad; g.prescale = prescale;
+    g.bias = m->d_p + m->oB[layer]; g.relu = 1;
+    return run_gemm(m, g, 1, st);
+}
+
 // tower forward on `nb` images; masks == nullptr -> inference (no dropout)
 int tower_fwd(alink_smallres* m, const float* img, int nb, int prescale, const uint8_t* mask1, const uint8_t* mask2,
               hipStream_t st) {
     const float* P = m->d_p;
     const float keep_scale = 1.f / (1.f - 0.25f);
-    hipLaunchKernelGGL(conv_fwd_kernel, g1((long long)nb * m->H * m->W * 32), dim3(256), 0, st, img, P + m->oW[0],
-                       P + m->oB[0], m->a1, nb, m->H, m->W, 3, 32, 1, prescale);
-    hipLaunchKernelGGL(conv_fwd_kernel, g1((long long)nb * m->H1 * m->W1 * 32), dim3(256), 0, st, m->a1, P + m->oW[1],
-                       P + m->oB[1], m->a2, nb, m->H, m->W, 32, 32, 0, 0);
+    int rc;
+    if ((rc = conv_fwd(m, img, m->a1, 0, nb, m->H, m->W, prescale, st))) return rc;
+    if ((rc = conv_fwd(m, m->a1, m->a2, 1, nb, m->H, m->W, 0, st))) return rc;
     hipLaunchKernelGGL(pool_fwd_kernel, g1((long long)nb * m->P1h * m->P1w * 32), dim3(256), 0, st, m->a2, m->p1,
                        m->arg1, mask1, keep_scale, nb, m->H1, m->W1, 32);
-    hipLaunchKernelGGL(conv_fwd_kernel, g1((long long)nb * m->P1h * m->P1w * 64), dim3(256), 0, st, m->p1, P + m->oW[2],
-                       P + m->oB[2], m->a3, nb, m->P1h, m->P1w, 32, 64, 1, 0);
-    hipLaunchKernelGGL(conv_fwd_kernel, g1((long long)nb * m->H3 * m->W3 * 64), dim3(256), 0, st, m->a3, P + m->oW[3],
-                       P + m->oB[3], m->a4, nb, m->P1h, m->P1w, 64, 64, 0, 0);
+    if ((rc = conv_fwd(m, m->p1, m->a3, 2, nb, m->P1h, m->P1w, 0, st))) return rc;
+    if ((rc = conv_fwd(m, m->a3, m->a4, 3, nb, m->P1h, m->P1w, 0, st))) return rc;
     hipLaunchKernelGGL(pool_fwd_kernel, g1((long long)nb * m->P2h * m->P2w * 64), dim3(256), 0, st, m->a4, m->p2,
                        m->arg2, mask2, keep_scale, nb, m->H3, m->W3, 64);
-    hipLaunchKernelGGL(dense_relu_fwd_kernel, g1((long long)nb * m->feat), dim3(256), 0, st, m->p2, P + m->oDW,
-                       P + m->oDB, m->f, nb, m->flat, m->feat);
+    // f = relu(p2 . W + b): [nb][flat] x [flat][feat]
+    GemmP g{};
+    g.A = m->p2; g.B = P + m->oDW; g.C = m->f; g.M = nb; g.N = m->feat; g.K = m->flat;
+    g.lda = m->flat; g.ldb = m->feat; g.ldc = m->feat; g.amode = A_ROW; g.bmode = B_ROW;
+    g.bias = P + m->oDB; g.relu = 1;
+    if ((rc = run_gemm(m, g, 16, st))) return rc;
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
 }
 
+// dW[layer], db[layer] (contiguous in the gradient buffer) from the layer input `in` [nb][H][W][Ci]
+// and dz [nb][Ho][Wo][Co]; `accumulate` adds to what is there (second siamese branch of conv1)
 int wgrad(alink_smallres* m, const float* in, const float* dz, int layer, int nb, int H, int W, int prescale,
+          int accumulate, hipStream_t st) {
+    const int Ci = CI[layer], Co = CO[layer], pad = PAD[layer];
+    GemmP g{};
+    g.A = in; g.B = dz; g.C = m->d_g + m->oW[layer];
+    g.Ho = H + 2 * pad - 2; g.Wo = W + 2 * pad - 2;
+    g.M = 9 * Ci + 1; g.N = Co; g.K = nb * g.Ho * g.Wo; g.ldb = Co; g.ldc = Co;      // row 9 Ci = bias gradient
+    g.amode = A_CONVT; g.bmode = B_ROW; g.H = H; g.W = W; g.Ci = Ci; g.pad = pad; g.prescale = prescale;
+    g.accumulate = accumulate;
+    return run_gemm(m, g, 128, st);
+}
+
+// din [nb][H][W][Ci] = conv-transpose of dz [nb][Ho][Wo][Co] with w[layer], masked by relu'(act) if act
+int dgrad(alink_smallres* m, const float* dz, float* din, const float* act, int layer, int nb, int H, int W,
           hipStream_t st) {
     const int Ci = CI[layer], Co = CO[layer], pad = PAD[layer];
-    const long long P = (long long)nb * (H + 2 * pad - 2) * (W + 2 * pad - 2);
-    const int chunk = 1024;
-    dim3 grid((9 * Ci * Co + Co + 255) / 256, (unsigned)((P + chunk - 1) / chunk), 1);
-    hipLaunchKernelGGL(conv_bwd_weight_kernel, grid, dim3(256), 0, st, in, dz, m->d_g + m->oW[layer],
-                       m->d_g + m->oB[layer], nb, H, W, Ci, Co, pad, prescale, chunk);
-    return ALINK_OK;
+    GemmP g{};
+    g.A = dz; g.B = m->d_p + m->oW[layer]; g.C = din;
+    g.H = H + 2 * pad - 2; g.W = W + 2 * pad - 2;          // the gathered tensor is dz
+    g.Ci = Co; g.Ho = H; g.Wo = W; g.pad = 2 - pad;
+    g.M = nb * H * W; g.N = Ci; g.K = 9 * Co; g.ldc = Ci;
+    g.amode = A_CONV; g.bmode = B_FLIP; g.act = act;
+    return run_gemm(m, g, 1, st);
 }
 
 }  // namespace
@@ -337,6 +246,8 @@ alink_smallres_t* alink_smallres_create(int img_h, int img_w, int feat, float lr
     rc |= sr_alloc(m, &m->arg1, nb * m->P1h * m->P1w * 32);
     rc |= sr_alloc(m, &m->arg2, nb * m->P2h * m->P2w * 64);
     rc |= sr_alloc(m, &m->d_all_grads, m->ntower + alink_head_num_params(m->head));
+    m->ws_floats = (size_t)16 << 20;
+    rc |= sr_alloc(m, &m->ws, m->ws_floats);
     if (rc) { delete m; return nullptr; }
     return m;
 }
@@ -439,28 +350,33 @@ int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const flo
         float* G = m->d_g;
         const int nb = 2 * n;
         const float keep_scale = 1.f / (1.f - 0.25f);
-        ALINK_HIP(hipMemsetAsync(G, 0, m->oDW * sizeof(float), st));
         hipLaunchKernelGGL(relu_mask_kernel, g1((long long)nb * m->feat), dim3(256), 0, st, m->f, m->dfeat, m->da,
                            (long long)nb * m->feat);
-        hipLaunchKernelGGL(dense_wgrad2_kernel, g1((long long)m->flat * m->feat + m->feat), dim3(256), 0, st, m->p2,
-                           m->da, G + m->oDW, G + m->oDB, nb, m->flat, m->feat);
-        hipLaunchKernelGGL(dense_dgrad2_kernel, g1((long long)nb * m->flat), dim3(256), 0, st, m->da, P + m->oDW, m->db,
-                           nb, m->flat, m->feat);
+        {   // gW[flat][feat] = p2^T . dz ; gb = column sums
+            GemmP g{};
+            g.A = m->p2; g.B = m->da; g.C = G + m->oDW; g.M = m->flat; g.N = m->feat; g.K = nb;
+            g.lda = m->flat; g.ldb = m->feat; g.ldc = m->feat; g.amode = A_COL; g.bmode = B_ROW;
+            if ((rc = run_gemm(m, g, 1, st))) return rc;
+            ALINK_HIP(launch_colsum(m->da, G + m->oDB, nb, m->feat, st));
+        }
+        {   // d(p2)[nb][flat] = dz . W^T
+            GemmP g{};
+            g.A = m->da; g.B = P + m->oDW; g.C = m->db; g.M = nb; g.N = m->flat; g.K = m->feat;
+            g.lda = m->feat; g.ldb = m->feat; g.ldc = m->flat; g.amode = A_ROW; g.bmode = B_COLT;
+            if ((rc = run_gemm(m, g, 16, st))) return rc;
+        }
         hipLaunchKernelGGL(pool_bwd_kernel, g1((long long)nb * m->H3 * m->W3 * 64), dim3(256), 0, st, m->db, m->arg2, m2,
                            keep_scale, m->a4, m->da, nb, m->H3, m->W3, 64);
-        wgrad(m, m->a3, m->da, 3, nb, m->P1h, m->P1w, 0, st);
-        hipLaunchKernelGGL(conv_bwd_data_kernel, g1((long long)nb * m->P1h * m->P1w * 64), dim3(256), 0, st, m->da,
-                           P + m->oW[3], m->a3, m->db, nb, m->P1h, m->P1w, 64, 64, 0);
-        wgrad(m, m->p1, m->db, 2, nb, m->P1h, m->P1w, 0, st);
-        hipLaunchKernelGGL(conv_bwd_data_kernel, g1((long long)nb * m->P1h * m->P1w * 32), dim3(256), 0, st, m->db,
-                           P + m->oW[2], (const float*)nullptr, m->da, nb, m->P1h, m->P1w, 32, 64, 1);
+        if ((rc = wgrad(m, m->a3, m->da, 3, nb, m->P1h, m->P1w, 0, 0, st))) return rc;
+        if ((rc = dgrad(m, m->da, m->db, m->a3, 3, nb, m->P1h, m->P1w, st))) return rc;
+        if ((rc = wgrad(m, m->p1, m->db, 2, nb, m->P1h, m->P1w, 0, 0, st))) return rc;
+        if ((rc = dgrad(m, m->db, m->da, nullptr, 2, nb, m->P1h, m->P1w, st))) return rc;
         hipLaunchKernelGGL(pool_bwd_kernel, g1((long long)nb * m->H1 * m->W1 * 32), dim3(256), 0, st, m->da, m->arg1, m1,
                            keep_scale, m->a2, m->db, nb, m->H1, m->W1, 32);
-        wgrad(m, m->a1, m->db, 1, nb, m->H, m->W, 0, st);
-        hipLaunchKernelGGL(conv_bwd_data_kernel, g1((long long)nb * m->H * m->W * 32), dim3(256), 0, st, m->db,
-                           P + m->oW[1], m->a1, m->da, nb, m->H, m->W, 32, 32, 0);
-        wgrad(m, dev_L, m->da, 0, n, m->H, m->W, prescale, st);
-        wgrad(m, dev_R, m->da + (size_t)n * m->H * m->W * 32, 0, n, m->H, m->W, prescale, st);
+        if ((rc = wgrad(m, m->a1, m->db, 1, nb, m->H, m->W, 0, 0, st))) return rc;
+        if ((rc = dgrad(m, m->db, m->da, m->a1, 1, nb, m->H, m->W, st))) return rc;
+        if ((rc = wgrad(m, dev_L, m->da, 0, n, m->H, m->W, prescale, 0, st))) return rc;
+        if ((rc = wgrad(m, dev_R, m->da + (size_t)n * m->H * m->W * 32, 0, n, m->H, m->W, prescale, 1, st))) return rc;
         ALINK_HIP(hipGetLastError());
     }
     // contiguous gradient copy [tower | head] for the data-parallel all-reduce

@@ -134,7 +134,7 @@ class SmallRes(SiameseNetwork, object):
         return [(128, 'relu'), (32, 'relu'), (2, None)]
 
     def preprocess(self, X):
-        X_temp = [(np.asarray(x, dtype=np.float32) - 128.) / 128. for x in X]
+        X_temp = [((x.float() if hasattr(x, "detach") else np.asarray(x, dtype=np.float32)) - 128.) / 128. for x in X]
         return X_temp
 
     def predict(self, X):

@@ -123,6 +123,7 @@ class SmallResNet(KerasFitMixin):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
     def predict(self, X, batch_size=1024, verbose=0):
+        as_torch = isinstance(X[0], self.torch.Tensor)
         L, R = self._dev(X[0]), self._dev(X[1])
         n = L.shape[0]
         out = self.torch.empty((n, 2), dtype=self.torch.float32, device=self.device)
@@ -131,7 +132,7 @@ class SmallResNet(KerasFitMixin):
             _abi.check(self.lib.alink_smallres_forward(self.h, _abi.ptr(L[s:s + m]), _abi.ptr(R[s:s + m]), m,
                                                        self.prescale, _abi.ptr(out[s:s + m]), _abi.current_stream()),
                        "alink_smallres_forward")
-        return out.cpu().numpy()
+        return out if as_torch else out.cpu().numpy()
 
     def draw_masks(self, n):
         """keep-masks (u8) for the 2n tower passes: Dropout(0.25) after each pool (code/siamese.py:146,153)."""
