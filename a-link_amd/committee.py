@@ -51,9 +51,11 @@ class Bagging:
         return out if hasattr(out, "detach") else np.array(out)      # CUDA tensors stay on the device
 
     def attackModel(self, image_pairs, target_size, target_labels=None):
-        perturbed_l, perturbed_r = [], []
+        """code/committee.py:28-37: every noise perturbs the pair batch, both sides are resized to
+        target_size; returns [[left per noise], [right per noise]]."""
+        sides = ([], [])
         for attack in self.attacks:
-            preturbed = attack.addPairNoise(image_pairs, target_labels)
-            perturbed_l.append(self.resize(preturbed[0], target_size))
-            perturbed_r.append(self.resize(preturbed[1], target_size))
-        return [perturbed_l, perturbed_r]
+            noisy = attack.addPairNoise(image_pairs, target_labels)
+            for side, images in zip(sides, noisy):
+                side.append(self.resize(images, target_size))
+        return [sides[0], sides[1]]
