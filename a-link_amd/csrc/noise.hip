@@ -247,10 +247,9 @@ __device__ double poisson_sample(double lam, unsigned long long seed, unsigned l
             ++k;
         }
     }
-    const double slam = sqrt(lam), loglam = log(lam);
+    const double slam = sqrt(lam);
     const double b = 0.931 + 2.53 * slam;
     const double a = -0.059 + 0.02483 * b;
-    const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
     const double vr = 0.9277 - 3.6224 / (b - 2.0);
     for (;;) {
         const U4 r = draw(seed, elem, sub++, ST_POISSON);
@@ -260,7 +259,9 @@ __device__ double poisson_sample(double lam, unsigned long long seed, unsigned l
         const double k = floor((2.0 * a / us + b) * U + lam + 0.43);
         if (us >= 0.07 && V <= vr) return k;
         if (k < 0.0 || (us < 0.013 && V > us)) continue;
-        if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + k * loglam - loggam(k + 1.0)) return k;
+        // the squeeze above accepts ~9 draws in 10; the logarithms are only needed here
+        const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+        if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + k * log(lam) - loggam(k + 1.0)) return k;
     }
 }
 
