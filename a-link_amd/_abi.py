@@ -54,6 +54,15 @@ PROTOTYPES = {
     "alink_resnet50_embed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "alink_resnet50_profile": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp, _vp, _vp, C.POINTER(_i)]),
     "alink_resnet50_op_name": (C.c_char_p, [_vp, _i]),
+    "alink_vgg16_create": (_vp, [_i, _i, _i]),
+    "alink_vgg16_destroy": (None, [_vp]),
+    "alink_vgg16_num_tensors": (_i, [_vp]),
+    "alink_vgg16_tensor_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_sz)]),
+    "alink_vgg16_feature_size": (_i, [_vp]),
+    "alink_vgg16_load": (_i, [_vp, C.c_char_p, _vp, _sz]),
+    "alink_vgg16_finalize": (_i, [_vp]),
+    "alink_vgg16_workspace_bytes": (_sz, [_vp, _i]),
+    "alink_vgg16_embed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "alink_head_create": (_vp, [_i, _i, _i, _f, _f, _f]),
     "alink_head_create_ex": (_vp, [_i, _i, _i, _i, _f, _f, _f]),
     "alink_head_destroy": (None, [_vp]),

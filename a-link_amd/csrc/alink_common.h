@@ -65,6 +65,10 @@ struct StemParams {
     const float* alpha;   // [C0]
     void*        out;     // [N][H][W][C0] T
     int N, H, W, C0, layout;
+    // input normalisation in the loader: v = (pixel[c] - sub[c']) * mul, stored as network channel c'
+    // (c' = 2 - c when flip: RGB pixels into a BGR-trained network).  IR-ResNet: sub = 127.5, mul = 1/128.
+    float sub[3], mul;
+    int flip;
 };
 hipError_t launch_stem(int dtype, const StemParams& p, hipStream_t stream);
 

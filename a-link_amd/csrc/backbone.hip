@@ -551,6 +551,7 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
     StemParams sp{};
     sp.in = dev_in; sp.wgt = bb->d_stem_w; sp.bias = bb->d_stem_bias; sp.alpha = bb->d_stem_alpha;
     sp.out = buf(0); sp.N = N; sp.H = cfg.height; sp.W = cfg.width; sp.C0 = 64; sp.layout = layout;
+    sp.sub[0] = sp.sub[1] = sp.sub[2] = 127.5f; sp.mul = 0.0078125f; sp.flip = 0;
     for (int r = 0; r < reps; ++r) ALINK_HIP(launch_stem(cfg.dtype, sp, stream));
     note(2.0 * N * cfg.height * cfg.width * 64.0 * 27.0, 0);
     if ((rc = mark())) return rc;

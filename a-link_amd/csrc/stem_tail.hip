@@ -61,9 +61,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
                 px = ((const float*)p.in)[(((size_t)n * 3 + c) * H + iy) * W + ix];
             else
                 px = (float)((const uint8_t*)p.in)[(((size_t)n * H + iy) * W + ix) * 3 + c];
-            v = (px - 127.5f) * 0.0078125f;
+            v = (px - p.sub[p.flip ? 2 - c : c]) * p.mul;
         }
-        tile[r * RP + ixp * 3 + c] = (T)v;
+        tile[r * RP + ixp * 3 + (p.flip ? 2 - c : c)] = (T)v;
     }
 
     // ---- per-lane constants ----------------------------------------------------------------------

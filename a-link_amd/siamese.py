@@ -3,6 +3,7 @@
     SiameseNetwork(shape, modelName, learningRate=1.0)      code/siamese.py:19-131
     ArcFace(shape, model_path)                              code/siamese.py:219-234
     RESNET50(shape)                                         code/siamese.py:203-216  (see resnet50.py)
+    FaceVGG16(shape)                                        code/siamese.py:187-200  (see vgg16.py)
     SmallRes(imageShape, featureShape, name, learningRate)  code/siamese.py:134-184  (see smallres.py)
 
 Same constructor signatures, attributes (`siamese_net`, `modelName`, `shape`, `learningRate`) and
@@ -139,6 +140,29 @@ class SmallRes(SiameseNetwork, object):
 
     def predict(self, X):
         return self.siamese_net.predict(self.preprocess(X), batch_size=1024)
+
+
+class FaceVGG16:
+    """code/siamese.py:187-200: VGGFace VGG-16 pool5 features (25088-d at 224 x 224).  `weights`: path of
+    keras-vggface's `rcmalli_vggface_tf_notop_vgg16.h5`, a dict, or None for synthetic weights."""
+
+    def __init__(self, shape, weights=None, dtype="bf16", max_batch=64, seed=1):
+        from .vgg16 import VGGFace16
+        self.shape = shape + (3,)
+        self.model = VGGFace16(image_size=tuple(shape), weights=weights, dtype=dtype, max_batch=max_batch, seed=seed)
+
+    def preprocess(self, X):
+        """utils.preprocess_input(np.copy(X), version=1): RGB -> BGR, subtract the VGGFace channel means."""
+        from .vgg16 import MEAN_BGR
+        X_temp = np.ascontiguousarray(np.array(X, dtype=np.float32, copy=True)[..., ::-1])
+        for c in range(3):
+            X_temp[..., c] -= MEAN_BGR[c]
+        return X_temp
+
+    def process(self, X):
+        if isinstance(X, (list, tuple)):
+            X = np.stack(X)
+        return self.model.predict(X, batch_size=128, preprocessed=False)
 
 
 class RESNET50:

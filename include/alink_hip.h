@@ -135,6 +135,25 @@ int alink_resnet50_profile(alink_resnet50_t* r, const float* dev_in, int n_image
 const char* alink_resnet50_op_name(const alink_resnet50_t* r, int i);
 
 /* ------------------------------------------------------------------------------------------------
+ * VGGFace VGG-16 feature extractor: siamese.FaceVGG16 (code/siamese.py:187-200) = keras_vggface
+ * VGGFace(model='vgg16', include_top=False) cut at 'pool5', flattened ((H/32)(W/32)512 = 25088 at
+ * 224 x 224), fed through utils.preprocess_input(version=1).  Tensors: "conv{b}_{l}/kernel"
+ * (3, 3, in, out) and "conv{b}_{l}/bias".  dev_in (n, H, W, 3) float32, raw RGB (preprocessed = 0)
+ * or already preprocessed (1); dev_out (n, feature_size) float32 in Keras' Flatten order (h, w, c).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct alink_vgg16 alink_vgg16_t;
+alink_vgg16_t* alink_vgg16_create(int height, int width, int dtype);
+void alink_vgg16_destroy(alink_vgg16_t* r);
+int alink_vgg16_num_tensors(const alink_vgg16_t* r);
+int alink_vgg16_tensor_info(const alink_vgg16_t* r, int i, const char** name, size_t* count);
+int alink_vgg16_feature_size(const alink_vgg16_t* r);
+int alink_vgg16_load(alink_vgg16_t* r, const char* name, const float* host, size_t count);
+int alink_vgg16_finalize(alink_vgg16_t* r);
+size_t alink_vgg16_workspace_bytes(const alink_vgg16_t* r, int n_images);
+int alink_vgg16_embed(alink_vgg16_t* r, const float* dev_in, int n_images, int preprocessed,
+                      float* dev_out, void* dev_workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Siamese pair head: |l - r| -> Dense(h1) ReLU -> Dense(h2) ReLU -> Dense(2) -> softmax.
  * Replaces SiameseNetwork.__init__/predict/finetune/customTrainModel's Keras calls
  * (code/siamese.py:19-35, 52-58, 81-112, 130-131) and committee.Bagging.predict
