@@ -31,7 +31,7 @@ def lib():
     for name, res, args in [
             ("H5Fcreate", hid_t, [C.c_char_p, C.c_uint, hid_t, hid_t]), ("H5Fopen", hid_t, [C.c_char_p, C.c_uint, hid_t]),
             ("H5Fclose", C.c_int, [hid_t]), ("H5Gcreate2", hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t]),
-            ("H5Gclose", C.c_int, [hid_t]), ("H5Screate_simple", hid_t, [C.c_int, C.c_void_p, C.c_void_p]),
+            ("H5Gclose", C.c_int, [hid_t]), ("H5Gopen2", hid_t, [hid_t, C.c_char_p, hid_t]), ("H5Screate_simple", hid_t, [C.c_int, C.c_void_p, C.c_void_p]),
             ("H5Screate", hid_t, [C.c_int]), ("H5Sclose", C.c_int, [hid_t]),
             ("H5Dcreate2", hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t, hid_t, hid_t]),
             ("H5Dwrite", C.c_int, [hid_t, hid_t, hid_t, hid_t, hid_t, C.c_void_p]),
@@ -86,16 +86,45 @@ def _write_attr(obj, name, value):
     L.H5Aclose(at); L.H5Sclose(s); L.H5Tclose(t)
 
 
-def write_keras_like(path, layers, backend=b"tensorflow", keras_version=b"2.1.2"):
+def _write_vlen_str_attr(obj, name, text):
+    """scalar variable-length UTF-8 string attribute — what h5py >= 3 writes for a Python str"""
+    L = lib()
+    t = L.H5Tcopy(_g("H5T_C_S1_g"))
+    L.H5Tset_size(t, C.c_size_t(-1).value)        # H5T_VARIABLE
+    L.H5Tset_cset.restype, L.H5Tset_cset.argtypes = C.c_int, [hid_t, C.c_int]
+    L.H5Tset_cset(t, 1)                           # H5T_CSET_UTF8
+    s = L.H5Screate(0)
+    at = L.H5Acreate2(obj, name.encode(), t, s, 0, 0)
+    assert at >= 0
+    buf = (C.c_char_p * 1)(text.encode("utf8"))
+    assert L.H5Awrite(at, t, buf) >= 0
+    L.H5Aclose(at); L.H5Sclose(s); L.H5Tclose(t)
+
+
+def write_keras_like(path, layers, backend=b"tensorflow", keras_version=b"2.1.2", vlen_scalars=False):
     """What keras.engine.topology.save_weights_to_hdf5_group does through h5py, done through libhdf5."""
     L = lib()
     f = L.H5Fcreate(path.encode(), 2, 0, 0)
     assert f >= 0
     _write_attr(f, "layer_names", np.array([n.encode() for n, _ in layers]))
-    _write_attr(f, "backend", np.bytes_(backend))
-    _write_attr(f, "keras_version", np.bytes_(keras_version))
+    if vlen_scalars:
+        _write_vlen_str_attr(f, "backend", backend.decode())
+        _write_vlen_str_attr(f, "keras_version", keras_version.decode())
+    else:
+        _write_attr(f, "backend", np.bytes_(backend))
+        _write_attr(f, "keras_version", np.bytes_(keras_version))
+    made_root = set()
     for lname, weights in layers:
-        g = L.H5Gcreate2(f, lname.encode(), 0, 0, 0)
+        parts = lname.split("/")
+        for i in range(1, len(parts)):                # h5py creates the intermediate groups of "a/b/c"
+            sub = "/".join(parts[:i])
+            if sub not in made_root and not any(sub == n for n, _ in layers if n in made_root):
+                sg = L.H5Gcreate2(f, sub.encode(), 0, 0, 0)
+                if sg >= 0:
+                    L.H5Gclose(sg)
+                made_root.add(sub)
+        g = L.H5Gcreate2(f, lname.encode(), 0, 0, 0) if lname not in made_root else L.H5Gopen2(f, lname.encode(), 0)
+        made_root.add(lname)
         assert g >= 0
         _write_attr(g, "weight_names", np.array([w.encode() for w, _ in weights]) if weights else np.zeros((0,), np.float64))
         made = set()

@@ -70,6 +70,37 @@ def test_h5_reader_on_files_written_by_libhdf5(tmp_path):
 
 
 @pytest.mark.skipif(h5ref.lib() is None, reason="no libhdf5 in this image")
+def test_h5_reader_multi_level_group_btree(tmp_path):
+    """300 layer groups in the root: libhdf5 splits the symbol table over many leaf nodes and a
+    two-level B-tree (a keras-vggface ResNet-50 weight file has ~110 root groups)."""
+    rng = np.random.RandomState(0)
+    layers = [("layer_%03d" % i, [("layer_%03d/gamma:0" % i, rng.randn(5).astype(np.float32))]) for i in range(300)]
+    p = str(tmp_path / "big.h5")
+    h5ref.write_keras_like(p, layers)
+    _same(H5.load_keras_weights(p), layers)
+    assert len(H5.File(p).keys()) == 300
+    # nested layer names as keras-vggface has them ("conv1/7x7_s2" and "conv1/7x7_s2/bn" share a prefix)
+    nested = [("conv1/7x7_s2", [("conv1/7x7_s2/kernel:0", rng.randn(7, 7, 3, 4).astype(np.float32))]),
+              ("conv1/7x7_s2/bn", [("conv1/7x7_s2/bn/gamma:0", rng.randn(4).astype(np.float32)),
+                                   ("conv1/7x7_s2/bn/beta:0", rng.randn(4).astype(np.float32))])]
+    q = str(tmp_path / "nested.h5")
+    h5ref.write_keras_like(q, nested)
+    _same(H5.load_keras_weights(q), nested)
+
+
+@pytest.mark.skipif(h5ref.lib() is None, reason="no libhdf5 in this image")
+def test_h5_reader_variable_length_string_attributes(tmp_path):
+    """h5py >= 3 stores Python-str attributes (backend, keras_version) as variable-length UTF-8 strings
+    in the global heap; layer/weight name arrays stay fixed-length."""
+    layers = _head_layers(6)
+    p = str(tmp_path / "vlen.h5")
+    h5ref.write_keras_like(p, layers, keras_version=b"2.4.3", vlen_scalars=True)
+    f = H5.File(p)
+    assert f.attrs["backend"] == b"tensorflow" and f.attrs["keras_version"] == b"2.4.3"
+    _same(H5.load_keras_weights(p), layers)
+
+
+@pytest.mark.skipif(h5ref.lib() is None, reason="no libhdf5 in this image")
 def test_h5_writer_output_is_readable_by_libhdf5(tmp_path):
     layers = _head_layers(4)
     p = str(tmp_path / "ours.h5")
