@@ -42,6 +42,10 @@ PROTOTYPES = {
     "alink_backbone_set_streams": (_i, [_vp, _i]),
     "alink_backbone_workspace_bytes": (_sz, [_vp, _i]),
     "alink_embed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "alink_backbone_enable_grad": (_i, [_vp]),
+    "alink_backbone_grad_workspace_bytes": (_sz, [_vp, _i]),
+    "alink_embed_cached": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "alink_embed_input_grad": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "alink_embed_profile": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "alink_conv_nhwc": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "alink_resnet50_create": (_vp, [_i, _i, _i, _f]),

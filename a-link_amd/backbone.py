@@ -14,7 +14,7 @@ from . import weights as W
 
 class IRBackbone(object):
     def __init__(self, params, image_size=(112, 112), emb=512, dtype="bf16", device=0, max_batch=256,
-                 widths=W.WIDTHS, streams=4, shards_per_call=1, bn_eps=2e-5):
+                 widths=W.WIDTHS, streams=4, shards_per_call=1, bn_eps=2e-5, enable_grad=False):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
@@ -36,6 +36,9 @@ class IRBackbone(object):
         self.h = self.lib.alink_backbone_create(C.byref(cfg))
         if not self.h:
             raise _abi.AlinkError("alink_backbone_create: " + self.lib.alink_last_error().decode())
+        self.grad_enabled = bool(enable_grad)
+        if enable_grad:
+            _abi.check(self.lib.alink_backbone_enable_grad(self.h), "alink_backbone_enable_grad")
         n = self.lib.alink_backbone_num_tensors(self.h)
         name, cnt = C.c_char_p(), C.c_size_t()
         for i in range(n):
@@ -124,6 +127,50 @@ class IRBackbone(object):
             done.record(s)
             cur.wait_event(done)                # results are valid in caller-stream order
         return out
+
+    # -- input gradient (FGSM / PGD extension) --------------------------------------------------------
+    def _grad_workspace(self, n):
+        cur = self._ws.get("grad")
+        if cur is None or n > cur[1]:
+            nbytes = self.lib.alink_backbone_grad_workspace_bytes(self.h, n)
+            cur = (self.torch.empty(nbytes + 256, dtype=self.torch.uint8, device="cuda:%d" % self.device), n)
+            self._ws["grad"] = cur
+        t = cur[0]
+        off = (-t.data_ptr()) % 256
+        return t.data_ptr() + off, t.numel() - off
+
+    def embed_with_cache(self, x):
+        """Forward on <= max_batch images keeping what input_gradient needs.  x: CUDA float32 NHWC/NCHW."""
+        if not self.grad_enabled:
+            raise _abi.AlinkError("IRBackbone was built without enable_grad=True")
+        torch = self.torch
+        layout = self._layout_of(x, self.image_size)
+        if layout == _abi.LAYOUT_NHWC_U8:
+            raise ValueError("gradients need float32 pixels")
+        x = x.contiguous()
+        n = x.shape[0]
+        assert 0 < n <= self.max_batch
+        out = torch.empty((n, self.emb), dtype=torch.float32, device=x.device)
+        ws, wsb = self._grad_workspace(n)
+        _abi.check(self.lib.alink_embed_cached(self.h, _abi.ptr(x), layout, n, _abi.ptr(out), C.c_void_p(ws), wsb,
+                                               _abi.current_stream()), "alink_embed_cached")
+        self._cached = (n, layout, out)
+        return out
+
+    def input_gradient(self, demb):
+        """d(loss)/d(pixels) for the batch of the last embed_with_cache, given demb = d(loss)/d(embedding)
+        (n, emb) float32 CUDA.  Same layout as the forward input."""
+        torch = self.torch
+        n, layout, emb = self._cached
+        demb = demb.to(torch.float32).contiguous()
+        assert tuple(demb.shape) == (n, self.emb)
+        h, w = self.image_size
+        shape = (n, h, w, 3) if layout == _abi.LAYOUT_NHWC_F32 else (n, 3, h, w)
+        dpix = torch.empty(shape, dtype=torch.float32, device=demb.device)
+        ws, wsb = self._grad_workspace(n)
+        _abi.check(self.lib.alink_embed_input_grad(self.h, _abi.ptr(demb), _abi.ptr(emb), layout, n, _abi.ptr(dpix),
+                                                   C.c_void_p(ws), wsb, _abi.current_stream()), "alink_embed_input_grad")
+        return dpix
 
     def embed(self, x):
         """numpy in -> numpy out (the reference's calling convention: host arrays, code/siamese.py:234);

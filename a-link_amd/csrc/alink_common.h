@@ -43,6 +43,8 @@ struct ConvParams {
     const float* bias;    // [ncls][Cout] f32, natural channel order; ncls = border_cls ? 9 : 1
     const float* alpha;   // [Cout] PReLU slopes, or nullptr
     const void*  resid;   // [M][Cout] T, or nullptr
+    const void*  dact;    // [M][Cout] T, or nullptr: backward mode — instead of the forward PReLU the result is
+                          // multiplied by PReLU'(z) read off the stored forward activation: 1 if dact > 0 else alpha[c]
     void*        out;     // [M][Cout] T;  split-K: f32 slabs [splitk][M][Cout]
     const void*  zero;    // >= 256 B of zeros (source for padded taps / tail rows)
     int N, H, W, Cin, Cout, Ho, Wo, stride, ksz, pad, M;
@@ -76,6 +78,7 @@ struct FcFinishParams {
     const float* slabs;   // [S][M][E]
     const float* bias;    // [E]
     float*       out;     // [M][E], L2-normalised rows
+    float*       norms;   // [M] row norms before normalisation (as divided by: 1 for a zero row), or nullptr
     int S, M, E;
 };
 hipError_t launch_fc_finish(const FcFinishParams& p, hipStream_t stream);
@@ -108,6 +111,14 @@ int        direct_variant(int ksz, int stride, int pad, int H, int W, int Cin, i
 int        direct_variant_cpl(int v);
 hipError_t direct_set_attributes();
 hipError_t launch_conv3x3_direct(int variant, int dtype, const ConvParams& p, hipStream_t st);
+
+// backward.hip (input-gradient pass)
+hipError_t launch_l2norm_bwd(int dtype, const float* g, const float* e, const float* norms, void* dz, int M, int E,
+                             hipStream_t st);
+hipError_t launch_zero_insert(int dtype, const void* in, void* out, int N, int H, int W, int Ho, int Wo, int C,
+                              hipStream_t st);
+hipError_t launch_stem_bwd(int dtype, const void* dy0, const void* y0, const float* w, const float* alpha, float* dpix,
+                           int N, int H, int W, float mul, int nchw, hipStream_t st);
 
 // host-side conversions
 uint16_t f32_to_bf16_rne(float f);

@@ -83,6 +83,11 @@ struct ConvLayer {
     float* d_bias = nullptr;                // [ncls][Cout]
     float* d_alpha = nullptr;               // [Cout]
     std::string name;
+    // input-gradient pass (alink_backbone_enable_grad): transposed + flipped folded weights for the
+    // convolution that maps d(output) to d(input), and where this layer sits in its residual unit
+    void* d_wb = nullptr;                   // T [Cin][k*k*Cout], rows permuted for `bvariant`
+    int   bvariant = 0;                     // direct variant of the backward convolution (0 = conv_igemm)
+    int   role = 0, unit = -1;              // 1 conv1, 2 shortcut, 3 conv2; index of the residual unit
 };
 
 }  // namespace alink
@@ -105,6 +110,12 @@ struct alink_backbone {
     void*  d_zero = nullptr;
     int fc_K = 0, fc_splitk = 1, fc_kps = 0;
     int Hf = 0, Wf = 0;                                        // final feature map size
+    // input-gradient support
+    bool grad = false;
+    void*  d_fc_wb = nullptr;                                  // T [C*Hf*Wf][emb]: FC transposed (rows permuted)
+    float* d_stem_wf = nullptr;                                // f32 [64][27] folded stem weights
+    float* d_zero_bias = nullptr;                              // zeros, >= 9 * max width floats
+    int n_units = 0;
     std::vector<void*> allocs;
     // Optional sub-batch streams (alink_backbone_set_streams): one call is split into image shards on
     // internal streams.  Measured: pays only when shards from SEVERAL calls overlap without a join
@@ -211,6 +222,29 @@ int build_conv(alink_backbone* bb, ConvLayer& L, const std::vector<float>& w, co
     if (prelu) {
         if ((rc = upload(bb, *prelu, (void**)&L.d_alpha))) return rc;
     }
+    if (bb->grad) {
+        // d(input) = conv(d(output), Wb): Wb[ci][tap'][co] = Wfolded[co][k*k-1-tap'][ci].  The backward
+        // convolution always runs at stride 1 over the layer's INPUT grid (stride-2 layers see a
+        // zero-inserted d(output)), with the layer's own padding.
+        const int Hb = (L.ksz == 3) ? L.Hin : L.Hout, Wb = (L.ksz == 3) ? L.Win : L.Wout;
+        L.bvariant = direct_variant(L.ksz, 1, L.pad, Hb, Wb, O, I);
+        const int bcpl = L.bvariant ? direct_variant_cpl(L.bvariant) : 16;
+        const int KB = k * k * O;
+        std::vector<uint16_t> wb((size_t)I * KB);
+        for (int ci = 0; ci < I; ++ci) {
+            const size_t row = (size_t)permuted_row(ci, bcpl) * KB;
+            for (int tap = 0; tap < k * k; ++tap) {
+                const int ft = k * k - 1 - tap, ky = ft / k, kx = ft % k;
+                for (int co = 0; co < O; ++co) {
+                    const double wv = (double)w[(((size_t)co * I + ci) * k + ky) * k + kx];
+                    const double ai = pre ? pre->a[ci] : 1.0;
+                    const size_t kidx = L.bvariant ? ((size_t)(co >> 6) * 9 + tap) * 64 + (co & 63) : (size_t)tap * O + co;
+                    wb[row + kidx] = cvt(dt, (float)(post.a[co] * wv * ai));
+                }
+            }
+        }
+        if ((rc = upload(bb, wb, &L.d_wb))) return rc;
+    }
     return ALINK_OK;
 }
 
@@ -313,6 +347,12 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
     ALINK_REQUIRE(!bb->finalized, ALINK_ESTATE, "backbone already finalized");
     for (const auto& e : bb->expected)
         ALINK_REQUIRE(bb->raw.count(e.first), ALINK_ESTATE, "tensor %s was never loaded", e.first.c_str());
+    if (bb->grad)   // the backward pass tells the PReLU side from the sign of the stored activation
+        for (const auto& e : bb->expected)
+            if (e.first.find("relu") != std::string::npos)
+                for (float a : bb->raw.at(e.first))
+                    ALINK_REQUIRE(a >= 0.f, ALINK_EINVAL, "%s has a negative PReLU slope: input gradients are not "
+                                  "supported for this checkpoint", e.first.c_str());
     int rc = init_kernels();
     if (rc) return rc;
     const alink_ir_cfg& cfg = bb->cfg;
@@ -343,6 +383,18 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
         if ((rc = upload(bb, wq, &bb->d_stem_w))) return rc;
         if ((rc = upload(bb, bias, (void**)&bb->d_stem_bias))) return rc;
         if ((rc = upload(bb, bb->raw.at("relu0_gamma"), (void**)&bb->d_stem_alpha))) return rc;
+        if (bb->grad) {
+            std::vector<float> wf((size_t)64 * 27);
+            for (int co = 0; co < 64; ++co)
+                for (int c = 0; c < 3; ++c)
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int kx = 0; kx < 3; ++kx)
+                            wf[(size_t)co * 27 + ky * 9 + kx * 3 + c] =
+                                (float)(bn0.a[co] * (double)cw[(((size_t)co * 3 + c) * 3 + ky) * 3 + kx]);
+            if ((rc = upload(bb, wf, (void**)&bb->d_stem_wf))) return rc;
+            std::vector<float> zb(std::max((size_t)9 * 2048, (size_t)cfg.widths[4] * (cfg.height / 16) * (cfg.width / 16)), 0.f);
+            if ((rc = upload(bb, zb, (void**)&bb->d_zero_bias))) return rc;
+        }
     }
 
     // ---- residual stages.  Workspace buffers: 0,1 = "big" (stem resolution), 2,3,4 = "small".
@@ -373,7 +425,7 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
             c1.Cin = cin; c1.Cout = c; c1.ksz = 3; c1.stride = 1; c1.pad = 1;
             c1.Hin = H; c1.Win = W; c1.Hout = H; c1.Wout = W;
             c1.border_cls = true; c1.has_alpha = true;
-            c1.in_buf = xb; c1.out_buf = tb; c1.resid_buf = -1;
+            c1.in_buf = xb; c1.out_buf = tb; c1.resid_buf = -1; c1.role = 1; c1.unit = bb->n_units;
             if ((rc = build_conv(bb, c1, bb->raw.at(P + "_conv1_weight"), &bn1, bn2, &bb->raw.at(P + "_relu1_gamma"))))
                 return rc;
             bb->convs.push_back(c1);
@@ -386,7 +438,7 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
                 sc.Cin = cin; sc.Cout = c; sc.ksz = 1; sc.stride = stride; sc.pad = 0;
                 sc.Hin = H; sc.Win = W; sc.Hout = Ho; sc.Wout = Wo;
                 sc.border_cls = false; sc.has_alpha = false;
-                sc.in_buf = xb; sc.out_buf = sb; sc.resid_buf = -1;
+                sc.in_buf = xb; sc.out_buf = sb; sc.resid_buf = -1; sc.role = 2; sc.unit = bb->n_units;
                 if ((rc = build_conv(bb, sc, bb->raw.at(P + "_conv1sc_weight"), nullptr, bsc, nullptr))) return rc;
                 bb->convs.push_back(sc);
                 resid = sb;
@@ -396,9 +448,10 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
             c2.Cin = c; c2.Cout = c; c2.ksz = 3; c2.stride = stride; c2.pad = 1;
             c2.Hin = H; c2.Win = W; c2.Hout = Ho; c2.Wout = Wo;
             c2.border_cls = false; c2.has_alpha = false;
-            c2.in_buf = tb; c2.out_buf = yb; c2.resid_buf = resid;
+            c2.in_buf = tb; c2.out_buf = yb; c2.resid_buf = resid; c2.role = 3; c2.unit = bb->n_units;
             if ((rc = build_conv(bb, c2, bb->raw.at(P + "_conv2_weight"), nullptr, bn3, nullptr))) return rc;
             bb->convs.push_back(c2);
+            ++bb->n_units;
             xb = yb;
             H = Ho;
             W = Wo;
@@ -426,6 +479,19 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
         }
         if ((rc = upload(bb, wq, &bb->d_fc_w))) return rc;
         if ((rc = upload(bb, bias, (void**)&bb->d_fc_bias))) return rc;
+        if (bb->grad) {
+            // d(x4)[pos][ch] = sum_o d(z)[o] * Wfolded[o][pos][ch]: a 1x1 "convolution" emb -> C*H*W
+            std::vector<uint16_t> wb((size_t)K * E);
+            for (int kk = 0; kk < K; ++kk) {
+                const int pos = kk / C, ch = kk - pos * C;
+                const size_t row = (size_t)((kk & ~63) + perm64_row_of_channel(kk & 63)) * E;
+                for (int o = 0; o < E; ++o) {
+                    const double wv = (double)fw[(size_t)o * K + (size_t)ch * HW + pos];
+                    wb[row + o] = cvt(dt, (float)(bfc.a[o] * wv * bnl.a[ch]));
+                }
+            }
+            if ((rc = upload(bb, wb, &bb->d_fc_wb))) return rc;
+        }
         bb->fc_K = K;
         const int nk = K / 64;
         int S = nk / 14;                         // ~14 K-steps per split
@@ -475,6 +541,25 @@ static void ws_layout(const alink_backbone* bb, int N, size_t off[6], size_t* to
     *total = o;
 }
 
+// gradient-mode workspace, after the forward layout: [t cache per unit][norms][d(fc out)][5 gradient buffers]
+struct GradLayout {
+    std::vector<size_t> toff;
+    size_t norms, dfc, g[5], total;
+};
+static void grad_layout(const alink_backbone* bb, int N, GradLayout* L) {
+    size_t off[6], o;
+    ws_layout(bb, N, off, &o);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    L->toff.assign(bb->n_units, 0);
+    for (const ConvLayer& c : bb->convs)
+        if (c.role == 1) { L->toff[c.unit] = o; o += al((size_t)N * c.Hout * c.Wout * c.Cout * 2); }
+    L->norms = o; o += al((size_t)N * 4);
+    L->dfc = o; o += al((size_t)N * bb->cfg.emb * 2);
+    const size_t big = al((size_t)N * bb->cfg.height * bb->cfg.width * bb->cfg.widths[0] * 2);
+    for (int i = 0; i < 5; ++i) { L->g[i] = o; o += big; }
+    L->total = o;
+}
+
 // shard sizes of an N-image forward: at least 64 images per shard, at most bb->nsub shards
 static int split_plan(const alink_backbone* bb, int N, int counts[alink_backbone::MAXSUB]) {
     int S = bb->nsub;
@@ -513,7 +598,7 @@ extern "C" void alink_debug_set_stamps(void* p) { g_stamps = p; }
 
 static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int N, float* dev_out,
                       void* ws, size_t ws_bytes, hipStream_t stream, float* ms, double* flops, int* kind,
-                      int* n_launches) {
+                      int* n_launches, const GradLayout* cache = nullptr) {
     ALINK_REQUIRE(bb && dev_in && dev_out && ws, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(bb->finalized, ALINK_ESTATE, "alink_embed before alink_backbone_finalize");
     ALINK_REQUIRE(N > 0, ALINK_EINVAL, "n_images must be positive");
@@ -523,6 +608,7 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
                   "batch of %d images exceeds the 2^31-element activation limit; split the batch", N);
     size_t off[6], total;
     ws_layout(bb, N, off, &total);
+    if (cache) total = cache->total;
     ALINK_REQUIRE(ws_bytes >= total, ALINK_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, total);
     ALINK_REQUIRE(((uintptr_t)ws & 255) == 0, ALINK_EINVAL, "workspace must be 256-byte aligned");
     char* base = (char*)ws;
@@ -562,6 +648,10 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         p.in = buf(L.in_buf); p.wgt = L.d_w; p.bias = L.d_bias; p.alpha = L.d_alpha;
         p.resid = L.resid_buf >= 0 ? buf(L.resid_buf) : nullptr;
         p.out = buf(L.out_buf); p.zero = bb->d_zero;
+        if (cache) {   // keep every unit's conv1 activation for the PReLU derivative of the backward pass
+            if (L.role == 1) p.out = base + cache->toff[L.unit];
+            if (L.role == 3) p.in = base + cache->toff[L.unit];
+        }
         p.N = N; p.H = L.Hin; p.W = L.Win; p.Cin = L.Cin; p.Cout = L.Cout; p.Ho = L.Hout; p.Wo = L.Wout;
         p.stride = L.stride; p.ksz = L.ksz; p.pad = L.pad; p.M = N * L.Hout * L.Wout;
         p.border_cls = L.border_cls ? 1 : 0; p.splitk = 1;
@@ -590,6 +680,7 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         if ((rc = mark())) return rc;
         FcFinishParams f{};
         f.slabs = (const float*)buf(5); f.bias = bb->d_fc_bias; f.out = dev_out;
+        f.norms = cache ? (float*)(base + cache->norms) : nullptr;
         f.S = bb->fc_splitk; f.M = N; f.E = cfg.emb;
         for (int r = 0; r < reps; ++r) ALINK_HIP(launch_fc_finish(f, stream));
         note(0.0, 3);
@@ -650,6 +741,106 @@ int alink_embed_profile(alink_backbone_t* bb, const void* dev_in, int layout, in
     ALINK_REQUIRE(ms && flops && kind && n_launches && *n_launches > 0, ALINK_EINVAL, "NULL profile buffers");
     return embed_impl(bb, dev_in, layout, n_images, dev_out, dev_workspace, workspace_bytes,
                       (hipStream_t)stream, ms, flops, kind, n_launches);
+}
+
+// ---- input gradient (FGSM / PGD extension) ------------------------------------------------------------
+int alink_backbone_enable_grad(alink_backbone_t* bb) {
+    ALINK_REQUIRE(bb, ALINK_EINVAL, "NULL backbone");
+    ALINK_REQUIRE(!bb->finalized, ALINK_ESTATE, "alink_backbone_enable_grad must precede alink_backbone_finalize");
+    bb->grad = true;
+    return ALINK_OK;
+}
+
+size_t alink_backbone_grad_workspace_bytes(const alink_backbone_t* bb, int n_images) {
+    if (!bb || !bb->finalized || !bb->grad || n_images <= 0) return 0;
+    GradLayout L;
+    grad_layout(bb, n_images, &L);
+    return L.total;
+}
+
+int alink_embed_cached(alink_backbone_t* bb, const void* dev_in, int layout, int n_images, float* dev_out,
+                       void* dev_workspace, size_t workspace_bytes, void* stream) {
+    ALINK_REQUIRE(bb && bb->finalized && bb->grad, ALINK_ESTATE, "needs alink_backbone_enable_grad + finalize");
+    GradLayout L;
+    grad_layout(bb, n_images > 0 ? n_images : 1, &L);
+    return embed_impl(bb, dev_in, layout, n_images, dev_out, dev_workspace, workspace_bytes, (hipStream_t)stream,
+                      nullptr, nullptr, nullptr, nullptr, &L);
+}
+
+int alink_embed_input_grad(alink_backbone_t* bb, const float* dev_demb, const float* dev_emb, int layout, int N,
+                           float* dev_dpix, void* ws, size_t ws_bytes, void* stream) {
+    ALINK_REQUIRE(bb && bb->finalized && bb->grad, ALINK_ESTATE, "needs alink_backbone_enable_grad + finalize");
+    ALINK_REQUIRE(dev_demb && dev_emb && dev_dpix && ws && N > 0, ALINK_EINVAL, "bad argument");
+    ALINK_REQUIRE(layout == ALINK_LAYOUT_NHWC_F32 || layout == ALINK_LAYOUT_NCHW_F32, ALINK_EINVAL,
+                  "gradient layout must be float32 NHWC or NCHW");
+    const alink_ir_cfg& cfg = bb->cfg;
+    const int dt = cfg.dtype;
+    hipStream_t st = (hipStream_t)stream;
+    GradLayout GL;
+    grad_layout(bb, N, &GL);
+    ALINK_REQUIRE(ws_bytes >= GL.total, ALINK_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, GL.total);
+    char* base = (char*)ws;
+    auto G = [&](int i) -> void* { return base + GL.g[i]; };
+    // 1) through the L2 normalisation, 2) through the folded FC
+    ALINK_HIP(launch_l2norm_bwd(dt, dev_demb, dev_emb, (const float*)(base + GL.norms), base + GL.dfc, N, cfg.emb, st));
+    int cur = 0;
+    {
+        ConvParams p{};
+        p.in = base + GL.dfc; p.wgt = bb->d_fc_wb; p.bias = bb->d_zero_bias; p.out = G(cur); p.zero = bb->d_zero;
+        p.N = N; p.H = 1; p.W = 1; p.Cin = cfg.emb; p.Cout = bb->fc_K; p.Ho = 1; p.Wo = 1; p.stride = 1; p.ksz = 1;
+        p.pad = 0; p.M = N; p.splitk = 1; p.ksteps_per_split = cfg.emb / 64;
+        ALINK_HIP(launch_conv_igemm(dt, p, st));
+    }
+    // 3) residual units in reverse
+    std::vector<const ConvLayer*> c1(bb->n_units, nullptr), sc(bb->n_units, nullptr), c2(bb->n_units, nullptr);
+    for (const ConvLayer& L : bb->convs) (L.role == 1 ? c1 : (L.role == 2 ? sc : c2))[L.unit] = &L;
+    for (int u = bb->n_units - 1; u >= 0; --u) {
+        const ConvLayer &A = *c1[u], &B = *c2[u];
+        const int H = A.Hin, W = A.Win, c = A.Cout, cin = A.Cin, Ho = B.Hout, Wo = B.Wout;
+        int ids[4], k = 0;
+        for (int i = 0; i < 5; ++i) if (i != cur) ids[k++] = i;
+        const void* dy = G(cur);
+        const void* dy_full = dy;                       // d(output) on the unit's input grid
+        if (B.stride == 2) {
+            ALINK_HIP(launch_zero_insert(dt, dy, G(ids[0]), N, H, W, Ho, Wo, c, st));
+            dy_full = G(ids[0]);
+        }
+        {   // through conv2 (+ bn3) and the PReLU: d(z1) = conv(dy, W2b) * PReLU'(t)
+            ConvParams p{};
+            p.in = dy_full; p.wgt = B.d_wb; p.bias = bb->d_zero_bias; p.alpha = A.d_alpha;
+            p.dact = base + GL.toff[u]; p.out = G(ids[1]); p.zero = bb->d_zero;
+            p.N = N; p.H = H; p.W = W; p.Cin = c; p.Cout = c; p.Ho = H; p.Wo = W; p.stride = 1; p.ksz = 3; p.pad = 1;
+            p.M = N * H * W; p.splitk = 1; p.ksteps_per_split = 9 * (c / 64);
+            if (B.bvariant) ALINK_HIP(launch_conv3x3_direct(B.bvariant, dt, p, st));
+            else            ALINK_HIP(launch_conv_igemm(dt, p, st));
+        }
+        const void* r = dy;                             // gradient arriving through the shortcut
+        if (sc[u]) {
+            const ConvLayer& S = *sc[u];
+            ConvParams p{};
+            p.in = dy; p.wgt = S.d_wb; p.bias = bb->d_zero_bias; p.out = G(ids[0]); p.zero = bb->d_zero;
+            p.N = N; p.H = Ho; p.W = Wo; p.Cin = c; p.Cout = cin; p.Ho = Ho; p.Wo = Wo; p.stride = 1; p.ksz = 1; p.pad = 0;
+            p.M = N * Ho * Wo; p.splitk = 1; p.ksteps_per_split = c / 64;
+            ALINK_HIP(launch_conv_igemm(dt, p, st));
+            ALINK_HIP(launch_zero_insert(dt, G(ids[0]), G(ids[2]), N, H, W, Ho, Wo, cin, st));
+            r = G(ids[2]);
+        }
+        {   // through conv1 (+ bn1, bn2 folded) and add the shortcut gradient
+            ConvParams p{};
+            p.in = G(ids[1]); p.wgt = A.d_wb; p.bias = bb->d_zero_bias; p.resid = r; p.out = G(ids[3]); p.zero = bb->d_zero;
+            p.N = N; p.H = H; p.W = W; p.Cin = c; p.Cout = cin; p.Ho = H; p.Wo = W; p.stride = 1; p.ksz = 3; p.pad = 1;
+            p.M = N * H * W; p.splitk = 1; p.ksteps_per_split = 9 * (c / 64);
+            if (A.bvariant) ALINK_HIP(launch_conv3x3_direct(A.bvariant, dt, p, st));
+            else            ALINK_HIP(launch_conv_igemm(dt, p, st));
+        }
+        cur = ids[3];
+    }
+    // 4) through the stem PReLU, the stem convolution and the input normalisation
+    size_t off[6], fwd_total;
+    ws_layout(bb, N, off, &fwd_total);
+    ALINK_HIP(launch_stem_bwd(dt, G(cur), base + off[0], bb->d_stem_wf, bb->d_stem_alpha, dev_dpix, N, cfg.height,
+                              cfg.width, 0.0078125f, layout == ALINK_LAYOUT_NCHW_F32, st));
+    return ALINK_OK;
 }
 
 // ---- diagnostic single-convolution entry (unit tests) -------------------------------------------

@@ -282,12 +282,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv3x3_direct_kernel(const ConvP
         const int cc = (ox == 0) ? 0 : ((ox == W - 1) ? 2 : 1);
         cls[u] = p.border_cls ? rc * 3 + cc : 0;
     }
-    vec8 res[TPW][CPL / 8];
-    if (p.resid) {
+    vec8 res[TPW][CPL / 8];      // the residual, or (backward mode) the stored forward activation
+    const T* extra = (const T*)(p.dact ? p.dact : p.resid);
+    if (extra) {
 #pragma unroll
         for (int u = 0; u < TPW; ++u)
 #pragma unroll
-            for (int h = 0; h < CPL / 8; ++h) res[u][h] = *(const vec8*)((const T*)p.resid + off[u] + chan_h(h));
+            for (int h = 0; h < CPL / 8; ++h) res[u][h] = *(const vec8*)(extra + off[u] + chan_h(h));
     }
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
@@ -298,19 +299,29 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv3x3_direct_kernel(const ConvP
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[4 * t + j] = acc[t][u][j] + b4[j];
         }
-        if (p.alpha) {
+        if (p.dact) {
+            // v *= PReLU'(z): 1 where the stored activation is positive, the slope elsewhere
 #pragma unroll
             for (int t = 0; t < TCW; ++t) {
                 const f32x4 a4 = *(const f32x4*)(ealpha + chan_t(t));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[4 * t + j] = v[4 * t + j] > 0.f ? v[4 * t + j] : v[4 * t + j] * a4[j];
+                for (int j = 0; j < 4; ++j) v[4 * t + j] *= (float)res[u][(4 * t + j) / 8][(4 * t + j) % 8] > 0.f ? 1.f : a4[j];
             }
-        }
-        if (p.resid) {
+        } else {
+            if (p.alpha) {
 #pragma unroll
-            for (int h = 0; h < CPL / 8; ++h)
+                for (int t = 0; t < TCW; ++t) {
+                    const f32x4 a4 = *(const f32x4*)(ealpha + chan_t(t));
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[8 * h + i] += (float)res[u][h][i];
+                    for (int j = 0; j < 4; ++j) v[4 * t + j] = v[4 * t + j] > 0.f ? v[4 * t + j] : v[4 * t + j] * a4[j];
+                }
+            }
+            if (p.resid) {
+#pragma unroll
+                for (int h = 0; h < CPL / 8; ++h)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[8 * h + i] += (float)res[u][h][i];
+            }
         }
         if (p.post_relu) {
 #pragma unroll

@@ -236,12 +236,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             cls[u] = rc * 3 + cc;
         }
     }
-    vec8 res[4][2];
-    if (p.resid) {
+    vec8 res[4][2];            // the residual, or (backward mode) the stored forward activation
+    const T* extra = (const T*)(p.dact ? p.dact : p.resid);
+    if (extra) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            res[u][0] = *(const vec8*)((const T*)p.resid + off[u]);
-            res[u][1] = *(const vec8*)((const T*)p.resid + off[u] + 8);
+            res[u][0] = *(const vec8*)(extra + off[u]);
+            res[u][1] = *(const vec8*)(extra + off[u] + 8);
         }
     }
     f32x4 bia[4][4];
@@ -265,15 +266,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[4 * t + j] = acc[t][u][j] + bia[u][t][j];
-        if (p.alpha) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * al[i];
-        }
-        if (p.resid) {
+        if (p.dact) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                v[i] += (float)res[u][0][i];
-                v[8 + i] += (float)res[u][1][i];
+                v[i] *= (float)res[u][0][i] > 0.f ? 1.f : al[i];
+                v[8 + i] *= (float)res[u][1][i] > 0.f ? 1.f : al[8 + i];
+            }
+        } else {
+            if (p.alpha) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * al[i];
+            }
+            if (p.resid) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] += (float)res[u][0][i];
+                    v[8 + i] += (float)res[u][1][i];
+                }
             }
         }
         if (p.post_relu) {

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void fc_finish_kernel(const FcFinishParams p) 
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     float nrm = sqrtf(ss);
     if (nrm == 0.f) nrm = 1.f;
+    if (p.norms && lane == 0) p.norms[m] = nrm;
     for (int c0 = lane * 4; c0 < E; c0 += 256) {
         f32x4 a = *(f32x4*)(p.out + (size_t)m * E + c0);
         a[0] /= nrm; a[1] /= nrm; a[2] /= nrm; a[3] /= nrm;

@@ -330,6 +330,19 @@ class DenseHead(KerasFitMixin):
         m = self._metrics.cpu().numpy()
         return [float(m[0]), float(m[1])]
 
+    def input_gradients(self, L, R, y):
+        """EXTENSION (FGSM / PGD): d(loss)/dL, d(loss)/dR of the Keras loss of this batch (mean over the
+        batch), parameters untouched.  L, R: (n, d_in) CUDA float32; y: (n, out_dim) targets."""
+        torch = self.torch
+        L, R, yd = self._dev(L), self._dev(R), self._dev(y)
+        n = L.shape[0]
+        dL, dR = torch.empty_like(L), torch.empty_like(R)
+        _abi.check(self.lib.alink_head_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), None, n, 0.0, 0,
+                                                  _abi.ptr(self._metrics), _abi.current_stream()), "alink_head_train_step")
+        _abi.check(self.lib.alink_head_input_grads(self.h, _abi.ptr(L), _abi.ptr(R), n, _abi.ptr(dL), _abi.ptr(dR),
+                                                   _abi.current_stream()), "alink_head_input_grads")
+        return dL, dR
+
     def test_on_batch(self, x, y):
         L, R = self._dev(x[0]), self._dev(x[1])
         yd = self._dev(y)

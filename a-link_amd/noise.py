@@ -238,6 +238,88 @@ class AdversarialNoise(Noise):
         return [left_half, right_half]
 
 
+class FGSM(Noise):
+    """EXTENSION — not in the reference (its only attack is the black-box few-pixel search above);
+    BASELINE.json's north_star and SURVEY.md §8f N1 name it.  One signed-gradient step on BOTH images of
+    every pair through the frozen feature model and the pair scorer:
+        x' = clip(x -/+ eps * sign(d BCE(scorer(f(xl), f(xr)), target) / dx), 0, 255)
+    targeted (default, like PixelAttacker.attack_all: target class = argmax(target_labels[i])) steps
+    DOWN the loss of the target class; untargeted steps UP the loss of the given labels.
+    Needs an ArcFace-style feature model built with gradients (`ArcFace(..., enable_grad=True)`) and a
+    DenseHead-backed pair model."""
+    steps, alpha, random_start = 1, None, False
+
+    def __init__(self, model=None, sess=None, feature_model=None, eps=4.0, targeted=True, clip=(0.0, 255.0),
+                 seed=None, device=0):
+        super(FGSM, self).__init__(model, sess, feature_model, seed=seed, device=device)
+        self.eps, self.targeted, self.clip = float(eps), bool(targeted), clip
+
+    def _parts(self):
+        from .head import DenseHead
+        bb = getattr(getattr(self.feature_model, "model", None), "model", None)
+        head = getattr(self.model, "siamese_net", None)
+        if bb is None or not getattr(bb, "grad_enabled", False) or not isinstance(head, DenseHead):
+            raise TypeError("FGSM/PGD need ArcFace(..., enable_grad=True) and a DenseHead-backed pair model")
+        return bb, head
+
+    def _targets(self, target_labels, n, out_dim):
+        t = np.asarray(target_labels)
+        cls = t.argmax(axis=1) if (t.ndim == 2 and t.shape[1] > 1) else t.reshape(n).astype(int)
+        if out_dim == 1:
+            return cls.reshape(n, 1).astype(np.float32)
+        y = np.zeros((n, out_dim), np.float32)
+        y[np.arange(n), cls] = 1.0
+        return y
+
+    def addPairNoise(self, image_pairs, target_labels):
+        import torch
+        bb, head = self._parts()
+        xl, as_torch = _as_device(image_pairs[0] if not isinstance(image_pairs[0], (list, tuple)) else np.stack(image_pairs[0]), self.device)
+        xr, _ = _as_device(image_pairs[1] if not isinstance(image_pairs[1], (list, tuple)) else np.stack(image_pairs[1]), self.device)
+        n = xl.shape[0]
+        y = torch.from_numpy(self._targets(target_labels, n, head.out_dim)).to(xl.device)
+        step = self.eps if self.alpha is None else float(self.alpha)
+        sign = -1.0 if self.targeted else 1.0
+        al, ar = xl.clone(), xr.clone()
+        if self.random_start:
+            g = torch.Generator(device=xl.device).manual_seed(self._next_seed() & 0x7FFFFFFF)
+            al += (torch.rand(al.shape, generator=g, device=al.device) * 2 - 1) * self.eps
+            ar += (torch.rand(ar.shape, generator=g, device=ar.device) * 2 - 1) * self.eps
+        mb = bb.max_batch
+        for _ in range(self.steps):
+            for s in range(0, n, mb):
+                sl = slice(s, min(n, s + mb))
+                er = bb.embed_device(ar[sl])
+                el = bb.embed_with_cache(al[sl])                  # left side: forward with cache, backward
+                dL, _ = head.input_gradients(el, er, y[sl])
+                gl = bb.input_gradient(dL)
+                er = bb.embed_with_cache(ar[sl])                  # right side against the un-stepped left
+                _, dR = head.input_gradients(el, er, y[sl])
+                gr = bb.input_gradient(dR)
+                al[sl] += sign * step * torch.sign(gl)
+                ar[sl] += sign * step * torch.sign(gr)
+            # stay inside the eps-ball of the clean images and inside the pixel range
+            al = torch.max(torch.min(al, xl + self.eps), xl - self.eps)
+            ar = torch.max(torch.min(ar, xr + self.eps), xr - self.eps)
+            if self.clip is not None:
+                al, ar = al.clamp(self.clip[0], self.clip[1]), ar.clamp(self.clip[0], self.clip[1])
+        return [_ret(al, as_torch), _ret(ar, as_torch)]
+
+    def addNoise(self, images, target_labels):
+        raise TypeError("gradient attacks perturb pairs: use addPairNoise")
+
+
+class PGD(FGSM):
+    """EXTENSION — projected gradient descent: `steps` signed-gradient steps of size `alpha` inside the
+    eps-ball (Madry et al. 2018), optional uniform random start."""
+
+    def __init__(self, model=None, sess=None, feature_model=None, eps=4.0, alpha=1.0, steps=5, random_start=True,
+                 targeted=True, clip=(0.0, 255.0), seed=None, device=0):
+        super(PGD, self).__init__(model, sess, feature_model, eps=eps, targeted=targeted, clip=clip, seed=seed,
+                                  device=device)
+        self.alpha, self.steps, self.random_start = float(alpha), int(steps), bool(random_start)
+
+
 def get_relevant_noise(noise_string):
     noise_mapping = {
         'gaussian': Gaussian,
@@ -247,6 +329,8 @@ def get_relevant_noise(noise_string):
         'plain': Noise,
         'perlin': Perlin,
         'adversarial': AdversarialNoise,
+        'fgsm': FGSM,          # extensions, not in the reference's table (code/noise.py:192-200)
+        'pgd': PGD,
     }
     if noise_string.lower() in noise_mapping:
         return noise_mapping[noise_string.lower()]

@@ -194,8 +194,9 @@ class RESNET50:
 
 
 class ArcFace:
-    def __init__(self, shape, model_path, dtype="bf16", max_batch=256):
+    def __init__(self, shape, model_path, dtype="bf16", max_batch=256, enable_grad=False):
         args = _Args({
+            "enable_grad": enable_grad,
             "image_size": "%d,%d" % (shape[0], shape[1]),
             "model": model_path + ",0",
             "gpu": 0,

@@ -99,6 +99,21 @@ int alink_embed_profile(alink_backbone_t* bb, const void* dev_in, int layout, in
                         float* dev_out, void* dev_workspace, size_t workspace_bytes, void* stream,
                         float* ms, double* flops, int* kind, int* n_launches);
 
+/* EXTENSION (not in the reference, which has only a black-box pixel attack: code/attack.py; named by
+ * BASELINE.json's north_star and SURVEY.md §8f N1): d(loss)/d(pixels) through the frozen backbone for
+ * FGSM / PGD.  alink_backbone_enable_grad (before finalize) also builds the transposed, flipped
+ * folded weights (doubles weight memory) and refuses checkpoints with negative PReLU slopes.
+ * alink_embed_cached = alink_embed that keeps what the backward pass needs in the (larger) workspace;
+ * alink_embed_input_grad then maps dev_demb = d(loss)/d(embedding) (n x emb, w.r.t. the L2-normalised
+ * output dev_emb of that forward) to dev_dpix = d(loss)/d(pixel) (n images, float32, NHWC or NCHW). */
+int alink_backbone_enable_grad(alink_backbone_t* bb);
+size_t alink_backbone_grad_workspace_bytes(const alink_backbone_t* bb, int n_images);
+int alink_embed_cached(alink_backbone_t* bb, const void* dev_in, int layout, int n_images, float* dev_out,
+                       void* dev_workspace, size_t workspace_bytes, void* stream);
+int alink_embed_input_grad(alink_backbone_t* bb, const float* dev_demb, const float* dev_emb, int layout,
+                           int n_images, float* dev_dpix, void* dev_workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* Diagnostic / unit-test entry: one fused NHWC convolution launch of the implicit-GEMM kernel
  *   out = [prelu_alpha]( conv(in, w) + bias[class] ) [+ resid]
  * dev_w is (Cout, ksz, ksz, Cin) in `dtype` in NATURAL cout order (the call permutes a private

@@ -54,7 +54,7 @@ def forward_raw(params, pixels_nchw, dtype=torch.float32, taps=None):
     """pixels_nchw: (N,3,H,W) float RGB 0..255 (what FaceModel.get_feature feeds MXNet after
     np.expand_dims, code/face_model.py:87-88).  Returns the un-normalised fc1 output (N, emb).
     `taps`, if a dict, receives intermediate NCHW tensors by layer name (for per-layer tests)."""
-    x = torch.as_tensor(np.asarray(pixels_nchw), dtype=dtype)
+    x = pixels_nchw.to(dtype) if isinstance(pixels_nchw, torch.Tensor) else torch.as_tensor(np.asarray(pixels_nchw), dtype=dtype)
     units = infer_units(params)
     x = (x - 127.5) * 0.0078125
     x = F.conv2d(x, _t(params, "conv0_weight", dtype), stride=1, padding=1)
