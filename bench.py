@@ -23,6 +23,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+class _stdout_to_stderr(object):
+    """fd-level redirect: RCCL prints a start-up banner on STDOUT when the first communicator is made;
+    the contract is ONE JSON line on stdout."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
 MFMA_PEAK_TFLOPS = 2516.6    # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU dense bf16/f16 (MI355X_MICROARCH.md)
 
 
@@ -55,9 +70,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: rendezvous even when alone
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()                                   # creates the communicator (and its banner) now
+            torch.cuda.synchronize()
 
     units = W.ARCH_UNITS[args.model]
     params = W.synthetic_ir_params(units, seed=1)
