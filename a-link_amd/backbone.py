@@ -89,6 +89,13 @@ class IRBackbone(object):
             return _abi.LAYOUT_NCHW_F32
         raise ValueError("images of shape %s do not match (N,%d,%d,3) / (N,3,%d,%d)" % (tuple(x.shape), h, w, h, w))
 
+    def _checked(self, out):
+        """float16 storage has 5 exponent bits: a network whose activations leave +-65504 (deep nets with
+        synthetic weights do) comes out as NaN.  Fail loudly instead of returning it (bf16 has the range)."""
+        if self.dtype == "f16" and not bool(self.torch.isfinite(out).all()):
+            raise _abi.AlinkError("activations exceeded the float16 range in this network: build the backbone with dtype='bf16'")
+        return out
+
     def embed_device(self, x, out=None):
         """x: CUDA tensor (N,H,W,3) f32|u8 or (N,3,H,W) f32, contiguous.  Returns (N, emb) f32 CUDA."""
         torch = self.torch
@@ -106,7 +113,7 @@ class IRBackbone(object):
                 ws, wsb = self._workspace(m)
                 _abi.check(self.lib.alink_embed(self.h, _abi.ptr(x[i:i + m]), layout, m, _abi.ptr(out[i:i + m]),
                                                 C.c_void_p(ws), wsb, st), "alink_embed")
-            return out
+            return self._checked(out)
         if self._side is None:
             self._side = [torch.cuda.Stream(device=x.device) for _ in range(self.n_streams)]
         cur = torch.cuda.current_stream()
@@ -126,7 +133,7 @@ class IRBackbone(object):
             done = torch.cuda.Event()
             done.record(s)
             cur.wait_event(done)                # results are valid in caller-stream order
-        return out
+        return self._checked(out)
 
     # -- input gradient (FGSM / PGD extension) --------------------------------------------------------
     def _grad_workspace(self, n):

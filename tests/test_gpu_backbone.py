@@ -148,3 +148,20 @@ def test_stream_sharding_is_invisible(gpu):
         assert np.array_equal(got.cpu().numpy(), outs[0])
     bb = IRBackbone(params, image_size=size, max_batch=8, streams=4)
     assert np.array_equal(bb.embed(x[137:138])[0], outs[0][137])
+
+
+def test_headline_depth_parity_r100_and_f16_range(gpu):
+    """IR-ResNet-100 at 112 x 112 — the network of the headline metric — against the unfused float32 CPU
+    oracle: 1 - cos within the north-star bar of 1e-3 in bf16 (measured 6e-4 .. 8e-4 with the SURVEY §8d
+    synthetic weights, whose activations grow to ~1e8 over 49 units; 1.4e-4 for IR-50).  The same growth
+    leaves the float16 range, which must be reported, not returned as NaN."""
+    from a_link_amd import _abi, weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import ir_resnet
+    params = W.synthetic_ir_params(W.ARCH_UNITS["r100"], seed=1)
+    x = np.random.default_rng(0).integers(0, 256, (4, 112, 112, 3)).astype(np.float32)
+    ref = ir_resnet.embed(params, x, batch=4).astype(np.float64)
+    got = IRBackbone(params, dtype="bf16", max_batch=4).embed(x).astype(np.float64)
+    assert (1.0 - (got * ref).sum(1)).max() < 1e-3
+    with pytest.raises(_abi.AlinkError):
+        IRBackbone(params, dtype="f16", max_batch=4).embed(x)
