@@ -1,0 +1,103 @@
+"""readDFW — drop-in for the parts of reference code/readDFW.py the drivers call.
+
+    lookupFile(fullPath)                                          code/readDFW.py:8-26
+    getAllTrainData(prefix, trainFolder, imageRes, model, ...)    code/readDFW.py:65-105
+    getRawTrainData(prefix, trainFolder, imageRes)                code/readDFW.py:108-140
+    getNormalGenerator / getImposterGenerator / getGenerator /
+    splitDisguiseData / createMiniBatch                           code/readDFW.py:143-244   (pairs.py)
+
+DFW layout: <prefix>/<trainFolder>/<person>/<files>; a file name containing `_h_` is a disguised face,
+`_I_` an impersonator, anything else a plain face of that person.  Images are read with PIL as float32
+RGB 0..255 and resized to imageRes with the bilinear rule of cv2.resize — on the device
+(alink_resize_bilinear), one image at a time because every file has its own size.  A person is kept
+only if it has all the kinds the reference asks for; unreadable files are reported and skipped.
+The face-box cropping helpers (cropImages, constructIndexMap, cropAllFolders: one-off dataset
+preparation that rewrites the image files) are not part of the hot path and are not provided.
+"""
+import os
+import re
+
+import numpy as np
+
+from .pairs import (createMiniBatch, getGenerator, getImposterGenerator, getNormalGenerator,  # noqa: F401
+                    splitDisguiseData)
+
+_BOM = '\xef\xbb\xbf'          # DFW's file lists carry stray byte-order marks in directory / file names
+
+
+def lookupFile(fullPath):
+    """The path itself or one of the BOM / leading-blank variants DFW ships (None if none exists)."""
+    directory, fileName = fullPath.rsplit('/', 1)
+    stem, extension = fileName.rsplit('.', 1)
+    candidates = [fullPath,
+                  os.path.join(directory + _BOM, stem) + "." + extension,
+                  os.path.join(directory + _BOM, stem + _BOM) + "." + extension,
+                  os.path.join(directory, stem + _BOM) + "." + extension,
+                  os.path.join(directory, " " + stem) + "." + extension]
+    for c in candidates:
+        if os.path.exists(c):
+            return c
+    print(fullPath)
+    print(os.listdir(directory))
+    return None
+
+
+def _load(path, imageRes):
+    from PIL import Image
+    from . import noise as _noise
+    img = np.asarray(Image.open(lookupFile(path)).convert('RGB'), dtype=np.float32)
+    img = np.asarray(_noise.resize_images(img[None], imageRes))[0]          # cv2.resize(img, imageRes)
+    if img.shape[0] != imageRes[0] or img.shape[1] != imageRes[1] or img.shape[2] != 3:
+        raise SystemExit("Image re-shape error occured. Exiting!")
+    return img
+
+
+def _people(prefix, trainFolder, imageRes):
+    """Yields per person the three lists (plain, disguised, impersonator) of loaded images."""
+    root = os.path.join(prefix, trainFolder)
+    for person in sorted(os.listdir(root)):
+        kinds = {"plain": [], "dig": [], "imp": []}
+        dirPath = os.path.join(root, person)
+        for impath in sorted(os.listdir(dirPath)):
+            fullName = re.sub(r"[/]\s", "/", os.path.join(dirPath, impath))
+            fileName = impath.rsplit('.', 1)[0]
+            try:
+                img = _load(fullName, imageRes)
+            except SystemExit:
+                raise
+            except Exception as ex:
+                print(ex)
+                continue
+            kinds["dig" if '_h_' in fileName else ("imp" if '_I_' in fileName else "plain")].append(img)
+        yield kinds
+
+
+def getAllTrainData(prefix, trainFolder, imageRes, model, combine_normal_imp=False):
+    """-> (X_plain, X_dig, X_imp): per-person FEATURE arrays, model.process applied at load.
+    combine_normal_imp files the disguised images under "plain" (code/readDFW.py:87-90); the keep-test
+    that follows still asks for a non-empty disguised list (:97), so in that mode the reference — and
+    this function — return no person at all (the baseline script that sets the flag, existing_al.py,
+    cannot have worked on it).  Reproduced, not repaired."""
+    X_plain, X_dig, X_imp = [], [], []
+    for k in _people(prefix, trainFolder, imageRes):
+        plain, dig = (k["plain"] + k["dig"], []) if combine_normal_imp else (k["plain"], k["dig"])
+        if dig and k["imp"] and plain:
+            if not combine_normal_imp:
+                X_dig.append(model.process(np.stack(dig)))
+            X_imp.append(model.process(np.stack(k["imp"])))
+            X_plain.append(model.process(np.stack(plain)))
+    if not combine_normal_imp:
+        assert len(X_plain) == len(X_dig) and len(X_dig) == len(X_imp)
+    return (X_plain, X_dig, X_imp)
+
+
+def getRawTrainData(prefix, trainFolder, imageRes):
+    """-> (X_plain, X_dig): per-person raw pixel arrays (k, H, W, 3).  A person needs disguised AND
+    impersonator images (the reference's condition, code/readDFW.py:136, never looks at the plain list)."""
+    X_plain, X_dig = [], []
+    for k in _people(prefix, trainFolder, imageRes):
+        if k["dig"] and k["imp"]:
+            X_dig.append(np.stack(k["dig"]))
+            X_plain.append(np.stack(k["plain"]))
+    assert len(X_plain) == len(X_dig)
+    return (X_plain, X_dig)

@@ -1,0 +1,57 @@
+"""GPU: the runnable driver (a-link_amd/ALINK_arc.py = reference code/ALINK_arc.py's __main__) on a
+synthetic DFW-style directory tree of PNG files: loaders, pre-training phases, framework loop, files."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_dfw(root, n_persons=6, seed=0):
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    d = os.path.join(root, "Training_data")
+    for p in range(n_persons):
+        pd = os.path.join(d, "person%02d" % p)
+        os.makedirs(pd)
+        for name, size in (("%02d.png" % p, (130, 120)), ("%02d_a.png" % p, (112, 112)), ("%02d_h_001.png" % p, (90, 100)),
+                           ("%02d_h_002.png" % p, (150, 140)), ("%02d_I_001.png" % p, (112, 112))):
+            Image.fromarray(rng.randint(0, 256, size + (3,)).astype(np.uint8)).save(os.path.join(pd, name))
+    os.makedirs(os.path.join(d, "person99"))                         # no impersonator -> skipped like the reference
+    Image.fromarray(rng.randint(0, 256, (50, 50, 3)).astype(np.uint8)).save(os.path.join(d, "person99", "99.png"))
+    return root
+
+
+def test_readDFW_loaders(gpu, tmp_path):
+    from a_link_amd import readDFW, siamese
+    root = _make_dfw(str(tmp_path))
+    conv = siamese.ArcFace((112, 112), "synthetic:r18:2")
+    Xp, Xd, Xi = readDFW.getAllTrainData(root, "Training_data", (112, 112), conv)
+    assert len(Xp) == len(Xd) == len(Xi) == 6
+    assert Xp[0].shape == (2, 512) and Xd[0].shape == (2, 512) and Xi[0].shape == (1, 512)
+    Rp, Rd = readDFW.getRawTrainData(root, "Training_data", (112, 112))
+    assert len(Rp) == 6 and Rp[0].shape == (2, 112, 112, 3) and Rd[0].shape == (2, 112, 112, 3)
+    assert Rp[0].dtype == np.float32 and 0 <= Rp[0].min() and Rp[0].max() <= 255
+    # features were computed from the same resized pixels
+    assert np.array_equal(conv.process(Rp[0]), Xp[0])
+    assert readDFW.lookupFile(os.path.join(root, "Training_data", "person00", "00.png")).endswith("00.png")
+    assert readDFW.getAllTrainData(root, "Training_data", (112, 112), conv, combine_normal_imp=True) == ([], [], [])
+
+
+def test_driver_phases_end_to_end(gpu, tmp_path):
+    from a_link_amd import ALINK_arc
+    root = _make_dfw(str(tmp_path))
+    models = str(tmp_path / "models")
+    os.makedirs(models)
+    common = ["--dataDirPrefix", root, "--arcface_model", "synthetic:r18:2", "--quiet",
+              "--out_model", os.path.join(models, "postALINK"), "--ensemble_basepath", os.path.join(models, "ensemble"),
+              "--disguised_basemodel", os.path.join(models, "disguisedModel"), "--pretrain_steps", "64",
+              "--dig_epochs", "1", "--undig_epochs", "1", "--noise", "gaussian,speckle,perlin"]
+    np.random.seed(0)
+    assert ALINK_arc.main(common + ["--train_disguised_model"]) is None        # phase 1: pre-train M2 and quit
+    assert os.path.exists(os.path.join(models, "disguisedModel.h5"))
+    st = ALINK_arc.main(common + ["--alink_bs", "3", "--batch_send", "8", "--disparity_ratio", "0.9", "--eps", "0.0001",
+                                  "--ft_epochs", "1"])
+    assert os.path.exists(os.path.join(models, "ensemble1.h5")) and os.path.exists(os.path.join(models, "postALINK.h5"))
+    assert st.iterations >= 1 and st.un_size > 0 and st.active_count >= 0
