@@ -55,3 +55,32 @@ def test_driver_phases_end_to_end(gpu, tmp_path):
                                   "--ft_epochs", "1"])
     assert os.path.exists(os.path.join(models, "ensemble1.h5")) and os.path.exists(os.path.join(models, "postALINK.h5"))
     assert st.iterations >= 1 and st.un_size > 0 and st.active_count >= 0
+
+
+def _make_mtp(root, n_persons=5, seed=0):
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    os.makedirs(root)
+    for p in range(1, n_persons + 1):
+        for suf in ("01_01_051_06.png", "02_01_051_06.png", "01_01_051_08.png", "02_01_051_08.png", "01_01_130_06.png"):
+            Image.fromarray(rng.randint(0, 256, (64, 64, 3)).astype(np.uint8)).save(os.path.join(root, "%03d_%s" % (p, suf)))
+    return root
+
+
+def test_mtp_driver_end_to_end(gpu, tmp_path):
+    from a_link_amd import ALINK_MTP, readMTP
+    train, test = _make_mtp(str(tmp_path / "train")), _make_mtp(str(tmp_path / "test"), seed=1)
+    people = readMTP.readAllImages(train)
+    assert len(people) == 5 and people[0].shape == (4, 64, 64, 3)          # the fifth shot does not qualify
+    models = str(tmp_path / "models")
+    os.makedirs(models)
+    common = ["--dataDirPrefix", train, "--testDir", test, "--quiet", "--lowRes", "32", "--noise", "gaussian,plain",
+              "--out_model", os.path.join(models, "postALINK"), "--ensemble_basepath", os.path.join(models, "ensemble"),
+              "--lowres_basemodel", os.path.join(models, "lowresModel"), "--pretrain_steps", "32", "--lowres_epochs", "1"]
+    np.random.seed(0)
+    assert ALINK_MTP.main(common) is None                                   # first run trains the low-res model and quits
+    assert os.path.exists(os.path.join(models, "lowresModel32.h5"))
+    st = ALINK_MTP.main(common + ["--alink_bs", "2", "--batch_send", "4", "--disparity_ratio", "1.0", "--eps", "0.0",
+                                  "--ft_epochs", "1", "--active_ratio", "4.0"])
+    assert os.path.exists(os.path.join(models, "postALINK.h5"))
+    assert st.iterations >= 1 and 0.0 <= st.top1 <= 1.0
