@@ -128,3 +128,43 @@ def get_stats(TPR, FPR, verbose=False):
         print('GAR is %f for %f FAR' % (out["gar_at_1pct_far"], 0.010))
         print('GAR is %f for %f FAR' % (out["gar_at_0p1pct_far"], 0.0010))
     return out
+
+
+def main(argv=None):
+    """The three evaluation scripts behind one entry point (same positional arguments as the originals):
+        python -m a_link_amd.evaluation matrix MODELNAME OUTPUT      utilities/generateMatrixDFW.py (processedData.npy in cwd)
+        python -m a_link_amd.evaluation roc SCORES OUTPUT ROC_CASE   utilities/ROC_precompute.py (mask + thresholds in cwd)
+        python -m a_link_amd.evaluation stats ROCFILE                utilities/getStats.py
+    """
+    import sys
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv or argv[0] not in ("matrix", "roc", "stats"):
+        print(main.__doc__)
+        return 2
+    cmd, args = argv[0], argv[1:]
+    if cmd == "stats":
+        TPR, FPR = np.loadtxt(args[0])
+        get_stats(TPR, FPR, verbose=True)
+        return 0
+    if cmd == "roc":
+        scores = np.loadtxt(args[0], dtype=float)
+        mask = np.loadtxt('updated_testing_mask.txt', dtype=int)
+        thresholds = np.loadtxt('thresholds.txt', dtype=float)
+        tpr, fpr = roc_precompute(scores, mask, thresholds, int(args[2]))
+        print('Genuine and Imposter score generated')
+        np.savetxt(args[1], np.array([tpr, fpr]))
+        return 0
+    from . import siamese
+    features = np.load("processedData.npy")
+    model = siamese.SiameseNetwork((features.shape[1],), args[0], 0.1)
+    if model.maybeLoadFromMemory():
+        print("Loaded model successfully!")
+    else:
+        print("Oops! Model not found")
+        return 1
+    np.savetxt(args[1], score_matrix(model, features, col=0))
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
