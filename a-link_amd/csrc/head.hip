@@ -44,7 +44,22 @@ struct alink_head {
     float *d_dm = nullptr, *d_z1 = nullptr, *d_z2 = nullptr, *d_dz1 = nullptr, *d_dz2 = nullptr,
           *d_dz3 = nullptr, *d_p = nullptr;
     std::vector<void*> allocs;
-    ~alink_head() { for (void* p : allocs) (void)hipFree(p); }
+    // hipGraph cache of the fine-tune step (a launch-bound chain of 8-9 small kernels): one executable
+    // graph per distinct (operand pointers, n, grad_scale, apply); replayed while the caller keeps
+    // feeding the same buffers (DenseHead stages every batch into persistent tensors for that purpose)
+    struct StepGraph {
+        const void *L, *R, *y, *sw, *metrics;
+        int n, apply;
+        float grad_scale, lr;
+        hipGraphExec_t exec;
+    };
+    std::vector<StepGraph> graphs;
+    bool use_graph = false;     // measured on MI355X: replay 67.8 us vs 66.2 us of plain launches — the chain is
+                                // bound by kernel-to-kernel dependency latency, not by launch cost; kept as an option
+    ~alink_head() {
+        for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
+        for (void* p : allocs) (void)hipFree(p);
+    }
 };
 
 namespace {
@@ -259,10 +274,13 @@ __global__ void dense_fwd_relu_in_kernel(const float* __restrict__ zin, const fl
 // Small-batch dense forward with enough waves to hide latency: block = (one row, 64 columns) x 8
 // K-slices (one wave each, coalesced weight rows, broadcast activation), fixed-order LDS reduce.
 // z[r][c] = sum_k act(a[r][k]) * w[k][c] + b[c]   (act = relu when relu_in).  K % 8 == 0.
+// With Rm != nullptr the input is |a - Rm| computed on the fly (the Lambda layer of code/siamese.py:27),
+// and the first column block also stores it to dm_out for the weight gradient.
 __global__ __launch_bounds__(512) void dense_fwd_tiled_kernel(const float* __restrict__ a,
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ b, float* __restrict__ z,
-                                                             int n, int K, int C, int relu_in) {
+                                                             int n, int K, int C, int relu_in,
+                                                             const float* __restrict__ Rm, float* __restrict__ dm_out) {
     __shared__ float part[8][64];
     const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane, r = blockIdx.y;
@@ -270,7 +288,15 @@ __global__ __launch_bounds__(512) void dense_fwd_tiled_kernel(const float* __res
     const float* ar = a + (size_t)r * K + ks * kper;
     const float* wp = w + (size_t)(ks * kper) * C + c;
     float s = 0.f;
-    if (c < C) {
+    if (Rm) {
+        const float* rr = Rm + (size_t)r * K + ks * kper;
+        if (blockIdx.x == 0)
+            for (int k = lane; k < kper; k += 64) dm_out[(size_t)r * K + ks * kper + k] = fabsf(ar[k] - rr[k]);
+        if (c < C) {
+#pragma unroll 8
+            for (int k = 0; k < kper; ++k) s = fmaf(fabsf(ar[k] - rr[k]), wp[(size_t)k * C], s);
+        }
+    } else if (c < C) {
 #pragma unroll 8
         for (int k = 0; k < kper; ++k) {
             float av = ar[k];
@@ -453,6 +479,73 @@ __global__ void head_input_grad_kernel(const float* __restrict__ L, const float*
     dR[i] = -s * sg;
 }
 
+// One launch for the two independent halves of the middle of the backward pass:
+//   blocks [0, nb_w):   gW2[k][c] = sum_i relu(z1[i][k]) dz2[i][c], gb2        (dense_wgrad_kernel's body)
+//   blocks [nb_w, ...): dz1[r][k] = (z1 > 0) sum_c dz2[r][c] W2[k][c]          (dense_dgrad_kernel's body)
+__global__ void head_bwd_mid_kernel(const float* __restrict__ z1, const float* __restrict__ dz2,
+                                    const float* __restrict__ w2, float* __restrict__ gw2, float* __restrict__ gb2,
+                                    float* __restrict__ dz1, int n, int h1, int h2, int nb_w) {
+    if ((int)blockIdx.x < nb_w) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < h1 * h2) {
+            const int k = i / h2, c = i - k * h2;
+            float s = 0.f;
+            for (int r = 0; r < n; ++r) s = fmaf(fmaxf(z1[(size_t)r * h1 + k], 0.f), dz2[(size_t)r * h2 + c], s);
+            gw2[i] = s;
+        } else if (i < h1 * h2 + h2) {
+            const int c = i - h1 * h2;
+            float s = 0.f;
+            for (int r = 0; r < n; ++r) s += dz2[(size_t)r * h2 + c];
+            gb2[c] = s;
+        }
+        return;
+    }
+    const int i = (blockIdx.x - nb_w) * 256 + threadIdx.x;
+    if (i >= n * h1) return;
+    const int r = i / h1, k = i - r * h1;
+    const float* wr = w2 + (size_t)k * h2;
+    const float* dr = dz2 + (size_t)r * h2;
+    float s = 0.f;
+    for (int c = 0; c < h2; ++c) s = fmaf(dr[c], wr[c], s);
+    dz1[i] = z1[i] > 0.f ? s : 0.f;
+}
+
+__device__ __forceinline__ void adadelta_one(float* prm, float* a, float* d, size_t i, float gi, float lr, float rho,
+                                             float eps) {
+    const float na = rho * a[i] + (1.f - rho) * gi * gi;
+    const float u = gi * sqrtf(d[i] + eps) / sqrtf(na + eps);
+    prm[i] = prm[i] - lr * u;
+    d[i] = rho * d[i] + (1.f - rho) * u * u;
+    a[i] = na;
+}
+
+// Last launch of the fused train step: the first-layer weight/bias gradient (gW1 = dm^T dz1, gb1) with
+// its Adadelta update applied in the same thread, and — in the remaining blocks — the Adadelta update
+// of every later parameter from the gradients the earlier launches stored.  All gradients were taken
+// with the old weights (nothing upstream reads W1 after this point; W2/W3 are updated only here).
+__global__ void head_wgrad1_update_kernel(const float* __restrict__ dm, const float* __restrict__ dz1,
+                                          float* __restrict__ prm, float* __restrict__ g, float* __restrict__ a,
+                                          float* __restrict__ d, int n, int D, int h1, size_t n_first, size_t nparams,
+                                          int nb_first, float lr, float rho, float eps) {
+    if ((int)blockIdx.x < nb_first) {
+        const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+        if (i >= n_first) return;
+        float s = 0.f;
+        if (i < (size_t)D * h1) {
+            const int k = (int)(i / h1), c = (int)(i - (size_t)k * h1);
+            for (int r = 0; r < n; ++r) s = fmaf(dm[(size_t)r * D + k], dz1[(size_t)r * h1 + c], s);
+        } else {
+            const int c = (int)(i - (size_t)D * h1);
+            for (int r = 0; r < n; ++r) s += dz1[(size_t)r * h1 + c];
+        }
+        g[i] = s;
+        adadelta_one(prm, a, d, i, s, lr, rho, eps);
+        return;
+    }
+    const size_t i = n_first + (size_t)(blockIdx.x - nb_first) * 256 + threadIdx.x;
+    if (i < nparams) adadelta_one(prm, a, d, i, g[i], lr, rho, eps);
+}
+
 __global__ void adadelta_kernel(float* __restrict__ prm, const float* __restrict__ g, float* __restrict__ a,
                                 float* __restrict__ d, size_t n, float lr, float rho, float eps) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -517,29 +610,37 @@ int launch_fwd(alink_head* h, const float* L, const float* R, const int32_t* li,
 }
 
 // forward (+ optional backward) on a small batch with the VALU kernels
+// The step is a chain of dependent small kernels (each ~7 us of pure latency at batch 16), so the chain
+// is kept short: |l - r| inside the first Dense, the two independent middle gradients in one launch,
+// and (fused_update) the first-layer weight gradient together with the whole Adadelta update: 5 launches.
 int small_pass(alink_head* h, const float* L, const float* R, const float* y, const float* sw, int n,
-               float grad_scale, bool want_grads, float* metrics, hipStream_t st) {
+               float grad_scale, bool want_grads, float* metrics, hipStream_t st, bool fused_update = false) {
     ALINK_REQUIRE(n > 0 && n <= h->cap, ALINK_EINVAL, "batch of %d rows outside 1..%d", n, h->cap);
     const int D = h->D, h1 = h->h1, h2 = h->h2;
     float* P = h->d_params;
     float* G = h->d_grads;
-    hipLaunchKernelGGL(absdiff_kernel, g1((long long)n * D), dim3(256), 0, st, L, R, h->d_dm, n, D);
-    hipLaunchKernelGGL(dense_fwd_tiled_kernel, dim3((h1 + 63) / 64, n), dim3(512), 0, st, h->d_dm, P + h->oW1,
-                       P + h->ob1, h->d_z1, n, D, h1, 0);
+    hipLaunchKernelGGL(dense_fwd_tiled_kernel, dim3((h1 + 63) / 64, n), dim3(512), 0, st, L, P + h->oW1,
+                       P + h->ob1, h->d_z1, n, D, h1, 0, R, h->d_dm);
     hipLaunchKernelGGL(dense_fwd_tiled_kernel, dim3((h2 + 63) / 64, n), dim3(512), 0, st, h->d_z1, P + h->oW2,
-                       P + h->ob2, h->d_z2, n, h1, h2, 1);
+                       P + h->ob2, h->d_z2, n, h1, h2, 1, (const float*)nullptr, (float*)nullptr);
     HeadLoss lp{};
     lp.z2 = h->d_z2; lp.w3 = P + h->oW3; lp.b3 = P + h->ob3; lp.y = y; lp.sw = sw; lp.probs = h->d_p;
     lp.dz3 = h->d_dz3; lp.dz2 = h->d_dz2; lp.gw3 = G + h->oW3; lp.gb3 = G + h->ob3; lp.metrics = metrics;
     lp.n = n; lp.h2 = h2; lp.want_grads = want_grads ? 1 : 0; lp.grad_scale = grad_scale; lp.od = h->od;
     hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(256), 0, st, lp);
     if (want_grads) {
-        hipLaunchKernelGGL(dense_wgrad_kernel, g1((long long)h1 * h2 + h2), dim3(256), 0, st, h->d_z1, h->d_dz2,
-                           G + h->oW2, G + h->ob2, n, h1, h2, 1);
-        hipLaunchKernelGGL(dense_dgrad_kernel, g1((long long)n * h1), dim3(256), 0, st, h->d_dz2, P + h->oW2,
-                           h->d_z1, h->d_dz1, n, h1, h2);
-        hipLaunchKernelGGL(dense_wgrad_kernel, g1((long long)D * h1 + h1), dim3(256), 0, st, h->d_dm, h->d_dz1,
-                           G + h->oW1, G + h->ob1, n, D, h1, 0);
+        const int nb_w = (h1 * h2 + h2 + 255) / 256, nb_d = (n * h1 + 255) / 256;
+        hipLaunchKernelGGL(head_bwd_mid_kernel, dim3(nb_w + nb_d), dim3(256), 0, st, h->d_z1, h->d_dz2, P + h->oW2,
+                           G + h->oW2, G + h->ob2, h->d_dz1, n, h1, h2, nb_w);
+        if (fused_update) {
+            const size_t n_first = (size_t)D * h1 + h1;            // W1 and b1 are the first parameters (oW1 = 0)
+            const int nb_first = (int)((n_first + 255) / 256), nb_rest = (int)((h->nparams - n_first + 255) / 256);
+            hipLaunchKernelGGL(head_wgrad1_update_kernel, dim3(nb_first + nb_rest), dim3(256), 0, st, h->d_dm, h->d_dz1,
+                               P, G, h->d_acc, h->d_dacc, n, D, h1, n_first, h->nparams, nb_first, h->lr, h->rho, h->eps);
+        } else {
+            hipLaunchKernelGGL(dense_wgrad_kernel, g1((long long)D * h1 + h1), dim3(256), 0, st, h->d_dm, h->d_dz1,
+                               G + h->oW1, G + h->ob1, n, D, h1, 0);
+        }
     }
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
@@ -666,13 +767,66 @@ int alink_pair_scores_matrix(alink_head_t* const* heads, int n_heads, const floa
     return ALINK_OK;
 }
 
+static int train_step_launches(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
+                               const float* dev_sw, int n, float grad_scale, int apply, float* dev_metrics,
+                               hipStream_t st) {
+    int rc = small_pass(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, true, dev_metrics, st, apply != 0);
+    if (rc) return rc;
+    if (apply) h->packed_dirty = true;
+    return ALINK_OK;
+}
+
+int alink_head_set_graph(alink_head_t* h, int on) {
+    ALINK_REQUIRE(h, ALINK_EINVAL, "NULL head");
+    h->use_graph = on != 0;
+    return ALINK_OK;
+}
+
 int alink_head_train_step(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
                           const float* dev_sw, int n, float grad_scale, int apply, float* dev_metrics,
                           void* stream) {
     ALINK_REQUIRE(h && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
-    int rc = small_pass(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, true, dev_metrics, (hipStream_t)stream);
-    if (rc) return rc;
-    if (apply) return alink_head_apply_update(h, stream);
+    ALINK_REQUIRE(n > 0 && n <= h->cap, ALINK_EINVAL, "batch of %d rows outside 1..%d", n, h->cap);
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    // the legacy default stream cannot be captured, and a stream the caller is already capturing must
+    // simply receive the launches
+    const bool can_graph = h->use_graph && st != nullptr &&
+                           hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+    if (!can_graph) return train_step_launches(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, apply, dev_metrics, st);
+    for (auto& g : h->graphs)
+        if (g.L == dev_L && g.R == dev_R && g.y == dev_y && g.sw == dev_sw && g.metrics == dev_metrics && g.n == n &&
+            g.apply == apply && g.grad_scale == grad_scale && g.lr == h->lr) {
+            ALINK_HIP(hipGraphLaunch(g.exec, st));
+            if (apply) h->packed_dirty = true;
+            return ALINK_OK;
+        }
+    hipGraph_t graph = nullptr;
+    ALINK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = train_step_launches(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, apply, dev_metrics, st);
+    const hipError_t ee = hipStreamEndCapture(st, &graph);
+    if (rc || ee != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        if (rc) return rc;
+        h->use_graph = false;                       // capture is not available here: plain launches from now on
+        return train_step_launches(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, apply, dev_metrics, st);
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) {
+        (void)hipGetLastError();
+        h->use_graph = false;
+        return train_step_launches(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, apply, dev_metrics, st);
+    }
+    if (h->graphs.size() >= 16) {
+        (void)hipGraphExecDestroy(h->graphs.front().exec);
+        h->graphs.erase(h->graphs.begin());
+    }
+    h->graphs.push_back({dev_L, dev_R, dev_y, dev_sw, dev_metrics, n, apply, grad_scale, h->lr, exec});
+    ALINK_HIP(hipGraphLaunch(exec, st));
+    if (apply) h->packed_dirty = true;
     return ALINK_OK;
 }
 

@@ -165,6 +165,7 @@ class DenseHead(KerasFitMixin):
                           glorot_uniform(rng, h1, h2), np.zeros(h2, np.float32),
                           glorot_uniform(rng, h2, self.out_dim), np.zeros(self.out_dim, np.float32)])
         self._metrics = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self._stage = {}          # persistent device tensors the host batches are copied into
 
     def __del__(self):
         try:
@@ -318,11 +319,23 @@ class DenseHead(KerasFitMixin):
             return np.asarray([class_weight[c] for c in cls if c in class_weight], dtype=np.float32)
         return None
 
+    def _staged(self, key, a):
+        """Device float32 tensor holding `a` at an address that stays the same from call to call."""
+        torch = self.torch
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device, torch.float32).contiguous()          # the caller's own buffer
+        arr = np.ascontiguousarray(a, dtype=np.float32)
+        buf = self._stage.get((key, arr.shape))
+        if buf is None:
+            buf = self._stage[(key, arr.shape)] = torch.empty(arr.shape, dtype=torch.float32, device=self.device)
+        buf.copy_(torch.from_numpy(arr))
+        return buf
+
     def train_on_batch(self, x, y, class_weight=None, sample_weight=None):
-        L, R = self._dev(x[0]), self._dev(x[1])
-        yd = self._dev(y)
+        L, R = self._staged("L", x[0]), self._staged("R", x[1])
+        yd = self._staged("y", y)
         sw = self._sample_weights(y, class_weight, sample_weight)
-        swd = self._dev(sw) if sw is not None else None
+        swd = self._staged("sw", sw) if sw is not None else None
         n = L.shape[0]
         _abi.check(self.lib.alink_head_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
                                                   0.0, 1, _abi.ptr(self._metrics), _abi.current_stream()),
