@@ -43,6 +43,7 @@ struct alink_head {
     int cap = 4096;
     float *d_dm = nullptr, *d_z1 = nullptr, *d_z2 = nullptr, *d_dz1 = nullptr, *d_dz2 = nullptr,
           *d_dz3 = nullptr, *d_p = nullptr;
+    float* d_tiny = nullptr;     // per-row-group partials of the tiny-batch train step
     std::vector<void*> allocs;
     // hipGraph cache of the fine-tune step (a launch-bound chain of 8-9 small kernels): one executable
     // graph per distinct (operand pointers, n, grad_scale, apply); replayed while the caller keeps
@@ -609,6 +610,554 @@ int launch_fwd(alink_head* h, const float* L, const float* R, const int32_t* li,
     return ALINK_OK;
 }
 
+bool g_use_tiny = true;
+
+// ------------------------------- tiny-batch train step (n <= 32) -------------------------------------
+// The fine-tune step of code/siamese.py:52-58 runs at batch 16: far too little work to fill the chip,
+// so its cost is the length of its chain of DEPENDENT launches and the memory round trips inside each.
+// Rows are independent up to dZ1, and only z1 -> z2 and dZ1 -> dW1 need every column / row of the
+// previous stage, so three launches suffice, each issuing all of its global loads up front:
+//   A  tiny_dense1_kernel    |l - r| (stored for dW1), Dense1 pre-activations            (h1/64 x n/4 blocks)
+//   B  tiny_dense2_loss_kernel  Dense2, Dense3, softmax/sigmoid, BCE, metrics partials, dZ3, dZ2, dZ1
+//                            (the whole per-row backward), per-row-group partials of dW3 / db3   (n/4 blocks)
+//   C  tiny_wgrad_update_kernel  dW1 tile (64 columns x 32 k) + Adadelta in place; the k-part-0 blocks
+//                            also db1 and dW2 rows (+ update), block (0,0) db2, dW3, db3, metrics
+//                                                                                   (h1/64 x D/32 blocks)
+// No parameter is read in C except by the thread that updates it (W1 is last read in A, W2 / W3 / b* in
+// B), so the in-place update races with nothing.
+constexpr int TINY_N = 32;      // rows the tiny path takes
+constexpr int TINY_RG = 4;      // rows per workgroup in A and B
+constexpr int TINY_KB = 32;     // W1 rows (k) per workgroup in C
+constexpr int TINY_PART = 2 + 64 * 2 + 2 + 4;   // floats one row group leaves: loss, acc, dW3, db3, [132] = rows that count
+
+// acc over K for TINY_RG rows x 4 columns per thread: 512 threads = 16 column lanes x 32 K-slices.
+// a_s: [TINY_RG][K] activations in LDS; w: [K][C] row-major; the thread's columns are c0 + 4*cl ...
+// All 16 weight loads of a 16-deep K chunk are in flight together.  K % 512 == 0.
+// Result: out[r * 64 + c] (c < 64) in `fin` (LDS, TINY_RG * 64 floats), summed in a fixed order.
+__device__ __forceinline__ const float* tiny_w_ptr(const float* __restrict__ w, int K, int C, int c0) {
+    const int tid = threadIdx.x, cl = tid & 15, ks = tid >> 4;
+    return w + (size_t)(ks * (K >> 5)) * C + c0 + cl * 4;
+}
+__device__ __forceinline__ void tiny_load_w(f32x4 (&wv)[16], const float* wp, int C) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wv[i] = *(const f32x4*)(wp + (size_t)i * C);
+}
+// `wv` holds the first 16-deep chunk (loaded by the caller before it staged a_s, so the weight loads and
+// the activation loads share one round trip).
+__device__ __forceinline__ void tiny_dense_core(const float* a_s, int K, const float* wp, int C, f32x4 (&wv)[16],
+                                                float* red /* [8][TINY_RG][64] */, float* fin) {
+    const int tid = threadIdx.x, cl = tid & 15, ks = tid >> 4;
+    const int kper = K >> 5;
+    float acc[TINY_RG][4];
+#pragma unroll
+    for (int r = 0; r < TINY_RG; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[r][j] = 0.f;
+    const float* ap = a_s + ks * kper;
+    for (int k0 = 0; k0 < kper; k0 += 16) {
+        if (k0) tiny_load_w(wv, wp + (size_t)k0 * C, C);
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+#pragma unroll
+            for (int r = 0; r < TINY_RG; ++r) {
+                const f32x4 av = *(const f32x4*)(ap + r * K + k0 + i4 * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[r][j] = fmaf(av[i], wv[i4 * 4 + i][j], acc[r][j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < TINY_RG; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[r][j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[r][j] = v;
+        }
+    if ((tid & 63) < 16) {
+#pragma unroll
+        for (int r = 0; r < TINY_RG; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[((tid >> 6) * TINY_RG + r) * 64 + cl * 4 + j] = acc[r][j];
+    }
+    __syncthreads();
+    if (tid < TINY_RG * 64) {
+        float s = red[tid];
+#pragma unroll
+        for (int wi = 1; wi < 8; ++wi) s += red[wi * TINY_RG * 64 + tid];
+        fin[tid] = s;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(512) void tiny_dense1_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         float* __restrict__ z1, float* __restrict__ dm, int n, int D,
+                                                         int h1) {
+    extern __shared__ __attribute__((aligned(16))) float tiny_lds[];
+    float* a_s = tiny_lds;                        // [TINY_RG][D]
+    float* red = a_s + TINY_RG * D;               // [8][TINY_RG][64]
+    float* fin = red + 8 * TINY_RG * 64;          // [TINY_RG][64]
+    const int tid = threadIdx.x, r0 = blockIdx.y * TINY_RG, c0 = blockIdx.x * 64;
+    const float* wp = tiny_w_ptr(w1, D, h1, c0);
+    f32x4 wv[16];
+    tiny_load_w(wv, wp, h1);
+    const float bias = tid < TINY_RG * 64 ? b1[c0 + (tid & 63)] : 0.f;
+    for (int i = tid; i < TINY_RG * D / 4; i += 512) {
+        const int r = (i * 4) / D, k = (i * 4) - r * D, row = r0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < n) {
+            const f32x4 l = *(const f32x4*)(L + (size_t)row * D + k), q = *(const f32x4*)(R + (size_t)row * D + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fabsf(l[j] - q[j]);
+            if (blockIdx.x == 0) *(f32x4*)(dm + (size_t)row * D + k) = v;
+        }
+        *(f32x4*)(a_s + i * 4) = v;
+    }
+    __syncthreads();
+    tiny_dense_core(a_s, D, wp, h1, wv, red, fin);
+    if (tid < TINY_RG * 64) {
+        const int r = tid >> 6, c = tid & 63, row = r0 + r;
+        if (row < n) z1[(size_t)row * h1 + c0 + c] = fin[tid] + bias;
+    }
+}
+
+struct TinyLoss {
+    const float *z1, *w2, *b2, *w3, *b3, *y, *sw;
+    float *z2, *probs, *dz2, *dz3, *dz1, *part;
+    int n, h1, od, want_grads;
+    float grad_scale;
+};
+
+// h2 == 64.  One workgroup per TINY_RG rows.
+__global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p) {
+    extern __shared__ __attribute__((aligned(16))) float tiny_lds[];
+    const int h1 = p.h1, n = p.n, od = p.od;
+    float* a_s = tiny_lds;                        // [TINY_RG][h1]  relu(z1)
+    float* red = a_s + TINY_RG * h1;
+    float* z2s = red + 8 * TINY_RG * 64;          // [TINY_RG][64]
+    float* dz3s = z2s + TINY_RG * 64;             // [TINY_RG][2]
+    float* rowm = dz3s + TINY_RG * 2;             // [TINY_RG][2]  loss, accuracy of the row
+    float* cnts = rowm + TINY_RG * 2;             // [1]
+    float* w3s = cnts + 4;                        // [64 * od + od]  W3 then b3 (contiguous parameters)
+    float* ys = w3s + 64 * 2 + 4;                 // [TINY_RG][2]
+    float* sws = ys + TINY_RG * 2;                // [TINY_RG]
+    const int tid = threadIdx.x, r0 = blockIdx.x * TINY_RG;
+    // every small operand is fetched now, together with the weights: nothing later waits on global memory
+    const float* wp = tiny_w_ptr(p.w2, h1, 64, 0);
+    f32x4 wv[16];
+    tiny_load_w(wv, wp, 64);
+    const float bias = tid < TINY_RG * 64 ? p.b2[tid & 63] : 0.f;
+    if (tid >= 64 && tid < 64 + 64 * od + od) w3s[tid - 64] = p.w3[tid - 64];
+    if (tid >= 256 && tid < 256 + TINY_RG * od) {
+        const int t = tid - 256, row = r0 + t / od;
+        ys[t] = row < n ? p.y[(size_t)row * od + t % od] : 0.f;
+    }
+    if (tid >= 320 && tid < 320 + TINY_RG) {
+        const int row = r0 + tid - 320;
+        sws[tid - 320] = (row < n && p.sw) ? p.sw[row] : 1.f;
+    }
+    for (int i = tid; i < TINY_RG * h1 / 4; i += 512) {
+        const int r = (i * 4) / h1, k = (i * 4) - r * h1, row = r0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < n) {
+            v = *(const f32x4*)(p.z1 + (size_t)row * h1 + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        *(f32x4*)(a_s + i * 4) = v;
+    }
+    if (tid < 64) {   // number of rows that count (sample weight != 0), over the WHOLE batch
+        float c = (tid < n) ? (p.sw ? (p.sw[tid] != 0.f ? 1.f : 0.f) : 1.f) : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (tid == 0) cnts[0] = c;
+    }
+    __syncthreads();
+    tiny_dense_core(a_s, h1, wp, 64, wv, red, z2s);
+    // one W2 row per thread for dZ1 below: in flight while the loss is computed (L1/L2-hot by now)
+    f32x4 wr[16];
+    if (p.want_grads && tid < h1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wr[i] = *(const f32x4*)(p.w2 + (size_t)tid * 64 + i * 4);
+    }
+    if (tid < TINY_RG * 64) {
+        const int r = tid >> 6, c = tid & 63, row = r0 + r;
+        const float v = z2s[tid] + bias;
+        z2s[tid] = v;
+        if (row < n) p.z2[(size_t)row * 64 + c] = v;
+    }
+    __syncthreads();
+    const float scale = p.grad_scale > 0.f ? p.grad_scale : 1.f / cnts[0];
+    if (tid < TINY_RG * 16) {
+        // layer 3 of row r: 16 lanes x 4 channels, xor-reduced; then the row's loss on lane 0
+        const int r = tid >> 4, l = tid & 15, row = r0 + r;
+        float z[2] = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = l * 4 + i;
+            const float v = fmaxf(z2s[r * 64 + c], 0.f);
+            z[0] = fmaf(v, w3s[c * od + 0], z[0]);
+            if (od == 2) z[1] = fmaf(v, w3s[c * od + 1], z[1]);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            z[0] += __shfl_xor(z[0], o, 64);
+            z[1] += __shfl_xor(z[1], o, 64);
+        }
+        if (l == 0) {
+            float li = 0.f, ai = 0.f, d3[2] = {0.f, 0.f};
+            if (row < n) {
+                const float w = sws[r];
+                const float* b3s = w3s + 64 * od;
+                if (od == 1) {
+                    // Dense(1, sigmoid) + binary_crossentropy over one output (code/siamese3.py:25-28)
+                    const float zz = z[0] + b3s[0];
+                    const float pr = 1.f / (1.f + expf(-zz));
+                    p.probs[row] = pr;
+                    const float y = ys[r];
+                    const float pc = fminf(fmaxf(pr, 1e-7f), 1.f - 1e-7f);
+                    const float x = logf(pc / (1.f - pc));
+                    li = (fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)))) * w;
+                    ai = (rintf(pr) == y) ? 1.f : 0.f;
+                    const bool inside = pr >= 1e-7f && pr <= 1.f - 1e-7f;
+                    const float dp = inside ? w * scale * (pc - y) / (pc * (1.f - pc)) : 0.f;
+                    d3[0] = dp * pr * (1.f - pr);
+                } else {
+                    const float z0 = z[0] + b3s[0], z1v = z[1] + b3s[1];
+                    const float m = fmaxf(z0, z1v);
+                    const float e0 = expf(z0 - m), e1 = expf(z1v - m);
+                    const float pr[2] = {e0 / (e0 + e1), e1 / (e0 + e1)};
+                    p.probs[row * 2 + 0] = pr[0];
+                    p.probs[row * 2 + 1] = pr[1];
+                    float lsum = 0.f, acc = 0.f, dp[2];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const float y = ys[r * 2 + c];
+                        const float pc = fminf(fmaxf(pr[c], 1e-7f), 1.f - 1e-7f);
+                        const float x = logf(pc / (1.f - pc));
+                        lsum += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+                        acc += (rintf(pr[c]) == y) ? 1.f : 0.f;
+                        const bool inside = pr[c] >= 1e-7f && pr[c] <= 1.f - 1e-7f;
+                        dp[c] = inside ? 0.5f * w * scale * (pc - y) / (pc * (1.f - pc)) : 0.f;
+                    }
+                    li = 0.5f * lsum * w;
+                    ai = 0.5f * acc;
+                    const float dot = dp[0] * pr[0] + dp[1] * pr[1];
+                    d3[0] = pr[0] * (dp[0] - dot);
+                    d3[1] = pr[1] * (dp[1] - dot);
+                }
+                if (p.want_grads) {
+                    p.dz3[row * od + 0] = d3[0];
+                    if (od == 2) p.dz3[row * od + 1] = d3[1];
+                }
+            }
+            dz3s[r * 2 + 0] = d3[0];
+            dz3s[r * 2 + 1] = d3[1];
+            rowm[r * 2 + 0] = li;
+            rowm[r * 2 + 1] = ai;
+        }
+    }
+    __syncthreads();
+    float* part = p.part + (size_t)blockIdx.x * TINY_PART;
+    if (tid == 0) {
+        float ls = 0.f, as = 0.f;
+#pragma unroll
+        for (int r = 0; r < TINY_RG; ++r) { ls += rowm[r * 2]; as += rowm[r * 2 + 1]; }
+        part[0] = ls;
+        part[1] = as;
+        part[132] = cnts[0];
+    }
+    if (!p.want_grads) return;
+    float* dz2s = red;                             // [TINY_RG][64], the reduction scratch is free again
+    if (tid < TINY_RG * 64) {
+        // dZ2[row][c] = (z2 > 0) * sum_j dz3[row][j] * w3[c][j]
+        const int r = tid >> 6, c = tid & 63, row = r0 + r;
+        float g = dz3s[r * 2] * w3s[c * od];
+        if (od == 2) g = fmaf(dz3s[r * 2 + 1], w3s[c * od + 1], g);
+        g = z2s[tid] > 0.f ? g : 0.f;
+        dz2s[tid] = g;
+        if (row < n) p.dz2[(size_t)row * 64 + c] = g;
+    } else if (tid < TINY_RG * 64 + 64 * od + od) {
+        // this row group's share of dW3[c][j] = sum_r relu(z2[r][c]) dz3[r][j] and db3[j] (rows >= n carry dz3 = 0)
+        const int t = tid - TINY_RG * 64;
+        float s = 0.f;
+        if (t < 64 * od) {
+            const int c = t / od, j = t - c * od;
+#pragma unroll
+            for (int r = 0; r < TINY_RG; ++r) s = fmaf(fmaxf(z2s[r * 64 + c], 0.f), dz3s[r * 2 + j], s);
+        } else {
+            const int j = t - 64 * od;
+#pragma unroll
+            for (int r = 0; r < TINY_RG; ++r) s += dz3s[r * 2 + j];
+        }
+        part[2 + t] = s;
+    }
+    __syncthreads();
+    // dZ1[row][k] = (z1 > 0) * sum_j dZ2[row][j] W2[k][j]: one W2 row (16 x 16 B, all in flight) per thread
+    for (int k = tid; k < h1; k += 512) {
+        if (k >= 512) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wr[i] = *(const f32x4*)(p.w2 + (size_t)k * 64 + i * 4);
+        }
+#pragma unroll
+        for (int r = 0; r < TINY_RG; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const f32x4 dv = *(const f32x4*)(dz2s + r * 64 + i * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s = fmaf(dv[j], wr[i][j], s);
+            }
+            if (r0 + r < n) p.dz1[(size_t)(r0 + r) * h1 + k] = a_s[r * h1 + k] > 0.f ? s : 0.f;
+        }
+    }
+}
+
+struct TinyBwd {
+    const float *z1, *dz1, *dz2, *dm, *part, *sw;
+    float *prm, *g, *a, *d, *metrics;
+    size_t oW1, ob1, oW2, ob2, oW3, ob3;
+    int n, D, h1, od, apply, ngroups;
+    float lr, rho, eps, grad_scale;
+};
+
+__device__ __forceinline__ float tiny_adadelta(float p, float g, float& a, float& d, float lr, float rho, float eps) {
+    const float na = rho * a + (1.f - rho) * g * g;
+    const float u = g * sqrtf(d + eps) / sqrtf(na + eps);
+    d = rho * d + (1.f - rho) * u * u;
+    a = na;
+    return p - lr * u;
+}
+// gradient of one parameter: store it, and (apply) update parameter and accumulators in place
+__device__ __forceinline__ void tiny_param(const TinyBwd& p, size_t i, float g) {
+    p.g[i] = g;
+    if (p.apply) {
+        float a = p.a[i], d = p.d[i];
+        p.prm[i] = tiny_adadelta(p.prm[i], g, a, d, p.lr, p.rho, p.eps);
+        p.a[i] = a;
+        p.d[i] = d;
+    }
+}
+
+// grid (h1 / 64, D / TINY_KB), 256 threads.  h2 == 64, n <= TINY_N.
+__global__ __launch_bounds__(256) void tiny_wgrad_update_kernel(const TinyBwd p) {
+    __shared__ __attribute__((aligned(16))) float dz1s[TINY_N * 64];
+    __shared__ __attribute__((aligned(16))) float dms[TINY_N * TINY_KB];
+    __shared__ __attribute__((aligned(16))) float dz2s[TINY_N * 64];   // k-part 0 only
+    __shared__ __attribute__((aligned(16))) float z1s[TINY_N * 64];    // k-part 0 only
+    const int tid = threadIdx.x, n = p.n, D = p.D, h1 = p.h1;
+    const int c0 = blockIdx.x * 64, kb = blockIdx.y * TINY_KB;
+    const bool lead = blockIdx.y == 0;
+    const int cl = tid & 15, kk = tid >> 4;       // dW1 mapping: 4 columns x 2 k rows per thread
+
+    // ---- every global read of the tile, issued together ---------------------------------------------------
+    f32x4 pw[2], pa[2], pd[2];                     // W1 / accumulators of this thread's dW1 outputs
+    if (p.apply) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const size_t i = p.oW1 + (size_t)(kb + kk * 2 + q) * h1 + c0 + cl * 4;
+            pw[q] = *(const f32x4*)(p.prm + i);
+            pa[q] = *(const f32x4*)(p.a + i);
+            pd[q] = *(const f32x4*)(p.d + i);
+        }
+    }
+    f32x4 w2w[4], w2a[4], w2d[4];                  // k-part 0: W2 rows c0 + 4 kk .. + 3, columns 4 cl .. + 3
+    float b1w = 0.f, b1a = 0.f, b1d = 0.f;         // k-part 0, tid < 64: b1[c0 + tid]
+    float sw_ = 0.f, sa_ = 0.f, sd_ = 0.f;         // block (0,0): b2 (tid < 64) and W3 / b3 (64 <= tid < 64 + 64 od + od)
+    if (lead && p.apply) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t i = p.oW2 + (size_t)(c0 + kk * 4 + q) * 64 + cl * 4;
+            w2w[q] = *(const f32x4*)(p.prm + i);
+            w2a[q] = *(const f32x4*)(p.a + i);
+            w2d[q] = *(const f32x4*)(p.d + i);
+        }
+        if (tid < 64) { b1w = p.prm[p.ob1 + c0 + tid]; b1a = p.a[p.ob1 + c0 + tid]; b1d = p.d[p.ob1 + c0 + tid]; }
+        if (blockIdx.x == 0 && tid < 64 + 64 * p.od + p.od) {
+            const size_t i = tid < 64 ? p.ob2 + tid : p.oW3 + (tid - 64);
+            sw_ = p.prm[i]; sa_ = p.a[i]; sd_ = p.d[i];
+        }
+    }
+    float partv[TINY_N / TINY_RG];                 // block (0,0): this thread's partial of every row group
+    float cnt = 1.f;
+    if (lead && blockIdx.x == 0) {
+        if (tid == 0) cnt = p.part[132];
+#pragma unroll
+        for (int gI = 0; gI < TINY_N / TINY_RG; ++gI) {
+            const int t = tid >= 64 ? tid - 64 + 2 : (tid < 2 ? tid : -1);
+            partv[gI] = (gI < p.ngroups && t >= 0 && t < TINY_PART) ? p.part[(size_t)gI * TINY_PART + t] : 0.f;
+        }
+    }
+    for (int i = tid; i < n * 16; i += 256) {      // rows of 64 floats as 16 x 16 B
+        const int r = i >> 4, j = (i & 15) * 4;
+        *(f32x4*)(dz1s + r * 64 + j) = *(const f32x4*)(p.dz1 + (size_t)r * h1 + c0 + j);
+        if (lead) {
+            *(f32x4*)(dz2s + r * 64 + j) = *(const f32x4*)(p.dz2 + (size_t)r * 64 + j);
+            *(f32x4*)(z1s + r * 64 + j) = *(const f32x4*)(p.z1 + (size_t)r * h1 + c0 + j);
+        }
+    }
+    for (int i = tid; i < n * (TINY_KB / 4); i += 256) {
+        const int r = i / (TINY_KB / 4), j = (i % (TINY_KB / 4)) * 4;
+        *(f32x4*)(dms + r * TINY_KB + j) = *(const f32x4*)(p.dm + (size_t)r * D + kb + j);
+    }
+    __syncthreads();
+
+    // ---- dW1[kb + 2 kk + q][c0 + 4 cl + j] = sum_r dm[r][k] dZ1[r][c], Adadelta in place -------------------------
+    {
+        float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int r = 0; r < n; ++r) {
+            const f32x4 dv = *(const f32x4*)(dz1s + r * 64 + cl * 4);
+            const float m0 = dms[r * TINY_KB + kk * 2], m1 = dms[r * TINY_KB + kk * 2 + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][j] = fmaf(m0, dv[j], acc[0][j]);
+                acc[1][j] = fmaf(m1, dv[j], acc[1][j]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const size_t i = p.oW1 + (size_t)(kb + kk * 2 + q) * h1 + c0 + cl * 4;
+            f32x4 gq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gq[j] = acc[q][j];
+            *(f32x4*)(p.g + i) = gq;
+            if (p.apply) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = pa[q][j], d = pd[q][j];
+                    pw[q][j] = tiny_adadelta(pw[q][j], gq[j], a, d, p.lr, p.rho, p.eps);
+                    pa[q][j] = a;
+                    pd[q][j] = d;
+                }
+                *(f32x4*)(p.prm + i) = pw[q];
+                *(f32x4*)(p.a + i) = pa[q];
+                *(f32x4*)(p.d + i) = pd[q];
+            }
+        }
+    }
+    if (!lead) return;
+
+    // ---- k-part 0 of the column block: db1, and dW2 rows c0 .. c0 + 63 (k index of W2 = column of layer 1) ------
+    if (tid < 64) {
+        float s = 0.f;
+        for (int r = 0; r < n; ++r) s += dz1s[r * 64 + tid];
+        p.g[p.ob1 + c0 + tid] = s;
+        if (p.apply) {
+            p.prm[p.ob1 + c0 + tid] = tiny_adadelta(b1w, s, b1a, b1d, p.lr, p.rho, p.eps);
+            p.a[p.ob1 + c0 + tid] = b1a;
+            p.d[p.ob1 + c0 + tid] = b1d;
+        }
+    }
+    {
+        float acc[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[q][j] = 0.f;
+        for (int r = 0; r < n; ++r) {
+            const f32x4 dv = *(const f32x4*)(dz2s + r * 64 + cl * 4);
+            const f32x4 zv = *(const f32x4*)(z1s + r * 64 + kk * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float a = fmaxf(zv[q], 0.f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[q][j] = fmaf(a, dv[j], acc[q][j]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t i = p.oW2 + (size_t)(c0 + kk * 4 + q) * 64 + cl * 4;
+            f32x4 gq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gq[j] = acc[q][j];
+            *(f32x4*)(p.g + i) = gq;
+            if (p.apply) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = w2a[q][j], d = w2d[q][j];
+                    w2w[q][j] = tiny_adadelta(w2w[q][j], gq[j], a, d, p.lr, p.rho, p.eps);
+                    w2a[q][j] = a;
+                    w2d[q][j] = d;
+                }
+                *(f32x4*)(p.prm + i) = w2w[q];
+                *(f32x4*)(p.a + i) = w2a[q];
+                *(f32x4*)(p.d + i) = w2d[q];
+            }
+        }
+    }
+    if (blockIdx.x != 0) return;
+
+    // ---- block (0, 0): db2 (threads 0..63), dW3 / db3 (threads 64..) and the metrics (thread 0) from the row
+    // groups' partials, summed in a fixed order ---------------------------------------------------------------------
+    const int od = p.od;
+    float ls = 0.f, as = 0.f;                      // thread 0 / 1: loss and accuracy sums
+    if (tid < 2) {
+#pragma unroll
+        for (int gI = 0; gI < TINY_N / TINY_RG; ++gI) ls += partv[gI];
+    }
+    __shared__ float acc_sum;
+    if (tid == 1) acc_sum = ls;
+    if (tid < 64 + 64 * od + od) {
+        float s = 0.f;
+        size_t i;
+        if (tid < 64) {
+            for (int r = 0; r < n; ++r) s += dz2s[r * 64 + tid];
+            i = p.ob2 + tid;
+        } else {
+#pragma unroll
+            for (int gI = 0; gI < TINY_N / TINY_RG; ++gI) s += partv[gI];
+            i = p.oW3 + (tid - 64);                // oW3 .. ob3 + od - 1 are contiguous
+        }
+        p.g[i] = s;
+        if (p.apply) {
+            p.prm[i] = tiny_adadelta(sw_, s, sa_, sd_, p.lr, p.rho, p.eps);
+            p.a[i] = sa_;
+            p.d[i] = sd_;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        as = acc_sum;
+        p.metrics[0] = ls * (p.grad_scale > 0.f ? p.grad_scale : 1.f / cnt);
+        p.metrics[1] = as / (float)n;
+    }
+}
+
+size_t tiny_lds_bytes(int K) { return (size_t)(TINY_RG * K + 8 * TINY_RG * 64 + TINY_RG * 64 + 192) * sizeof(float); }
+
+bool tiny_ok(const alink_head* h, int n) {
+    return g_use_tiny && n <= TINY_N && h->h2 == 64 && h->h1 % 512 == 0 && h->D % 512 == 0 && h->D <= 2048 &&
+           h->h1 <= 2048 && h->oW1 == 0;
+}
+
+// the three launches; gradients are always left in d_grads, parameters updated when `apply`
+int tiny_train(alink_head* h, const float* L, const float* R, const float* y, const float* sw, int n,
+               float grad_scale, bool apply, float* metrics, hipStream_t st) {
+    const int D = h->D, h1 = h->h1;
+    float* P = h->d_params;
+    const int ngroups = (n + TINY_RG - 1) / TINY_RG;
+    hipLaunchKernelGGL(tiny_dense1_kernel, dim3(h1 / 64, ngroups), dim3(512), tiny_lds_bytes(D), st, L, R, P + h->oW1,
+                       P + h->ob1, h->d_z1, h->d_dm, n, D, h1);
+    TinyLoss lp{};
+    lp.z1 = h->d_z1; lp.w2 = P + h->oW2; lp.b2 = P + h->ob2; lp.w3 = P + h->oW3; lp.b3 = P + h->ob3; lp.y = y;
+    lp.sw = sw; lp.z2 = h->d_z2; lp.probs = h->d_p; lp.dz2 = h->d_dz2; lp.dz3 = h->d_dz3; lp.dz1 = h->d_dz1;
+    lp.part = h->d_tiny; lp.n = n; lp.h1 = h1; lp.od = h->od; lp.want_grads = 1; lp.grad_scale = grad_scale;
+    hipLaunchKernelGGL(tiny_dense2_loss_kernel, dim3(ngroups), dim3(512), tiny_lds_bytes(h1), st, lp);
+    TinyBwd bp{};
+    bp.z1 = h->d_z1; bp.dz1 = h->d_dz1; bp.dz2 = h->d_dz2; bp.dm = h->d_dm; bp.part = h->d_tiny; bp.sw = sw;
+    bp.prm = P; bp.g = h->d_grads; bp.a = h->d_acc; bp.d = h->d_dacc; bp.metrics = metrics;
+    bp.oW1 = h->oW1; bp.ob1 = h->ob1; bp.oW2 = h->oW2; bp.ob2 = h->ob2; bp.oW3 = h->oW3; bp.ob3 = h->ob3;
+    bp.n = n; bp.D = D; bp.h1 = h1; bp.od = h->od; bp.apply = apply ? 1 : 0; bp.ngroups = ngroups;
+    bp.lr = h->lr; bp.rho = h->rho; bp.eps = h->eps; bp.grad_scale = grad_scale;
+    hipLaunchKernelGGL(tiny_wgrad_update_kernel, dim3(h1 / 64, D / TINY_KB), dim3(256), 0, st, bp);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
 // forward (+ optional backward) on a small batch with the VALU kernels
 // The step is a chain of dependent small kernels (each ~7 us of pure latency at batch 16), so the chain
 // is kept short: |l - r| inside the first Dense, the two independent middle gradients in one launch,
@@ -690,6 +1239,7 @@ alink_head_t* alink_head_create_ex(int d_in, int h1, int h2, int out_dim, float 
     rc |= head_alloc(h, &h->d_dz2, (size_t)h->cap * h2);
     rc |= head_alloc(h, &h->d_dz3, (size_t)h->cap * 2);
     rc |= head_alloc(h, &h->d_p, (size_t)h->cap * 2);
+    rc |= head_alloc(h, &h->d_tiny, (size_t)(TINY_N / TINY_RG) * TINY_PART);
     if (rc) { delete h; return nullptr; }
     return h;
 }
@@ -770,11 +1320,14 @@ int alink_pair_scores_matrix(alink_head_t* const* heads, int n_heads, const floa
 static int train_step_launches(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
                                const float* dev_sw, int n, float grad_scale, int apply, float* dev_metrics,
                                hipStream_t st) {
-    int rc = small_pass(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, true, dev_metrics, st, apply != 0);
+    int rc = tiny_ok(h, n) ? tiny_train(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, apply != 0, dev_metrics, st)
+                           : small_pass(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, true, dev_metrics, st, apply != 0);
     if (rc) return rc;
     if (apply) h->packed_dirty = true;
     return ALINK_OK;
 }
+
+void alink_debug_set_tiny_step(int on) { g_use_tiny = on != 0; }
 
 int alink_head_set_graph(alink_head_t* h, int on) {
     ALINK_REQUIRE(h, ALINK_EINVAL, "NULL head");

@@ -222,3 +222,49 @@ def test_head_error_paths(gpu):
     with pytest.raises(gpu.AlinkError):      # train batches are capped (scratch sized for 4096 rows)
         h.train_on_batch([L, L], np.zeros((5000, 2), np.float32))
     assert h.predict([L[:0], L[:0]]).shape == (0, 2)
+
+
+@pytest.mark.parametrize("d,out_dim", [(512, 2), (2048, 2), (512, 1)])
+def test_tiny_batch_step_equals_generic_chain(gpu, d, out_dim):
+    """Batches of <= 32 rows take the three-launch train step (head.hip, tiny_*); it must leave the
+    same metrics, gradients, parameters and Adadelta state as the generic chain — zero sample weights,
+    ragged row groups (n % 4 != 0), gradient-only mode and the 32 / 33 boundary included."""
+    from a_link_amd.head import DenseHead
+    rng = np.random.RandomState(5)
+    a = DenseHead(d, lr=0.1, seed=3, out_dim=out_dim)
+    b = DenseHead(d, lr=0.1, seed=3, out_dim=out_dim)
+    ws = a.get_weights()
+    for i in (1, 3, 5):
+        ws[i] = (rng.randn(*ws[i].shape) * 0.1).astype(np.float32)
+    a.set_weights(ws)
+    b.set_weights(ws)
+    for step, n in enumerate([16, 5, 32, 1, 33, 16]):
+        L, R = _data(n, d, 300 + step)
+        lab = rng.randint(0, 2, n)
+        y = np.eye(2, dtype=np.float32)[lab] if out_dim == 2 else lab.reshape(n, 1).astype(np.float32)
+        sw = None
+        if step % 2 == 1:
+            sw = rng.rand(n).astype(np.float32)
+            sw[::3] = 0.0
+            if not sw.any():
+                sw[0] = 1.0
+        a.lib.alink_debug_set_tiny_step(1)
+        ma = a.train_on_batch([L, R], y, sample_weight=sw)
+        a.lib.alink_debug_set_tiny_step(0)
+        mb = b.train_on_batch([L, R], y, sample_weight=sw)
+        a.lib.alink_debug_set_tiny_step(1)
+        np.testing.assert_allclose(ma, mb, rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(a.grads_tensor().cpu().numpy(), b.grads_tensor().cpu().numpy(), rtol=1e-5, atol=1e-8)
+        for x, z in zip(a.get_weights(), b.get_weights()):
+            np.testing.assert_allclose(x, z, rtol=0, atol=2e-6)
+    # gradient-only mode (the data-parallel step) and the input gradient that follows it
+    L, R = _data(12, d, 999)
+    lab = rng.randint(0, 2, 12)
+    y = np.eye(2, dtype=np.float32)[lab] if out_dim == 2 else lab.reshape(12, 1).astype(np.float32)
+    ga = [t.cpu().numpy() for t in a.input_gradients(L, R, y)]
+    a.lib.alink_debug_set_tiny_step(0)
+    gb = [t.cpu().numpy() for t in b.input_gradients(L, R, y)]
+    a.lib.alink_debug_set_tiny_step(1)
+    for x, z in zip(ga, gb):
+        np.testing.assert_allclose(x, z, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(a.grads_tensor().cpu().numpy(), b.grads_tensor().cpu().numpy(), rtol=1e-5, atol=1e-8)

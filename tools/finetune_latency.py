@@ -2,7 +2,7 @@
 """Latency of one 16-pair fine-tune step (code/siamese.py:104 train_on_batch): plain launches vs hipGraph
 replay, through DenseHead.train_on_batch and through the raw C-ABI call."""
 import sys, os, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import a_link_amd
 from a_link_amd.head import DenseHead
