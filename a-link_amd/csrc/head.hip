@@ -778,11 +778,12 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
     }
     __syncthreads();
     tiny_dense_core(a_s, h1, wp, 64, wv, red, z2s);
-    // one W2 row per thread for dZ1 below: in flight while the loss is computed (L1/L2-hot by now)
-    f32x4 wr[16];
-    if (p.want_grads && tid < h1) {
+    // dZ1 below walks W2 in chunks of 128 rows staged through LDS (coalesced 16-B loads here, padded rows
+    // read back per thread): the first chunk is fetched now, under the loss computation
+    f32x4 wc[4];
+    if (p.want_grads) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) wr[i] = *(const f32x4*)(p.w2 + (size_t)tid * 64 + i * 4);
+        for (int i = 0; i < 4; ++i) wc[i] = *(const f32x4*)(p.w2 + (size_t)(tid + 512 * i) * 4);
     }
     if (tid < TINY_RG * 64) {
         const int r = tid >> 6, c = tid & 63, row = r0 + r;
@@ -897,23 +898,31 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
         part[2 + t] = s;
     }
     __syncthreads();
-    // dZ1[row][k] = (z1 > 0) * sum_j dZ2[row][j] W2[k][j]: one W2 row (16 x 16 B, all in flight) per thread
-    for (int k = tid; k < h1; k += 512) {
-        if (k >= 512) {
+    // dZ1[row][k] = (z1 > 0) * sum_j dZ2[row][j] W2[k][j].  Chunk of 128 W2 rows in LDS with a row pitch of
+    // 68 floats (16-B reads of 16 consecutive rows then fall on distinct banks); thread = (k, row).
+    float* w2s = a_s + TINY_RG * h1 + 8 * TINY_RG * 64 + TINY_RG * 64 + 192;     // [128][68], after everything else
+    const int kq = tid & 127, rq = tid >> 7;
+    for (int kc = 0; kc < h1; kc += 128) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) wr[i] = *(const f32x4*)(p.w2 + (size_t)k * 64 + i * 4);
+        for (int i = 0; i < 4; ++i) {
+            const int e = (tid + 512 * i) * 4;                                    // element of the 128 x 64 chunk
+            *(f32x4*)(w2s + (e >> 6) * 68 + (e & 63)) = wc[i];
         }
+        __syncthreads();
+        if (kc + 128 < h1) {
 #pragma unroll
-        for (int r = 0; r < TINY_RG; ++r) {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const f32x4 dv = *(const f32x4*)(dz2s + r * 64 + i * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s = fmaf(dv[j], wr[i][j], s);
-            }
-            if (r0 + r < n) p.dz1[(size_t)(r0 + r) * h1 + k] = a_s[r * h1 + k] > 0.f ? s : 0.f;
+            for (int i = 0; i < 4; ++i) wc[i] = *(const f32x4*)(p.w2 + (size_t)(kc + 128) * 64 + (size_t)(tid + 512 * i) * 4);
         }
+        float sdot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const f32x4 wv4 = *(const f32x4*)(w2s + kq * 68 + i * 4);
+            const f32x4 dv = *(const f32x4*)(dz2s + rq * 64 + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sdot = fmaf(dv[j], wv4[j], sdot);
+        }
+        if (r0 + rq < n) p.dz1[(size_t)(r0 + rq) * h1 + kc + kq] = a_s[rq * h1 + kc + kq] > 0.f ? sdot : 0.f;
+        __syncthreads();
     }
 }
 
@@ -932,83 +941,60 @@ __device__ __forceinline__ float tiny_adadelta(float p, float g, float& a, float
     a = na;
     return p - lr * u;
 }
-// gradient of one parameter: store it, and (apply) update parameter and accumulators in place
-__device__ __forceinline__ void tiny_param(const TinyBwd& p, size_t i, float g) {
-    p.g[i] = g;
+// Adadelta on 4 consecutive parameters whose old values were loaded up front
+__device__ __forceinline__ void tiny_update4(const TinyBwd& p, size_t i, const f32x4& g, f32x4 w, f32x4 a, f32x4 d) {
+    *(f32x4*)(p.g + i) = g;
     if (p.apply) {
-        float a = p.a[i], d = p.d[i];
-        p.prm[i] = tiny_adadelta(p.prm[i], g, a, d, p.lr, p.rho, p.eps);
-        p.a[i] = a;
-        p.d[i] = d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float aj = a[j], dj = d[j];
+            w[j] = tiny_adadelta(w[j], g[j], aj, dj, p.lr, p.rho, p.eps);
+            a[j] = aj;
+            d[j] = dj;
+        }
+        *(f32x4*)(p.prm + i) = w;
+        *(f32x4*)(p.a + i) = a;
+        *(f32x4*)(p.d + i) = d;
     }
 }
 
-// grid (h1 / 64, D / TINY_KB), 256 threads.  h2 == 64, n <= TINY_N.
+// grid (h1 / 64, D / TINY_KB + 2), 256 threads; h2 == 64, n <= TINY_N.  Roles by blockIdx.y:
+//   y <  D / TINY_KB : dW1 tile (64 columns x TINY_KB k rows) + update
+//   y == D / TINY_KB : db1 and dW2 rows of column block x + update (k index of W2 = column of layer 1)
+//   y == last, x == 0: db2, dW3, db3 + update, and the metrics, from the row groups' partials
+// so every block's chain is load -> one short reduction -> store, and they all run side by side.
 __global__ __launch_bounds__(256) void tiny_wgrad_update_kernel(const TinyBwd p) {
-    __shared__ __attribute__((aligned(16))) float dz1s[TINY_N * 64];
-    __shared__ __attribute__((aligned(16))) float dms[TINY_N * TINY_KB];
-    __shared__ __attribute__((aligned(16))) float dz2s[TINY_N * 64];   // k-part 0 only
-    __shared__ __attribute__((aligned(16))) float z1s[TINY_N * 64];    // k-part 0 only
+    __shared__ __attribute__((aligned(16))) float sa[TINY_N * 64];
+    __shared__ __attribute__((aligned(16))) float sb[TINY_N * 64];
+    __shared__ float acc_sum;
     const int tid = threadIdx.x, n = p.n, D = p.D, h1 = p.h1;
-    const int c0 = blockIdx.x * 64, kb = blockIdx.y * TINY_KB;
-    const bool lead = blockIdx.y == 0;
-    const int cl = tid & 15, kk = tid >> 4;       // dW1 mapping: 4 columns x 2 k rows per thread
-
-    // ---- every global read of the tile, issued together ---------------------------------------------------
-    f32x4 pw[2], pa[2], pd[2];                     // W1 / accumulators of this thread's dW1 outputs
-    if (p.apply) {
+    const int c0 = blockIdx.x * 64, nkp = D / TINY_KB;
+    const int cl = tid & 15, kk = tid >> 4;
+    if ((int)blockIdx.y < nkp) {
+        // ---- dW1[kb + 2 kk + q][c0 + 4 cl + j] = sum_r dm[r][k] dZ1[r][c] -----------------------------------------
+        const int kb = blockIdx.y * TINY_KB;
+        float* dz1s = sa;                          // [n][64]
+        float* dms = sb;                           // [n][TINY_KB]
+        f32x4 pw[2], pa[2], pd[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const size_t i = p.oW1 + (size_t)(kb + kk * 2 + q) * h1 + c0 + cl * 4;
-            pw[q] = *(const f32x4*)(p.prm + i);
-            pa[q] = *(const f32x4*)(p.a + i);
-            pd[q] = *(const f32x4*)(p.d + i);
+            if (p.apply) {
+                pw[q] = *(const f32x4*)(p.prm + i);
+                pa[q] = *(const f32x4*)(p.a + i);
+                pd[q] = *(const f32x4*)(p.d + i);
+            }
         }
-    }
-    f32x4 w2w[4], w2a[4], w2d[4];                  // k-part 0: W2 rows c0 + 4 kk .. + 3, columns 4 cl .. + 3
-    float b1w = 0.f, b1a = 0.f, b1d = 0.f;         // k-part 0, tid < 64: b1[c0 + tid]
-    float sw_ = 0.f, sa_ = 0.f, sd_ = 0.f;         // block (0,0): b2 (tid < 64) and W3 / b3 (64 <= tid < 64 + 64 od + od)
-    if (lead && p.apply) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const size_t i = p.oW2 + (size_t)(c0 + kk * 4 + q) * 64 + cl * 4;
-            w2w[q] = *(const f32x4*)(p.prm + i);
-            w2a[q] = *(const f32x4*)(p.a + i);
-            w2d[q] = *(const f32x4*)(p.d + i);
+        for (int i = tid; i < n * 16; i += 256) {
+            const int r = i >> 4, j = (i & 15) * 4;
+            *(f32x4*)(dz1s + r * 64 + j) = *(const f32x4*)(p.dz1 + (size_t)r * h1 + c0 + j);
         }
-        if (tid < 64) { b1w = p.prm[p.ob1 + c0 + tid]; b1a = p.a[p.ob1 + c0 + tid]; b1d = p.d[p.ob1 + c0 + tid]; }
-        if (blockIdx.x == 0 && tid < 64 + 64 * p.od + p.od) {
-            const size_t i = tid < 64 ? p.ob2 + tid : p.oW3 + (tid - 64);
-            sw_ = p.prm[i]; sa_ = p.a[i]; sd_ = p.d[i];
+        for (int i = tid; i < n * (TINY_KB / 4); i += 256) {
+            const int r = i / (TINY_KB / 4), j = (i % (TINY_KB / 4)) * 4;
+            *(f32x4*)(dms + r * TINY_KB + j) = *(const f32x4*)(p.dm + (size_t)r * D + kb + j);
         }
-    }
-    float partv[TINY_N / TINY_RG];                 // block (0,0): this thread's partial of every row group
-    float cnt = 1.f;
-    if (lead && blockIdx.x == 0) {
-        if (tid == 0) cnt = p.part[132];
-#pragma unroll
-        for (int gI = 0; gI < TINY_N / TINY_RG; ++gI) {
-            const int t = tid >= 64 ? tid - 64 + 2 : (tid < 2 ? tid : -1);
-            partv[gI] = (gI < p.ngroups && t >= 0 && t < TINY_PART) ? p.part[(size_t)gI * TINY_PART + t] : 0.f;
-        }
-    }
-    for (int i = tid; i < n * 16; i += 256) {      // rows of 64 floats as 16 x 16 B
-        const int r = i >> 4, j = (i & 15) * 4;
-        *(f32x4*)(dz1s + r * 64 + j) = *(const f32x4*)(p.dz1 + (size_t)r * h1 + c0 + j);
-        if (lead) {
-            *(f32x4*)(dz2s + r * 64 + j) = *(const f32x4*)(p.dz2 + (size_t)r * 64 + j);
-            *(f32x4*)(z1s + r * 64 + j) = *(const f32x4*)(p.z1 + (size_t)r * h1 + c0 + j);
-        }
-    }
-    for (int i = tid; i < n * (TINY_KB / 4); i += 256) {
-        const int r = i / (TINY_KB / 4), j = (i % (TINY_KB / 4)) * 4;
-        *(f32x4*)(dms + r * TINY_KB + j) = *(const f32x4*)(p.dm + (size_t)r * D + kb + j);
-    }
-    __syncthreads();
-
-    // ---- dW1[kb + 2 kk + q][c0 + 4 cl + j] = sum_r dm[r][k] dZ1[r][c], Adadelta in place -------------------------
-    {
-        float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        __syncthreads();
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         for (int r = 0; r < n; ++r) {
             const f32x4 dv = *(const f32x4*)(dz1s + r * 64 + cl * 4);
             const float m0 = dms[r * TINY_KB + kk * 2], m1 = dms[r * TINY_KB + kk * 2 + 1];
@@ -1019,45 +1005,51 @@ __global__ __launch_bounds__(256) void tiny_wgrad_update_kernel(const TinyBwd p)
             }
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const size_t i = p.oW1 + (size_t)(kb + kk * 2 + q) * h1 + c0 + cl * 4;
-            f32x4 gq;
+        for (int q = 0; q < 2; ++q)
+            tiny_update4(p, p.oW1 + (size_t)(kb + kk * 2 + q) * h1 + c0 + cl * 4, acc[q], pw[q], pa[q], pd[q]);
+        return;
+    }
+    if ((int)blockIdx.y == nkp) {
+        // ---- db1[c0 ..] and dW2[c0 + 4 kk + q][4 cl + j] = sum_r relu(z1[r][c0 + 4 kk + q]) dZ2[r][4 cl + j] -----
+        float* dz2s = sa;                          // [n][64]
+        float* z1s = sb;                           // [n][64]
+        f32x4 w2w[4], w2a[4], w2d[4];
+        float b1w = 0.f, b1a = 0.f, b1d = 0.f;
+        if (p.apply) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gq[j] = acc[q][j];
-            *(f32x4*)(p.g + i) = gq;
+            for (int q = 0; q < 4; ++q) {
+                const size_t i = p.oW2 + (size_t)(c0 + kk * 4 + q) * 64 + cl * 4;
+                w2w[q] = *(const f32x4*)(p.prm + i);
+                w2a[q] = *(const f32x4*)(p.a + i);
+                w2d[q] = *(const f32x4*)(p.d + i);
+            }
+            if (tid < 64) { b1w = p.prm[p.ob1 + c0 + tid]; b1a = p.a[p.ob1 + c0 + tid]; b1d = p.d[p.ob1 + c0 + tid]; }
+        }
+        float gb1 = 0.f;                            // db1 straight from global: column c0 + tid of dZ1
+        if (tid < 64) {
+            float v[TINY_N];
+#pragma unroll
+            for (int r = 0; r < TINY_N; ++r) v[r] = r < n ? p.dz1[(size_t)r * h1 + c0 + tid] : 0.f;
+#pragma unroll
+            for (int r = 0; r < TINY_N; ++r) gb1 += v[r];
+        }
+        for (int i = tid; i < n * 16; i += 256) {
+            const int r = i >> 4, j = (i & 15) * 4;
+            *(f32x4*)(dz2s + r * 64 + j) = *(const f32x4*)(p.dz2 + (size_t)r * 64 + j);
+            *(f32x4*)(z1s + r * 64 + j) = *(const f32x4*)(p.z1 + (size_t)r * h1 + c0 + j);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            p.g[p.ob1 + c0 + tid] = gb1;
             if (p.apply) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float a = pa[q][j], d = pd[q][j];
-                    pw[q][j] = tiny_adadelta(pw[q][j], gq[j], a, d, p.lr, p.rho, p.eps);
-                    pa[q][j] = a;
-                    pd[q][j] = d;
-                }
-                *(f32x4*)(p.prm + i) = pw[q];
-                *(f32x4*)(p.a + i) = pa[q];
-                *(f32x4*)(p.d + i) = pd[q];
+                p.prm[p.ob1 + c0 + tid] = tiny_adadelta(b1w, gb1, b1a, b1d, p.lr, p.rho, p.eps);
+                p.a[p.ob1 + c0 + tid] = b1a;
+                p.d[p.ob1 + c0 + tid] = b1d;
             }
         }
-    }
-    if (!lead) return;
-
-    // ---- k-part 0 of the column block: db1, and dW2 rows c0 .. c0 + 63 (k index of W2 = column of layer 1) ------
-    if (tid < 64) {
-        float s = 0.f;
-        for (int r = 0; r < n; ++r) s += dz1s[r * 64 + tid];
-        p.g[p.ob1 + c0 + tid] = s;
-        if (p.apply) {
-            p.prm[p.ob1 + c0 + tid] = tiny_adadelta(b1w, s, b1a, b1d, p.lr, p.rho, p.eps);
-            p.a[p.ob1 + c0 + tid] = b1a;
-            p.d[p.ob1 + c0 + tid] = b1d;
-        }
-    }
-    {
-        float acc[4][4];
+        f32x4 acc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[q][j] = 0.f;
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < n; ++r) {
             const f32x4 dv = *(const f32x4*)(dz2s + r * 64 + cl * 4);
             const f32x4 zv = *(const f32x4*)(z1s + r * 64 + kk * 4);
@@ -1069,69 +1061,61 @@ __global__ __launch_bounds__(256) void tiny_wgrad_update_kernel(const TinyBwd p)
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const size_t i = p.oW2 + (size_t)(c0 + kk * 4 + q) * 64 + cl * 4;
-            f32x4 gq;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) gq[j] = acc[q][j];
-            *(f32x4*)(p.g + i) = gq;
-            if (p.apply) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float a = w2a[q][j], d = w2d[q][j];
-                    w2w[q][j] = tiny_adadelta(w2w[q][j], gq[j], a, d, p.lr, p.rho, p.eps);
-                    w2a[q][j] = a;
-                    w2d[q][j] = d;
-                }
-                *(f32x4*)(p.prm + i) = w2w[q];
-                *(f32x4*)(p.a + i) = w2a[q];
-                *(f32x4*)(p.d + i) = w2d[q];
-            }
-        }
+        for (int q = 0; q < 4; ++q)
+            tiny_update4(p, p.oW2 + (size_t)(c0 + kk * 4 + q) * 64 + cl * 4, acc[q], w2w[q], w2a[q], w2d[q]);
+        return;
     }
     if (blockIdx.x != 0) return;
-
-    // ---- block (0, 0): db2 (threads 0..63), dW3 / db3 (threads 64..) and the metrics (thread 0) from the row
-    // groups' partials, summed in a fixed order ---------------------------------------------------------------------
+    // ---- db2 (threads 0..63), dW3 / db3 (threads 64..) and the metrics (thread 0), fixed summation order -----------
     const int od = p.od;
-    float ls = 0.f, as = 0.f;                      // thread 0 / 1: loss and accuracy sums
-    if (tid < 2) {
+    const bool is_b2 = tid < 64, is_w3 = tid >= 64 && tid < 64 + 64 * od + od;
+    const size_t pi = is_b2 ? p.ob2 + tid : p.oW3 + (tid - 64);      // oW3 .. ob3 + od - 1 are contiguous
+    float w_ = 0.f, a_ = 0.f, d_ = 0.f;
+    if ((is_b2 || is_w3) && p.apply) { w_ = p.prm[pi]; a_ = p.a[pi]; d_ = p.d[pi]; }
+    float partv[TINY_N / TINY_RG], lossv[TINY_N / TINY_RG];
+    const float cnt = tid == 0 ? p.part[132] : 1.f;
 #pragma unroll
-        for (int gI = 0; gI < TINY_N / TINY_RG; ++gI) ls += partv[gI];
+    for (int gI = 0; gI < TINY_N / TINY_RG; ++gI) {
+        partv[gI] = (is_w3 && gI < p.ngroups) ? p.part[(size_t)gI * TINY_PART + 2 + (tid - 64)] : 0.f;
+        lossv[gI] = (tid < 2 && gI < p.ngroups) ? p.part[(size_t)gI * TINY_PART + tid] : 0.f;
     }
-    __shared__ float acc_sum;
-    if (tid == 1) acc_sum = ls;
-    if (tid < 64 + 64 * od + od) {
-        float s = 0.f;
-        size_t i;
-        if (tid < 64) {
-            for (int r = 0; r < n; ++r) s += dz2s[r * 64 + tid];
-            i = p.ob2 + tid;
-        } else {
+    float s = 0.f;
+    if (is_b2) {
+        float v[TINY_N];
 #pragma unroll
-            for (int gI = 0; gI < TINY_N / TINY_RG; ++gI) s += partv[gI];
-            i = p.oW3 + (tid - 64);                // oW3 .. ob3 + od - 1 are contiguous
-        }
-        p.g[i] = s;
+        for (int r = 0; r < TINY_N; ++r) v[r] = r < n ? p.dz2[(size_t)r * 64 + tid] : 0.f;
+#pragma unroll
+        for (int r = 0; r < TINY_N; ++r) s += v[r];
+    } else {
+#pragma unroll
+        for (int gI = 0; gI < TINY_N / TINY_RG; ++gI) s += partv[gI];
+    }
+    float ls = 0.f;
+#pragma unroll
+    for (int gI = 0; gI < TINY_N / TINY_RG; ++gI) ls += lossv[gI];
+    if (tid == 1) acc_sum = ls;
+    if (is_b2 || is_w3) {
+        p.g[pi] = s;
         if (p.apply) {
-            p.prm[i] = tiny_adadelta(sw_, s, sa_, sd_, p.lr, p.rho, p.eps);
-            p.a[i] = sa_;
-            p.d[i] = sd_;
+            p.prm[pi] = tiny_adadelta(w_, s, a_, d_, p.lr, p.rho, p.eps);
+            p.a[pi] = a_;
+            p.d[pi] = d_;
         }
     }
     __syncthreads();
     if (tid == 0) {
-        as = acc_sum;
         p.metrics[0] = ls * (p.grad_scale > 0.f ? p.grad_scale : 1.f / cnt);
-        p.metrics[1] = as / (float)n;
+        p.metrics[1] = acc_sum / (float)n;
     }
 }
 
-size_t tiny_lds_bytes(int K) { return (size_t)(TINY_RG * K + 8 * TINY_RG * 64 + TINY_RG * 64 + 192) * sizeof(float); }
+size_t tiny_lds_bytes(int K, bool with_w2 = false) {
+    return (size_t)(TINY_RG * K + 8 * TINY_RG * 64 + TINY_RG * 64 + 192 + (with_w2 ? 128 * 68 : 0)) * sizeof(float);
+}
 
 bool tiny_ok(const alink_head* h, int n) {
     return g_use_tiny && n <= TINY_N && h->h2 == 64 && h->h1 % 512 == 0 && h->D % 512 == 0 && h->D <= 2048 &&
-           h->h1 <= 2048 && h->oW1 == 0;
+           h->h1 <= 1024 && h->oW1 == 0;     // LDS: 43 KB (A at D = 2048), 61 KB (B at h1 = 1024) of the 64 KB default
 }
 
 // the three launches; gradients are always left in d_grads, parameters updated when `apply`
@@ -1146,14 +1130,14 @@ int tiny_train(alink_head* h, const float* L, const float* R, const float* y, co
     lp.z1 = h->d_z1; lp.w2 = P + h->oW2; lp.b2 = P + h->ob2; lp.w3 = P + h->oW3; lp.b3 = P + h->ob3; lp.y = y;
     lp.sw = sw; lp.z2 = h->d_z2; lp.probs = h->d_p; lp.dz2 = h->d_dz2; lp.dz3 = h->d_dz3; lp.dz1 = h->d_dz1;
     lp.part = h->d_tiny; lp.n = n; lp.h1 = h1; lp.od = h->od; lp.want_grads = 1; lp.grad_scale = grad_scale;
-    hipLaunchKernelGGL(tiny_dense2_loss_kernel, dim3(ngroups), dim3(512), tiny_lds_bytes(h1), st, lp);
+    hipLaunchKernelGGL(tiny_dense2_loss_kernel, dim3(ngroups), dim3(512), tiny_lds_bytes(h1, true), st, lp);
     TinyBwd bp{};
     bp.z1 = h->d_z1; bp.dz1 = h->d_dz1; bp.dz2 = h->d_dz2; bp.dm = h->d_dm; bp.part = h->d_tiny; bp.sw = sw;
     bp.prm = P; bp.g = h->d_grads; bp.a = h->d_acc; bp.d = h->d_dacc; bp.metrics = metrics;
     bp.oW1 = h->oW1; bp.ob1 = h->ob1; bp.oW2 = h->oW2; bp.ob2 = h->ob2; bp.oW3 = h->oW3; bp.ob3 = h->ob3;
     bp.n = n; bp.D = D; bp.h1 = h1; bp.od = h->od; bp.apply = apply ? 1 : 0; bp.ngroups = ngroups;
     bp.lr = h->lr; bp.rho = h->rho; bp.eps = h->eps; bp.grad_scale = grad_scale;
-    hipLaunchKernelGGL(tiny_wgrad_update_kernel, dim3(h1 / 64, D / TINY_KB), dim3(256), 0, st, bp);
+    hipLaunchKernelGGL(tiny_wgrad_update_kernel, dim3(h1 / 64, D / TINY_KB + 2), dim3(256), 0, st, bp);
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
 }
@@ -1273,7 +1257,11 @@ int alink_head_set_lr(alink_head_t* h, float lr) {
     return ALINK_OK;
 }
 float alink_head_get_lr(const alink_head_t* h) { return h ? h->lr : 0.f; }
-float* alink_head_params_dev(alink_head_t* h) { return h ? h->d_params : nullptr; }
+float* alink_head_params_dev(alink_head_t* h) {
+    if (!h) return nullptr;
+    h->packed_dirty = true;      // the caller may write through it: re-pack the forward's weight copies on next use
+    return h->d_params;
+}
 float* alink_head_grads_dev(alink_head_t* h) { return h ? h->d_grads : nullptr; }
 
 int alink_head_forward(alink_head_t* h, const float* dev_L, const float* dev_R, const int32_t* dev_li,

@@ -165,6 +165,9 @@ class DenseHead(KerasFitMixin):
                           glorot_uniform(rng, h1, h2), np.zeros(h2, np.float32),
                           glorot_uniform(rng, h2, self.out_dim), np.zeros(self.out_dim, np.float32)])
         self._metrics = torch.zeros(2, dtype=torch.float32, device=self.device)
+        # {loss, accuracy} of a step land in pinned host memory, written by the kernel itself (pinned memory
+        # is mapped into the device's address space): the step ends with one stream wait, not a copy
+        self._metrics_host = torch.zeros(2, dtype=torch.float32).pin_memory()
         self._stage = {}          # persistent device tensors the host batches are copied into
 
     def __del__(self):
@@ -338,10 +341,10 @@ class DenseHead(KerasFitMixin):
         swd = self._staged("sw", sw) if sw is not None else None
         n = L.shape[0]
         _abi.check(self.lib.alink_head_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
-                                                  0.0, 1, _abi.ptr(self._metrics), _abi.current_stream()),
+                                                  0.0, 1, _abi.ptr(self._metrics_host), _abi.current_stream()),
                    "alink_head_train_step")
-        m = self._metrics.cpu().numpy()
-        return [float(m[0]), float(m[1])]
+        self.torch.cuda.current_stream().synchronize()
+        return self._metrics_host.tolist()
 
     def input_gradients(self, L, R, y):
         """EXTENSION (FGSM / PGD): d(loss)/dL, d(loss)/dR of the Keras loss of this batch (mean over the
@@ -360,9 +363,9 @@ class DenseHead(KerasFitMixin):
         L, R = self._dev(x[0]), self._dev(x[1])
         yd = self._dev(y)
         _abi.check(self.lib.alink_head_eval(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), L.shape[0],
-                                            _abi.ptr(self._metrics), _abi.current_stream()), "alink_head_eval")
-        m = self._metrics.cpu().numpy()
-        return [float(m[0]), float(m[1])]
+                                            _abi.ptr(self._metrics_host), _abi.current_stream()), "alink_head_eval")
+        self.torch.cuda.current_stream().synchronize()
+        return self._metrics_host.tolist()
 
 
 def committee_predict_device(heads, L, R, li=None, ri=None):

@@ -190,7 +190,9 @@ int alink_head_reset_optimizer(alink_head_t* h);
 /* keras.callbacks.ReduceLROnPlateau hook (code/siamese.py:54): change Adadelta's lr */
 int alink_head_set_lr(alink_head_t* h, float lr);
 float alink_head_get_lr(const alink_head_t* h);
-/* device pointers of the flat parameter / gradient buffers (for RCCL all-reduce by the caller) */
+/* device pointers of the flat parameter / gradient buffers (for RCCL all-reduce / broadcast by the caller).
+ * The forward keeps packed copies of W1 / W2: call alink_head_params_dev again AFTER writing through the
+ * pointer (each call marks those copies stale). */
 float* alink_head_params_dev(alink_head_t* h);
 float* alink_head_grads_dev(alink_head_t* h);
 
