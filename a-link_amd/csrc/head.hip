@@ -1211,7 +1211,7 @@ alink_head_t* alink_head_create_ex(int d_in, int h1, int h2, int out_dim, float 
     h->oW3 = h->ob2 + h2; h->ob3 = h->oW3 + (size_t)h2 * out_dim; h->nparams = h->ob3 + out_dim;
     int rc = 0;
     rc |= head_alloc(h, &h->d_params, h->nparams);
-    rc |= head_alloc(h, &h->d_grads, h->nparams);
+    rc |= head_alloc(h, &h->d_grads, h->nparams + 4);   // + 4 spare floats: see alink_head_grads_dev
     rc |= head_alloc(h, &h->d_acc, h->nparams);
     rc |= head_alloc(h, &h->d_dacc, h->nparams);
     rc |= head_alloc(h, &h->d_w1p, (size_t)d_in * h1);

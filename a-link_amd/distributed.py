@@ -70,20 +70,23 @@ def dp_train_on_batch(head, x, y, class_weight=None, sample_weight=None, group=N
     w_all = np.ones(n, np.float32) if sw is None else np.asarray(sw, np.float32)
     denom = float((w_all != 0).sum())                        # Keras: mean(w*l) / mean(w != 0)
     lo, hi = shard_range(n, rank, world)
-    m = torch.zeros(2, dtype=torch.float32, device=head.device)
-    g = head.grads_tensor()
+    # gradients and {loss, accuracy-sum} travel in ONE all-reduce: the metrics live in the spare floats
+    # that follow the flat gradient buffer
+    gm = head.grads_tensor(with_metrics=True)
+    m = gm[-4:]
+    m.zero_()
     if hi > lo:
-        L, R = head._dev(np.asarray(x[0])[lo:hi]), head._dev(np.asarray(x[1])[lo:hi])
-        yd, swd = head._dev(np.asarray(y)[lo:hi]), head._dev(w_all[lo:hi])
+        take = lambda a: a[lo:hi] if hasattr(a, "shape") else np.asarray(a)[lo:hi]
+        L, R = head._dev(take(x[0])), head._dev(take(x[1]))
+        yd, swd = head._dev(take(y)), (None if sw is None else head._dev(w_all[lo:hi]))
         _abi.check(head.lib.alink_head_train_step(head.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd),
                                                   hi - lo, 1.0 / denom, 0, _abi.ptr(m), _abi.current_stream()))
         m[1] *= (hi - lo)                                    # accuracy: local mean -> local sum
     else:
-        g.zero_()
-    dist.all_reduce(g, group=group)
-    dist.all_reduce(m, group=group)
+        gm.zero_()
+    dist.all_reduce(gm, group=group)
     _abi.check(head.lib.alink_head_apply_update(head.h, _abi.current_stream()))
-    out = m.cpu().numpy()
+    out = m[:2].cpu().numpy()
     return [float(out[0]), float(out[1] / n)]
 
 

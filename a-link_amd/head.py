@@ -263,16 +263,17 @@ class DenseHead(KerasFitMixin):
         a = np.ascontiguousarray(a, dtype=np.float32 if dtype in (None, torch.float32) else np.int32)
         return torch.from_numpy(a).to(self.device)
 
-    def grads_tensor(self):
-        """torch view-less alias of the flat gradient buffer (for torch.distributed.all_reduce)."""
-        return self._alias(self.lib.alink_head_grads_dev(self.h))
+    def grads_tensor(self, with_metrics=False):
+        """torch view-less alias of the flat gradient buffer (for torch.distributed.all_reduce); with_metrics
+        appends the 4 spare floats that follow it (slot 0 / 1: loss, accuracy of a data-parallel step)."""
+        return self._alias(self.lib.alink_head_grads_dev(self.h), 4 if with_metrics else 0)
 
     def params_tensor(self):
         return self._alias(self.lib.alink_head_params_dev(self.h))
 
-    def _alias(self, devptr):
+    def _alias(self, devptr, extra=0):
         torch = self.torch
-        n = self.lib.alink_head_num_params(self.h)
+        n = self.lib.alink_head_num_params(self.h) + extra
 
         class _CAI(object):  # __cuda_array_interface__ holder
             pass

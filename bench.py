@@ -128,6 +128,32 @@ def main():
         "frac_mfma_peak_end_to_end": emb_per_s * gflop_per_emb / 1e3 / (MFMA_PEAK_TFLOPS * world),
     }
 
+    if dist is not None and not args.no_extras:
+        # ---- data-parallel fine-tune step: the 16-pair batch split over the ranks, ONE RCCL
+        # all-reduce of the flat gradient buffer (+ metrics), identical Adadelta update on every rank
+        from a_link_amd import distributed as D
+        from a_link_amd.head import DenseHead
+        hdp = DenseHead(512, lr=0.1, seed=0)
+        rng = np.random.RandomState(0)
+        Ld = torch.from_numpy(rng.randn(16, 512).astype(np.float32)).cuda()
+        Rd = torch.from_numpy(rng.randn(16, 512).astype(np.float32)).cuda()
+        yh = np.zeros((16, 2), np.float32)
+        yh[np.arange(16), rng.randint(0, 2, 16)] = 1
+        ydd = torch.from_numpy(yh).cuda()
+        for _ in range(20):
+            D.dp_train_on_batch(hdp, [Ld, Rd], ydd)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(100):
+            D.dp_train_on_batch(hdp, [Ld, Rd], ydd)
+        torch.cuda.synchronize()
+        barrier()
+        tdp = torch.tensor([(time.perf_counter() - t1) / 100], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tdp, op=dist.ReduceOp.MAX)
+        line["finetune_step_dp_ms"] = 1e3 * float(tdp.item())
+        del hdp
+
     if rank == 0 and not args.no_extras:
         # ---- roofline of the dominant kernel (conv_igemm_kernel): HIP events around every launch
         conv_ms, conv_fl, other_ms, profs = [], [], [], []

@@ -192,7 +192,9 @@ int alink_head_set_lr(alink_head_t* h, float lr);
 float alink_head_get_lr(const alink_head_t* h);
 /* device pointers of the flat parameter / gradient buffers (for RCCL all-reduce / broadcast by the caller).
  * The forward keeps packed copies of W1 / W2: call alink_head_params_dev again AFTER writing through the
- * pointer (each call marks those copies stale). */
+ * pointer (each call marks those copies stale).  The gradient buffer is num_params floats followed by 4
+ * spare floats: a data-parallel caller points dev_metrics of alink_head_train_step at them so that ONE
+ * all-reduce carries the gradients and {loss, accuracy}. */
 float* alink_head_params_dev(alink_head_t* h);
 float* alink_head_grads_dev(alink_head_t* h);
 
