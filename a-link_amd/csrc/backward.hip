@@ -59,48 +59,83 @@ __global__ void zero_insert_kernel(const T* __restrict__ in, T* __restrict__ out
 }
 
 // dpix[n][iy][ix][c] = mul * sum_{ky,kx,co} dz0[n][iy-ky+1][ix-kx+1][co] * w[co][ky*9 + kx*3 + c],
-// dz0 = dy0 * PReLU'(y0).  One thread per pixel; the 64 x 27 folded stem weights and slopes sit in LDS.
+// dz0 = dy0 * PReLU'(y0).  A workgroup owns a 14 x 14 tile of pixels (112 = 8 x 14): each of its 256
+// threads first turns ONE position of the 16 x 16 halo region into its 27 tap contributions
+// t[tap][c] = sum_co dz0[co] w[co][tap][c] (dy0 / y0 are read once per position, not once per tap; the
+// folded weights sit in LDS as [64][28] and are fetched by 16-B broadcast reads; the FMAs are written on
+// float2 so that they issue as v_pk_fma_f32), parks them in LDS, then sums the nine neighbours of its pixel.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <typename T>
 __global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ dy0, const T* __restrict__ y0,
                                                        const float* __restrict__ w, const float* __restrict__ alpha,
                                                        float* __restrict__ dpix, int N, int H, int W, float mul,
                                                        int nchw) {
     typedef typename Vec8<T>::type vec8;
-    __shared__ float sw[64 * 28];
+    constexpr int TS = 14, HS = TS + 2;                    // 256 halo positions, 27 floats each (odd pitch: conflict-free)
+    __shared__ float ts[HS * HS * 27];
+    __shared__ __attribute__((aligned(16))) float sw[64 * 28];
     __shared__ float sa[64];
-    for (int i = threadIdx.x; i < 64 * 27; i += 256) sw[(i / 27) * 28 + i % 27] = w[i];
-    if (threadIdx.x < 64) sa[threadIdx.x] = alpha[threadIdx.x];
-    __syncthreads();
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)N * H * W) return;
-    const int ix = (int)(i % W);
-    const long long r = i / W;
-    const int iy = (int)(r % H), n = (int)(r / H);
-    float acc[3] = {0.f, 0.f, 0.f};
-    for (int ky = 0; ky < 3; ++ky) {
-        const int oy = iy - ky + 1;
-        if ((unsigned)oy >= (unsigned)H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ox = ix - kx + 1;
-            if ((unsigned)ox >= (unsigned)W) continue;
-            const size_t base = (((size_t)n * H + oy) * W + ox) * 64;
-            for (int c8 = 0; c8 < 8; ++c8) {
-                const vec8 g = *(const vec8*)(dy0 + base + c8 * 8);
-                const vec8 a = *(const vec8*)(y0 + base + c8 * 8);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 64 * 28; i += 256) sw[i] = (i % 28) < 27 ? w[(i / 28) * 27 + i % 28] : 0.f;
+    if (tid < 64) sa[tid] = alpha[tid];
+    const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int py = tid / HS, px = tid % HS;
+    const int oy = ty * TS - 1 + py, ox = tx * TS - 1 + px;
+    const bool inside = (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W;
+    vec8 g[8], a[8];
+    if (inside) {
+        const size_t base = (((size_t)n * H + oy) * W + ox) * 64;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int co = c8 * 8 + j;
-                    const float d = (float)g[j] * ((float)a[j] > 0.f ? 1.f : sa[co]);
-                    const float* wr = sw + co * 28 + ky * 9 + kx * 3;
-                    acc[0] = fmaf(d, wr[0], acc[0]);
-                    acc[1] = fmaf(d, wr[1], acc[1]);
-                    acc[2] = fmaf(d, wr[2], acc[2]);
+        for (int c8 = 0; c8 < 8; ++c8) {
+            g[c8] = *(const vec8*)(dy0 + base + c8 * 8);
+            a[c8] = *(const vec8*)(y0 + base + c8 * 8);
+        }
+    }
+    __syncthreads();
+    f32x2 t[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) t[j] = f32x2{0.f, 0.f};
+    if (inside) {
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8) {
+                const int co = c8 * 8 + j8;
+                const float d = (float)g[c8][j8] * ((float)a[c8][j8] > 0.f ? 1.f : sa[co]);
+                const f32x2 d2 = {d, d};
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    const f32x4 w4 = *(const f32x4*)(sw + co * 28 + q * 4);
+                    t[2 * q] += d2 * f32x2{w4[0], w4[1]};
+                    t[2 * q + 1] += d2 * f32x2{w4[2], w4[3]};
                 }
             }
         }
     }
+#pragma unroll
+    for (int j = 0; j < 27; ++j) ts[tid * 27 + j] = t[j >> 1][j & 1];
+    __syncthreads();
+    const int ly = tid / TS, lx = tid % TS;
+    const int iy = ty * TS + ly, ix = tx * TS + lx;
+    if (tid >= TS * TS || iy >= H || ix >= W) return;
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            // output position (iy - ky + 1, ix - kx + 1) = halo position (ly + 2 - ky, lx + 2 - kx)
+            const float* tp = ts + ((ly + 2 - ky) * HS + (lx + 2 - kx)) * 27 + ky * 9 + kx * 3;
+            acc[0] += tp[0];
+            acc[1] += tp[1];
+            acc[2] += tp[2];
+        }
+    const size_t i = ((size_t)n * H + iy) * W + ix;
     for (int c = 0; c < 3; ++c) {
-        const size_t o = nchw ? (((size_t)n * 3 + c) * H + iy) * W + ix : (size_t)i * 3 + c;
+        const size_t o = nchw ? (((size_t)n * 3 + c) * H + iy) * W + ix : i * 3 + c;
         dpix[o] = acc[c] * mul;
     }
 }
@@ -128,8 +163,9 @@ hipError_t launch_zero_insert(int dtype, const void* in, void* out, int N, int H
 
 hipError_t launch_stem_bwd(int dtype, const void* dy0, const void* y0, const float* w, const float* alpha, float* dpix,
                            int N, int H, int W, float mul, int nchw, hipStream_t st) {
-    const long long tot = (long long)N * H * W;
-    dim3 grid((unsigned)((tot + 255) / 256)), block(256);
+    const long long tiles = (long long)N * ((H + 13) / 14) * ((W + 13) / 14);
+    if (tiles <= 0 || tiles >= (1ll << 31)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)tiles), block(256);
     if (dtype == ALINK_DT_BF16)
         hipLaunchKernelGGL(stem_bwd_kernel<__bf16>, grid, block, 0, st, (const __bf16*)dy0, (const __bf16*)y0, w, alpha, dpix, N, H, W, mul, nchw);
     else
