@@ -111,6 +111,11 @@ int        direct_variant(int ksz, int stride, int pad, int H, int W, int Cin, i
 int        direct_variant_cpl(int v);
 hipError_t direct_set_attributes();
 hipError_t launch_conv3x3_direct(int variant, int dtype, const ConvParams& p, hipStream_t st);
+// linear-tile variants (conv3x3_linear.hip), reached through the four functions above as variants 11..13
+int        linear_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout);
+int        linear_variant_cpl(int v);
+hipError_t linear_set_attributes();
+hipError_t launch_conv3x3_linear(int variant, int dtype, const ConvParams& p, hipStream_t st);
 
 // backward.hip (input-gradient pass)
 hipError_t launch_l2norm_bwd(int dtype, const float* g, const float* e, const float* norms, void* dz, int M, int E,

@@ -1,0 +1,360 @@
+// conv3x3_linear.hip — 3x3 / stride 1 / pad 1 NHWC convolution on LINEAR pixel tiles (no dummy columns).
+//
+// The row-aligned tiles of conv3x3_direct.hip spend 2 of every 16 MFMA columns on pixels that do not
+// exist (maps are 14, 28, 56 wide): 12.5 % of the matrix-core work — and, on a part that runs this
+// workload at its package power limit, 12.5 % of the energy — buys nothing.  Here the
+// whole batch is one tall image of N*H rows of W pixels, NHWC being contiguous across images, and a
+// workgroup owns 224 CONSECUTIVE pixels of it (16 rows of 14, 8 rows of 28 or 4 rows of 56) = exactly
+// fourteen 16-pixel MFMA tiles, as two wave groups of seven:
+//
+//   * Input staging is a plain contiguous copy: the 224 pixels plus W + 1 before and after (one row of
+//     halo each side, one pixel of slack) for the current 64-channel chunk, by LDS-DMA, XOR-swizzled.
+//     No zero frame is built.
+//   * A lane's pixel for tile t is 16 t + d, its operand for tap (ky, kx) sits at LDS position
+//     16 t + d + ky W + kx: 16 consecutive positions for any tap, so the delta() lane permutation and
+//     the chunk ^ ((pos >> 1) & 7) swizzle of the row-aligned kernel keep every ds_read_b128 conflict-free;
+//     (16 t) vanishes from the swizzle term, so nine per-lane offsets serve all tiles through the ds_read
+//     immediate, and the upper K half is the same address ^ 64.
+//   * What the zero frame did is done by ADDRESS: a tap that would read across a row end (left / right
+//     image border) or across an image boundary (top / bottom) is redirected to a 128-B block of zeros.
+//     Four border bits per tile and lane (28 bits, one VGPR) are set up once; per (tile, tap) that costs
+//     an and, a compare and two selects of the address — against eight MFMAs.
+//   * Output (and residual / stored activation) addresses are linear too: pixel index x Cout.
+//
+// Weights, K-step order, epilogue and the two-workgroups-per-CU residency are those of the 4-wave
+// variants of conv3x3_direct.hip (same row permutation codes, so the packed weights are interchangeable).
+#include "alink_common.h"
+
+namespace alink {
+namespace {
+
+template <typename T> struct Vec8;
+template <> struct Vec8<__bf16>   { typedef bf16x8 type; };
+template <> struct Vec8<_Float16> { typedef f16x8 type; };
+
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16(typename Vec8<T>::type a, typename Vec8<T>::type b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mfma16<__bf16>(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mfma16<_Float16>(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gsrc,
+        (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+// pixel (0..15) inside a 16-pixel MFMA tile handled by MFMA column lr (see conv3x3_direct.hip)
+__device__ __forceinline__ int delta(int lr) { return lr < 4 ? 2 * lr : (lr < 12 ? 2 * (lr - 4) + 1 : 2 * (lr - 8)); }
+
+__device__ __forceinline__ void wait_dma_then_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int A>
+struct IC { static constexpr int a = A; };
+
+constexpr int GPX = 224;        // pixels per workgroup: 14 tiles
+constexpr int TPW = 7;          // tiles per wave group (2 groups)
+constexpr int NT = 256;         // 4 waves: 2 pixel groups x 2 channel groups
+
+template <int W, int TCW>
+struct Lin {
+    static constexpr int BN = 2 * TCW * 16;
+    static constexpr int XPIX = GPX + 2 * W + 2;                       // halo row + slack pixel on both sides
+    static constexpr int XSLOTS = (XPIX * 8 + NT - 1) / NT;
+    static constexpr int XBYTES = XSLOTS * NT * 16;
+    static constexpr int ZOFF = XBYTES;                                // 128 B of zeros
+    static constexpr int WOFF = ZOFF + 128;
+    static constexpr int WBYTES = BN * 128;
+    static constexpr size_t lds_bytes() { return (size_t)WOFF + 2 * WBYTES + 10 * BN * 4; }
+    static_assert(GPX % W == 0, "a workgroup covers whole rows");
+    static_assert(ZOFF >= 2048 * 13, "zero-block address minus any tile offset stays non-negative");
+};
+
+template <typename T, int W, int TCW>
+__global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams p) {
+    typedef typename Vec8<T>::type vec8;
+    typedef Lin<W, TCW> G;
+    constexpr int BN = G::BN, XSLOTS = G::XSLOTS, WBYTES = G::WBYTES, WSLOTS = BN * 8 / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wpx = wave >> 1, wco = wave & 1;
+    const int q = lane >> 4, lr = lane & 15;
+    const int H = p.H, Cin = p.Cin;
+    const int ncc = Cin >> 6, nk = ncc * 9;
+    const int K = 9 * Cin;
+    const long long totpix = (long long)p.N * H * W;
+
+    const int ntn = p.Cout / BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % ntn, grp = lid / ntn;
+    const int n0 = tile_n * BN;
+    const long long gp0 = (long long)grp * GPX;                        // first pixel of the group
+
+    const T* __restrict__ gin = (const T*)p.in;
+    const T* __restrict__ gw = (const T*)p.wgt;
+    const T* __restrict__ gz = (const T*)p.zero;
+
+    // ---- X staging: LDS position idx <- pixel gp0 - W - 1 + idx, a contiguous span of the tensor.  Slot
+    // s = tid + 256 i -> position (tid >> 3) + 32 i, 16-B piece tid & 7; the swizzle term ((position >> 1) & 7)
+    // is the same for every i, so one offset per thread serves all slots ------------------------------------------
+    const int xpos0 = tid >> 3;
+    const int xc16 = (tid & 7) ^ ((tid >> 4) & 7);
+    const long long xgp0 = gp0 - W - 1 + xpos0;                        // pixel of slot 0
+    auto stage_x = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < XSLOTS; ++i) {
+            const long long gp = xgp0 + 32 * i;
+            const bool ok = xpos0 + 32 * i < G::XPIX && gp >= 0 && gp < totpix;
+            const T* src = ok ? gin + ((size_t)gp * Cin + cc * 64 + xc16 * 8) : gz + (lane & 7) * 8;
+            dma16(src, smem + (NT * i + wave * 64) * 16);
+        }
+    };
+    // ---- W staging (K-step order [cout][chunk][tap][64], as conv3x3_direct): slot s = tid + 256 i -> row
+    // (tid >> 3) + 32 i, piece tid & 7, again with an i-independent swizzle term ------------------------------------
+    const unsigned woff0 = (unsigned)((tid >> 3) * K + (((tid & 7) ^ ((tid >> 4) & 7)) * 8));
+    const T* wstep = gw + (size_t)n0 * K;                              // advanced by 64 elements per K-step (uniform)
+    auto stage_w = [&](int bufoff) {
+#pragma unroll
+        for (int i = 0; i < WSLOTS; ++i)
+            dma16(wstep + (woff0 + (unsigned)(32 * i * K)), smem + G::WOFF + bufoff + (NT * i + wave * 64) * 16);
+        wstep += 64;
+    };
+
+    // ---- per-lane fragment offsets and border bits --------------------------------------------------------------
+    const int dl = delta(lr);
+    // operand offset of tap (ky, kx), lower K half (the upper half is ^ 64): position s = dl + ky W + kx,
+    // byte s * 128 + ((q ^ ((s >> 1) & 7)) << 4).  Recomputed per K-step from dl (four VALU operations) rather
+    // than kept in nine registers.
+    const int xbase = wpx * (TPW * 2048);
+    // bit 4u + {0: top row of an image, 1: bottom row, 2: left column, 3: right column} for tile u
+    unsigned border = 0;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int pl = 16 * (wpx * TPW + u) + dl;
+        const int col = pl % W;
+        const int y = (int)((gp0 / W + pl / W) % H);
+        border |= ((y == 0 ? 1u : 0u) | (y == H - 1 ? 2u : 0u) | (col == 0 ? 4u : 0u) | (col == W - 1 ? 8u : 0u)) << (4 * u);
+    }
+    int wl[2];
+    {
+        const int rowb = wco * (16 * TCW) + lr;
+        const int f = (lr >> 1) & 7;
+        wl[0] = G::WOFF + rowb * 128 + (((0 | q) ^ f) << 4);
+        wl[1] = G::WOFF + rowb * 128 + (((4 | q) ^ f) << 4);
+    }
+
+    f32x4 acc[TCW][TPW];
+#pragma unroll
+    for (int t = 0; t < TCW; ++t)
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ncls = p.border_cls ? 9 : 1;
+    float* const ebias = (float*)(smem + G::WOFF + 2 * WBYTES);
+    float* const ealpha = ebias + 9 * BN;
+    for (int i = tid; i < ncls * BN; i += NT) ebias[i] = p.bias[(i / BN) * p.Cout + n0 + (i % BN)];
+    if (p.alpha)
+        for (int i = tid; i < BN; i += NT) ealpha[i] = p.alpha[n0 + i];
+    if (tid < 8) *(f32x4*)(smem + G::ZOFF + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage_x(0);
+    stage_w(0);
+    wait_dma_then_barrier();
+
+    int wtog = 0;
+    for (int cc = 0; cc < ncc; ++cc) {
+        auto step = [&](auto tapc) {
+            constexpr int tap = decltype(tapc)::a;
+            constexpr int ky = tap / 3, kx = tap % 3;
+            constexpr unsigned tapbits = (ky == 0 ? 1u : 0u) | (ky == 2 ? 2u : 0u) | (kx == 0 ? 4u : 0u) | (kx == 2 ? 8u : 0u);
+            const int t = cc * 9 + tap;
+            if (t + 1 < nk) stage_w(wtog ^ WBYTES);
+            // the border tests are loop-invariant over the channel chunks; recomputing them (a handful of VALU
+            // operations per 8 MFMAs) is far cheaper than the registers the compiler would hoist them into
+            unsigned bnow = border;
+            asm volatile("" : "+v"(bnow));
+            int sdl = dl, zaddr = G::ZOFF;
+            asm volatile("" : "+v"(sdl), "+v"(zaddr));  // opaque: nothing derived from them is hoisted or materialised per tile
+            const int spos = sdl + ky * W + kx;
+            const int xt0 = xbase + spos * 128 + ((q ^ ((spos >> 1) & 7)) << 4);
+            const int xt1 = xt0 ^ 64;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                vec8 wf[TCW], pf[TPW];
+#pragma unroll
+                for (int tt = 0; tt < TCW; ++tt) wf[tt] = *(const vec8*)(smem + (wl[ks] + wtog) + tt * 2048);
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    const bool inval = tapbits != 0 && (bnow & (tapbits << (4 * u))) != 0;
+                    const int a = inval ? zaddr : (ks ? xt1 : xt0) + 2048 * u;
+                    pf[u] = *(const vec8*)(smem + a);
+                }
+#pragma unroll
+                for (int tt = 0; tt < TCW; ++tt)
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) acc[tt][u] = mfma16<T>(wf[tt], pf[u], acc[tt][u]);
+            }
+            wait_dma_then_barrier();
+            wtog ^= WBYTES;
+        };
+        step(IC<0>{}); step(IC<1>{}); step(IC<2>{});
+        step(IC<3>{}); step(IC<4>{}); step(IC<5>{});
+        step(IC<6>{}); step(IC<7>{}); step(IC<8>{});
+        if (cc + 1 < ncc) {
+            // single X buffer: every wave is past its last read of this chunk; refill and wait — the
+            // co-resident workgroup keeps the matrix cores busy meanwhile
+            stage_x(cc + 1);
+            wait_dma_then_barrier();
+        }
+    }
+
+    // ---- epilogue (as conv3x3_direct: bias by border class, PReLU | PReLU', residual, 16-B stores) -----------
+    constexpr int CPL = TCW * 4;
+    const int wbase = wco * (16 * TCW);
+    auto chan_t = [&](int t) { return wbase + (TCW == 4 ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) : 8 * q + 4 * t); };
+    auto chan_h = [&](int h) { return wbase + (TCW == 4 ? 32 * h + 8 * q : 8 * q); };
+    size_t off[TPW];
+    bool ok[TPW];
+    int cls[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const long long gp = gp0 + 16 * (wpx * TPW + u) + dl;
+        ok[u] = gp < totpix;
+        off[u] = (size_t)(ok[u] ? gp : 0) * p.Cout + n0;
+        const unsigned b4 = (border >> (4 * u)) & 15u;
+        const int rc = (b4 & 1u) ? 0 : ((b4 & 2u) ? 2 : 1);
+        const int ccl = (b4 & 4u) ? 0 : ((b4 & 8u) ? 2 : 1);
+        cls[u] = p.border_cls ? rc * 3 + ccl : 0;
+    }
+    vec8 res[TPW][CPL / 8];
+    const T* extra = (const T*)(p.dact ? p.dact : p.resid);
+    if (extra) {
+#pragma unroll
+        for (int u = 0; u < TPW; ++u)
+#pragma unroll
+            for (int h = 0; h < CPL / 8; ++h) res[u][h] = *(const vec8*)(extra + off[u] + chan_h(h));
+    }
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        float v[CPL];
+#pragma unroll
+        for (int t = 0; t < TCW; ++t) {
+            const f32x4 b4 = *(const f32x4*)(ebias + cls[u] * BN + chan_t(t));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * t + j] = acc[t][u][j] + b4[j];
+        }
+        if (p.dact) {
+#pragma unroll
+            for (int t = 0; t < TCW; ++t) {
+                const f32x4 a4 = *(const f32x4*)(ealpha + chan_t(t));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[4 * t + j] *= (float)res[u][(4 * t + j) / 8][(4 * t + j) % 8] > 0.f ? 1.f : a4[j];
+            }
+        } else {
+            if (p.alpha) {
+#pragma unroll
+                for (int t = 0; t < TCW; ++t) {
+                    const f32x4 a4 = *(const f32x4*)(ealpha + chan_t(t));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[4 * t + j] = v[4 * t + j] > 0.f ? v[4 * t + j] : v[4 * t + j] * a4[j];
+                }
+            }
+            if (p.resid) {
+#pragma unroll
+                for (int h = 0; h < CPL / 8; ++h)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[8 * h + i] += (float)res[u][h][i];
+            }
+        }
+        if (p.post_relu) {
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (ok[u]) {
+#pragma unroll
+            for (int h = 0; h < CPL / 8; ++h) {
+                vec8 o8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o8[i] = (T)v[8 * h + i];
+                *(vec8*)((T*)p.out + off[u] + chan_h(h)) = o8;
+            }
+        }
+    }
+}
+
+template <typename T, int W, int TCW>
+hipError_t launch_one(const ConvParams& p, hipStream_t st) {
+    typedef Lin<W, TCW> G;
+    const long long totpix = (long long)p.N * p.H * W;
+    const long long groups = (totpix + GPX - 1) / GPX;
+    const long long nwg = groups * (p.Cout / G::BN);
+    if (nwg <= 0 || nwg >= (1ll << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW>), dim3((unsigned)nwg), dim3(NT), G::lds_bytes(), st, p);
+    return hipGetLastError();
+}
+template <typename T, int W, int TCW>
+hipError_t set_attr_one() {
+    return hipFuncSetAttribute((const void*)conv3x3_linear_kernel<T, W, TCW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)Lin<W, TCW>::lds_bytes());
+}
+
+// Which map widths take the linear-tile kernel: bit 0 = 56, bit 1 = 28, bit 2 = 14.  Measured on MI355X
+// (DESIGN.md §4): at 56 wide it beats the row-aligned 8-wave variant by 6 %; at 28 and 14 wide a 256-image
+// launch has 448 workgroups for 512 slots — the 12.5 % of MFMA work saved turns into idle slots, not time,
+// and the border selects cost 3 us per launch — so those stay opt-in (+1.5 % end to end when many launches
+// overlap).
+int g_linear_mode = 1;
+
+}  // namespace
+
+extern "C" void alink_debug_set_linear(int mode) { g_linear_mode = mode; }
+
+// 11 / 12 / 13: linear-tile kernel for 14 / 28 / 56-wide square maps (0 = not applicable)
+int linear_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout) {
+    if (ksz != 3 || stride != 1 || pad != 1 || H != W || Cin % 64) return 0;
+    if ((g_linear_mode & 4) && W == 14 && Cout % 128 == 0) return 11;
+    if ((g_linear_mode & 2) && W == 28 && Cout % 128 == 0) return 12;
+    if ((g_linear_mode & 1) && W == 56 && Cout % 64 == 0) return 13;
+    return 0;
+}
+int linear_variant_cpl(int v) { return v == 13 ? 8 : 17; }
+
+hipError_t linear_set_attributes() {
+    hipError_t e;
+#define A(T)                                                              \
+    if ((e = set_attr_one<T, 14, 4>()) != hipSuccess) return e;           \
+    if ((e = set_attr_one<T, 28, 4>()) != hipSuccess) return e;           \
+    if ((e = set_attr_one<T, 56, 2>()) != hipSuccess) return e;
+    A(__bf16) A(_Float16)
+#undef A
+    return hipSuccess;
+}
+
+hipError_t launch_conv3x3_linear(int variant, int dtype, const ConvParams& p, hipStream_t st) {
+    if (p.ksz != 3 || p.stride != 1 || p.pad != 1 || p.splitk != 1 || p.H != p.W) return hipErrorInvalidValue;
+    if ((long long)p.N * p.H * p.W * p.Cin >= (1ll << 31)) return hipErrorInvalidValue;
+#define L(W_, TCW_) (dtype == ALINK_DT_BF16 ? launch_one<__bf16, W_, TCW_>(p, st) : launch_one<_Float16, W_, TCW_>(p, st))
+    switch (variant) {
+        case 11: return p.W == 14 ? L(14, 4) : hipErrorInvalidValue;
+        case 12: return p.W == 28 ? L(28, 4) : hipErrorInvalidValue;
+        case 13: return p.W == 56 ? L(56, 2) : hipErrorInvalidValue;
+    }
+#undef L
+    return hipErrorInvalidValue;
+}
+
+}  // namespace alink

@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--input", default="f32", choices=["f32", "u8"], help="pixel type resident in HBM")
     ap.add_argument("--streams", type=int, default=4, help="streams the chunks of one step are spread over")
+    ap.add_argument("--linear", type=int, default=-1, help="A/B: widths on linear pixel tiles (bit0 56, bit1 28, bit2 14)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile / fine-tune timing")
     args = ap.parse_args()
@@ -77,6 +78,9 @@ def main():
             dist.barrier()                                   # creates the communicator (and its banner) now
             torch.cuda.synchronize()
 
+    if args.linear >= 0:
+        from a_link_amd import _abi
+        _abi.load().alink_debug_set_linear(args.linear)
     units = W.ARCH_UNITS[args.model]
     params = W.synthetic_ir_params(units, seed=1)
     bb = IRBackbone(params, image_size=(112, 112), dtype=args.dtype, device=local_rank, max_batch=args.chunk,

@@ -49,16 +49,27 @@ def _ref(x, w, bias, alpha, resid, stride, pad, border):
     return y
 
 
+# linear-tile kernel (conv3x3_linear.hip): image borders and image boundaries inside a 224-pixel group,
+# the tail group of a batch, every epilogue mode
+LINEAR_CASES = [
+    (11, 14, 14, 128, 256, 3, 1, 1, 1, 1, 1),   # 11 images: groups straddle image boundaries, ragged tail
+    (3, 28, 28, 64, 128, 3, 1, 1, 1, 0, 1),
+    (1, 56, 56, 64, 64, 3, 1, 1, 0, 1, 0),
+]
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("dma", [1, 0])
-def test_conv_matches_cpu(gpu, dt, dma):
+@pytest.mark.parametrize("dma,linear", [(1, -1), (0, -1), (1, 7)])
+def test_conv_matches_cpu(gpu, dt, dma, linear):
     lib = gpu.load()
     lib.alink_debug_set_dma(dma)
+    if linear >= 0:
+        lib.alink_debug_set_linear(linear)      # 7: the linear-tile kernel at every width it supports
     tdt = torch.bfloat16 if dt == "bf16" else torch.float16
     code = gpu.DT_BF16 if dt == "bf16" else gpu.DT_F16
     g = torch.Generator().manual_seed(1234)
     try:
-        for (N, H, W, Ci, Co, k, s, p, border, use_alpha, use_resid) in CASES:
+        for (N, H, W, Ci, Co, k, s, p, border, use_alpha, use_resid) in CASES + LINEAR_CASES:
             x = (torch.randn(N, H, W, Ci, generator=g)).to(tdt)
             w = (torch.randn(Co, k, k, Ci, generator=g) * (1.0 / np.sqrt(k * k * Ci))).to(tdt)
             ncls = 9 if border else 1
@@ -84,6 +95,7 @@ def test_conv_matches_cpu(gpu, dt, dma):
                 (N, H, W, Ci, Co, k, s, p, border), dt, dma, float((err - tol).max()))
     finally:
         lib.alink_debug_set_dma(1)
+        lib.alink_debug_set_linear(1)           # library default: 56-wide maps only
 
 
 def test_conv_rejects_bad_shapes(gpu):

@@ -19,6 +19,7 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--ablate", type=int, default=0)
 ap.add_argument("--no-direct", action="store_true")
 ap.add_argument("--no-pair", action="store_true")
+ap.add_argument("--linear", type=int, default=-1, help="linear-tile widths: bit0 56, bit1 28, bit2 14 (default: library default)")
 a = ap.parse_args()
 units = W.ARCH_UNITS[a.model]
 from a_link_amd import _abi
@@ -28,6 +29,8 @@ if a.no_direct:
     _lib.alink_debug_set_direct(0)
 if a.no_pair:
     _lib.alink_debug_set_pair(0)
+if a.linear >= 0:
+    _lib.alink_debug_set_linear(a.linear)
 bb = IRBackbone(W.synthetic_ir_params(units, seed=1), dtype=a.dtype, max_batch=a.batch)
 x = torch.randint(0, 256, (a.batch, 112, 112, 3), dtype=torch.uint8).float().cuda()
 for _ in range(2):
