@@ -15,10 +15,11 @@
 //     the chunk ^ ((pos >> 1) & 7) swizzle of the row-aligned kernel keep every ds_read_b128 conflict-free;
 //     (16 t) vanishes from the swizzle term, so nine per-lane offsets serve all tiles through the ds_read
 //     immediate, and the upper K half is the same address ^ 64.
-//   * What the zero frame did is done by ADDRESS: a tap that would read across a row end (left / right
-//     image border) or across an image boundary (top / bottom) is redirected to a 128-B block of zeros.
-//     Four border bits per tile and lane (28 bits, one VGPR) are set up once; per (tile, tap) that costs
-//     an and, a compare and two selects of the address — against eight MFMAs.
+//   * What the zero frame did is done by ADDRESS: a lane whose tap would read across a row end (left /
+//     right image border) or across an image boundary (top / bottom) gets its border bits added to the
+//     operand address far above bit 17, i.e. outside the workgroup's LDS allocation, where a DS read
+//     returns zero.  Four border bits per tile and lane (28 bits, one VGPR) are set up once; per (tile, tap)
+//     that costs an and and a shift-add — against eight MFMAs.
 //   * Output (and residual / stored activation) addresses are linear too: pixel index x Cout.
 //
 // Weights, K-step order, epilogue and the two-workgroups-per-CU residency are those of the 4-wave
@@ -75,12 +76,10 @@ struct Lin {
     static constexpr int XPIX = GPX + 2 * W + 2;                       // halo row + slack pixel on both sides
     static constexpr int XSLOTS = (XPIX * 8 + NT - 1) / NT;
     static constexpr int XBYTES = XSLOTS * NT * 16;
-    static constexpr int ZOFF = XBYTES;                                // 128 B of zeros
-    static constexpr int WOFF = ZOFF + 128;
+    static constexpr int WOFF = XBYTES;
     static constexpr int WBYTES = BN * 128;
     static constexpr size_t lds_bytes() { return (size_t)WOFF + 2 * WBYTES + 10 * BN * 4; }
     static_assert(GPX % W == 0, "a workgroup covers whole rows");
-    static_assert(ZOFF >= 2048 * 13, "zero-block address minus any tile offset stays non-negative");
 };
 
 template <typename T, int W, int TCW>
@@ -170,7 +169,6 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     for (int i = tid; i < ncls * BN; i += NT) ebias[i] = p.bias[(i / BN) * p.Cout + n0 + (i % BN)];
     if (p.alpha)
         for (int i = tid; i < BN; i += NT) ealpha[i] = p.alpha[n0 + i];
-    if (tid < 8) *(f32x4*)(smem + G::ZOFF + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     stage_x(0);
     stage_w(0);
     wait_dma_then_barrier();
@@ -183,12 +181,15 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
             constexpr unsigned tapbits = (ky == 0 ? 1u : 0u) | (ky == 2 ? 2u : 0u) | (kx == 0 ? 4u : 0u) | (kx == 2 ? 8u : 0u);
             const int t = cc * 9 + tap;
             if (t + 1 < nk) stage_w(wtog ^ WBYTES);
-            // the border tests are loop-invariant over the channel chunks; recomputing them (a handful of VALU
-            // operations per 8 MFMAs) is far cheaper than the registers the compiler would hoist them into
+            // A lane whose pixel lies on the border this tap crosses must read zeros: its border bits, shifted
+            // up to 2^18 and beyond, are ADDED to its operand address, which then lies outside the workgroup's
+            // LDS allocation — and a DS read out of range returns zero (alink_debug_lds_oob_probe checks this
+            // contract).  Two VALU operations per (tile, tap) and the tile offset stays in the ds_read immediate.
+            // bnow / sdl are made opaque so that nothing derived from them is hoisted out of the chunk loop
+            // into registers the kernel does not have.
             unsigned bnow = border;
-            asm volatile("" : "+v"(bnow));
-            int sdl = dl, zaddr = G::ZOFF;
-            asm volatile("" : "+v"(sdl), "+v"(zaddr));  // opaque: nothing derived from them is hoisted or materialised per tile
+            int sdl = dl;
+            asm volatile("" : "+v"(bnow), "+v"(sdl));
             const int spos = sdl + ky * W + kx;
             const int xt0 = xbase + spos * 128 + ((q ^ ((spos >> 1) & 7)) << 4);
             const int xt1 = xt0 ^ 64;
@@ -199,9 +200,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
                 for (int tt = 0; tt < TCW; ++tt) wf[tt] = *(const vec8*)(smem + (wl[ks] + wtog) + tt * 2048);
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) {
-                    const bool inval = tapbits != 0 && (bnow & (tapbits << (4 * u))) != 0;
-                    const int a = inval ? zaddr : (ks ? xt1 : xt0) + 2048 * u;
-                    pf[u] = *(const vec8*)(smem + a);
+                    const unsigned t = tapbits ? (bnow & (tapbits << (4 * u))) : 0u;
+                    const unsigned far = 4 * u < 18 ? t << (18 - (4 * u < 18 ? 4 * u : 0)) : t;
+                    pf[u] = *(const vec8*)(smem + ((ks ? xt1 : xt0) + (int)far) + 2048 * u);
                 }
 #pragma unroll
                 for (int tt = 0; tt < TCW; ++tt)
@@ -312,23 +313,43 @@ hipError_t set_attr_one() {
                                (int)Lin<W, TCW>::lds_bytes());
 }
 
-// Which map widths take the linear-tile kernel: bit 0 = 56, bit 1 = 28, bit 2 = 14.  Measured on MI355X
-// (DESIGN.md §4): at 56 wide it beats the row-aligned 8-wave variant by 6 %; at 28 and 14 wide a 256-image
-// launch has 448 workgroups for 512 slots — the 12.5 % of MFMA work saved turns into idle slots, not time,
-// and the border selects cost 3 us per launch — so those stay opt-in (+1.5 % end to end when many launches
-// overlap).
-int g_linear_mode = 1;
+// Which map widths take the linear-tile kernel: bit 0 = 56, bit 1 = 28, bit 2 = 14, bit 3 = 7 (default: all).
+// Measured on MI355X: a single 256-image launch at 28 or 14 wide has 448 workgroups for 512
+// slots, so alone it takes as long as the row-aligned kernel (12.5 % fewer MFMAs, idle slots instead of
+// time); with launches overlapping on several streams the embedding rate rises by 4.3 %.
+int g_linear_mode = 15;
 
 }  // namespace
 
 extern "C" void alink_debug_set_linear(int mode) { g_linear_mode = mode; }
 
-// 11 / 12 / 13: linear-tile kernel for 14 / 28 / 56-wide square maps (0 = not applicable)
+// Hardware contract probe: a DS read whose address lies beyond the workgroup's LDS allocation returns zero
+// (and does not fault).  out: 64 x 4 floats read 256 KB into a 1 KB allocation, then 4 floats read in range.
+namespace {
+__global__ void lds_oob_probe_kernel(float* out) {
+    __shared__ __attribute__((aligned(16))) float buf[256];
+    for (int i = threadIdx.x; i < 256; i += 64) buf[i] = 1.0f + i;
+    __syncthreads();
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)buf;   // escapes: the stores stay
+    const unsigned far = base + 0x40000u + threadIdx.x * 16u, near = base + (threadIdx.x & 3) * 16u;
+    f32x4 a, b;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(far), "v"(near) : "memory");
+    *(f32x4*)(out + threadIdx.x * 4) = a;
+    if (threadIdx.x == 0) *(f32x4*)(out + 256) = b;
+}
+}  // namespace
+extern "C" int alink_debug_lds_oob_probe(float* dev_out260, void* stream) {
+    hipLaunchKernelGGL(lds_oob_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_out260);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// 11 / 12 / 13 / 14: linear-tile kernel for 14 / 28 / 56 / 7-wide square maps (0 = not applicable)
 int linear_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout) {
     if (ksz != 3 || stride != 1 || pad != 1 || H != W || Cin % 64) return 0;
     if ((g_linear_mode & 4) && W == 14 && Cout % 128 == 0) return 11;
     if ((g_linear_mode & 2) && W == 28 && Cout % 128 == 0) return 12;
     if ((g_linear_mode & 1) && W == 56 && Cout % 64 == 0) return 13;
+    if ((g_linear_mode & 8) && W == 7 && Cout % 128 == 0) return 14;
     return 0;
 }
 int linear_variant_cpl(int v) { return v == 13 ? 8 : 17; }
@@ -338,7 +359,8 @@ hipError_t linear_set_attributes() {
 #define A(T)                                                              \
     if ((e = set_attr_one<T, 14, 4>()) != hipSuccess) return e;           \
     if ((e = set_attr_one<T, 28, 4>()) != hipSuccess) return e;           \
-    if ((e = set_attr_one<T, 56, 2>()) != hipSuccess) return e;
+    if ((e = set_attr_one<T, 56, 2>()) != hipSuccess) return e;           \
+    if ((e = set_attr_one<T, 7, 4>()) != hipSuccess) return e;
     A(__bf16) A(_Float16)
 #undef A
     return hipSuccess;
@@ -352,6 +374,7 @@ hipError_t launch_conv3x3_linear(int variant, int dtype, const ConvParams& p, hi
         case 11: return p.W == 14 ? L(14, 4) : hipErrorInvalidValue;
         case 12: return p.W == 28 ? L(28, 4) : hipErrorInvalidValue;
         case 13: return p.W == 56 ? L(56, 2) : hipErrorInvalidValue;
+        case 14: return p.W == 7 ? L(7, 4) : hipErrorInvalidValue;
     }
 #undef L
     return hipErrorInvalidValue;

@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--input", default="f32", choices=["f32", "u8"], help="pixel type resident in HBM")
     ap.add_argument("--streams", type=int, default=4, help="streams the chunks of one step are spread over")
-    ap.add_argument("--linear", type=int, default=-1, help="A/B: widths on linear pixel tiles (bit0 56, bit1 28, bit2 14)")
+    ap.add_argument("--linear", type=int, default=-1, help="A/B: widths on linear pixel tiles (bit0 56, bit1 28, bit2 14, bit3 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile / fine-tune timing")
     args = ap.parse_args()
@@ -172,7 +172,7 @@ def main():
         achieved_all = conv_fl[0] / (cms * 1e-3) / 1e12
         # the DOMINANT kernel: conv launches of one forward grouped by their algorithmic FLOPs (= same
         # shape = same kernel instantiation); the group with the most time.  For r100/r50 that is the
-        # 14x14x256->256 stage-3 convolution (conv3x3_direct_kernel, 4-wave variant, 2 workgroups/CU).
+        # 14x14x256->256 stage-3 convolution (conv3x3_linear_kernel; conv3x3_direct_kernel with --linear 0).
         # launch order of the chain: per stage s, unit u: conv1, [shortcut], conv2 (csrc/backbone.hip)
         shape_of = []
         for s_ in range(4):
@@ -196,11 +196,11 @@ def main():
         traffic = None
         try:
             import glob
-            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01d*pmc_hbm_traffic_%s_*.csv" % args.model)))
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_hbm_traffic_%s_*.csv" % args.model)))
             if pm:
                 rows = [ln.split(",") for ln in open(pm[-1]).read().splitlines()[1:]]
-                # the dominant instantiation is the conv3x3_direct row with the most launches per forward
-                rows = [r for r in rows if r[0] == "conv3x3_direct_kernel" and r[1]]
+                # the dominant instantiation is the 3x3 conv row with the most launches per forward
+                rows = [r for r in rows if r[0] in ("conv3x3_linear_kernel", "conv3x3_direct_kernel") and r[1]]
                 r = max(rows, key=lambda r: float(r[2]))
                 traffic = {"bytes_per_launch": (float(r[3]) + float(r[4])) * 1e6, "fetch_MB": float(r[3]),
                            "write_MB": float(r[4]), "launches_per_forward": float(r[2]), "per_images": 256,
@@ -211,8 +211,9 @@ def main():
         except Exception:
             traffic = None
         line["roofline"] = {"bound": "mfma",
-                            "kernel": "conv3x3_direct_kernel, %s: %d launches per %d-image forward, %.1f GFLOP each"
-                                      % (dom_name, len(dom_ms) // len(profs), args.chunk, dom_f / 1e9),
+                            "kernel": "%s, %s: %d launches per %d-image forward, %.1f GFLOP each"
+                                      % ("conv3x3_linear_kernel (linear 16-pixel tiles, 4 waves, 2 workgroups/CU)"
+                                         if (args.linear < 0 or args.linear & 4) else "conv3x3_direct_kernel", dom_name, len(dom_ms) // len(profs), args.chunk, dom_f / 1e9),
                             "achieved": dom_achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": dom_achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                             "flops_per_launch": dom_f, "avg_launch_ms": dom_avg,

@@ -55,16 +55,17 @@ LINEAR_CASES = [
     (11, 14, 14, 128, 256, 3, 1, 1, 1, 1, 1),   # 11 images: groups straddle image boundaries, ragged tail
     (3, 28, 28, 64, 128, 3, 1, 1, 1, 0, 1),
     (1, 56, 56, 64, 64, 3, 1, 1, 0, 1, 0),
+    (9, 7, 7, 128, 128, 3, 1, 1, 1, 1, 1),      # 16-pixel tiles span three rows; 4.6 images per group
 ]
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("dma,linear", [(1, -1), (0, -1), (1, 7)])
+@pytest.mark.parametrize("dma,linear", [(1, -1), (0, -1), (1, 0)])
 def test_conv_matches_cpu(gpu, dt, dma, linear):
     lib = gpu.load()
     lib.alink_debug_set_dma(dma)
     if linear >= 0:
-        lib.alink_debug_set_linear(linear)      # 7: the linear-tile kernel at every width it supports
+        lib.alink_debug_set_linear(linear)      # 0: row-aligned / implicit-GEMM kernels only (library default: linear tiles)
     tdt = torch.bfloat16 if dt == "bf16" else torch.float16
     code = gpu.DT_BF16 if dt == "bf16" else gpu.DT_F16
     g = torch.Generator().manual_seed(1234)
@@ -95,7 +96,7 @@ def test_conv_matches_cpu(gpu, dt, dma, linear):
                 (N, H, W, Ci, Co, k, s, p, border), dt, dma, float((err - tol).max()))
     finally:
         lib.alink_debug_set_dma(1)
-        lib.alink_debug_set_linear(1)           # library default: 56-wide maps only
+        lib.alink_debug_set_linear(15)          # library default: linear tiles at every width they support
 
 
 def test_conv_rejects_bad_shapes(gpu):

@@ -19,7 +19,7 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--ablate", type=int, default=0)
 ap.add_argument("--no-direct", action="store_true")
 ap.add_argument("--no-pair", action="store_true")
-ap.add_argument("--linear", type=int, default=-1, help="linear-tile widths: bit0 56, bit1 28, bit2 14 (default: library default)")
+ap.add_argument("--linear", type=int, default=-1, help="linear-tile widths: bit0 56, bit1 28, bit2 14, bit3 7 (default: library default)")
 a = ap.parse_args()
 units = W.ARCH_UNITS[a.model]
 from a_link_amd import _abi
