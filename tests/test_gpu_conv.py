@@ -105,3 +105,16 @@ def test_conv_rejects_bad_shapes(gpu):
     rc = lib.alink_conv_nhwc(0, gpu.ptr(x), gpu.ptr(x), gpu.ptr(x), None, None, gpu.ptr(x),
                              1, 4, 4, 32, 64, 3, 1, 1, 0, None)
     assert rc == -1 and b"multiples of 64" in lib.alink_last_error()
+
+
+def test_lds_out_of_range_read_is_zero(gpu):
+    """conv3x3_linear.hip sends border lanes to an address beyond the workgroup's LDS allocation and
+    relies on the DS read returning zero there (no fault): check that hardware contract directly."""
+    import ctypes as C
+    lib = gpu.load()
+    out = torch.full((260,), 7.0, device="cuda")
+    assert lib.alink_debug_lds_oob_probe(C.c_void_p(out.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    o = out.cpu()
+    assert (o[:256] == 0).all()                          # 64 lanes x 16 B read 256 KB past a 1 KB allocation
+    assert o[256:260].tolist() == [1.0, 2.0, 3.0, 4.0]   # the in-range read of the same instruction pair
