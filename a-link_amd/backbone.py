@@ -13,7 +13,7 @@ from . import weights as W
 
 
 class IRBackbone(object):
-    def __init__(self, params, image_size=(112, 112), emb=512, dtype="bf16", device=0, max_batch=256,
+    def __init__(self, params, image_size=(112, 112), emb=512, dtype="bf16", device=0, max_batch=292,
                  widths=W.WIDTHS, streams=4, shards_per_call=1, bn_eps=2e-5, enable_grad=False):
         import torch
         self.torch = torch
@@ -24,6 +24,8 @@ class IRBackbone(object):
         self.units = W.infer_units(params)
         self.emb = emb
         self.image_size = tuple(image_size)
+        # 292 images per launch: 292 x 196 pixels / 224 per workgroup x 2 channel halves = 511 workgroups of the
+        # 14-wide convolutions for the chip's 512 slots (1022 / 1024 at 28 wide) — a lone 256-image launch leaves 64 idle
         self.max_batch = int(max_batch)
         cfg = _abi.IRCfg()
         cfg.units[:] = list(self.units)

@@ -16,7 +16,7 @@ from . import weights as W
 from .backbone import IRBackbone
 
 
-def get_model(ctx, image_size, model_str, layer, dtype="bf16", max_batch=256, enable_grad=False):
+def get_model(ctx, image_size, model_str, layer, dtype="bf16", max_batch=292, enable_grad=False):
     assert layer == "fc1", "the reference slices the symbol at fc1_output (code/face_model.py:36,53)"
     params, cfg = W.resolve_model_config(model_str, image_size)
     device = ctx if isinstance(ctx, int) else 0

@@ -194,7 +194,7 @@ class RESNET50:
 
 
 class ArcFace:
-    def __init__(self, shape, model_path, dtype="bf16", max_batch=256, enable_grad=False):
+    def __init__(self, shape, model_path, dtype="bf16", max_batch=292, enable_grad=False):
         args = _Args({
             "enable_grad": enable_grad,
             "image_size": "%d,%d" % (shape[0], shape[1]),

@@ -47,8 +47,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="r100", choices=["r100", "r50", "r34", "r18"])
-    ap.add_argument("--batch", type=int, default=1024, help="images per step per GPU")
-    ap.add_argument("--chunk", type=int, default=256, help="images per alink_embed call (chunks of a step are "
+    ap.add_argument("--batch", type=int, default=1168, help="images per step per GPU")
+    ap.add_argument("--chunk", type=int, default=292, help="images per alink_embed call: 292 x 196 pixels = 511 workgroups of the "
+                    "14-wide linear-tile kernel for the chip's 512 slots, 1022 for 1024 at 28 wide (chunks of a step are "
                     "issued round-robin on --streams streams)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--input", default="f32", choices=["f32", "u8"], help="pixel type resident in HBM")
@@ -202,9 +203,11 @@ def main():
                 # the dominant instantiation is the 3x3 conv row with the most launches per forward
                 rows = [r for r in rows if r[0] in ("conv3x3_linear_kernel", "conv3x3_direct_kernel") and r[1]]
                 r = max(rows, key=lambda r: float(r[2]))
+                import re
+                nimg = int(re.search(r"_b(\d+)\.csv$", pm[-1]).group(1))       # images per launch of that profile
                 traffic = {"bytes_per_launch": (float(r[3]) + float(r[4])) * 1e6, "fetch_MB": float(r[3]),
-                           "write_MB": float(r[4]), "launches_per_forward": float(r[2]), "per_images": 256,
-                           "algorithmic_bytes_per_launch": 256 * 196 * 256 * 2 * 2.5 + 256 * 2304 * 2,
+                           "write_MB": float(r[4]), "launches_per_forward": float(r[2]), "per_images": nimg,
+                           "algorithmic_bytes_per_launch": nimg * 196 * 256 * 2 * 2.5 + 256 * 2304 * 2,
                            "note": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) and WRITE_SIZE, separate passes; "
                                    "algorithmic = input + output (+ residual on every second launch) + weights",
                            "source": os.path.basename(pm[-1])}
