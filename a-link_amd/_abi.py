@@ -43,6 +43,7 @@ PROTOTYPES = {
     "alink_backbone_workspace_bytes": (_sz, [_vp, _i]),
     "alink_embed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "alink_backbone_enable_grad": (_i, [_vp]),
+    "alink_backbone_set_small_batch_split": (_i, [_vp, _i]),
     "alink_backbone_grad_workspace_bytes": (_sz, [_vp, _i]),
     "alink_embed_cached": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "alink_embed_input_grad": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),

@@ -14,7 +14,8 @@ from . import weights as W
 
 class IRBackbone(object):
     def __init__(self, params, image_size=(112, 112), emb=512, dtype="bf16", device=0, max_batch=292,
-                 widths=W.WIDTHS, streams=4, shards_per_call=1, bn_eps=2e-5, enable_grad=False):
+                 widths=W.WIDTHS, streams=4, shards_per_call=1, bn_eps=2e-5, enable_grad=False,
+                 small_batch_split=False):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
@@ -38,6 +39,8 @@ class IRBackbone(object):
         self.h = self.lib.alink_backbone_create(C.byref(cfg))
         if not self.h:
             raise _abi.AlinkError("alink_backbone_create: " + self.lib.alink_last_error().decode())
+        if small_batch_split:      # latency mode: batches <= 32 split their convolutions over K (not bit-equal to fused)
+            _abi.check(self.lib.alink_backbone_set_small_batch_split(self.h, 1), "alink_backbone_set_small_batch_split")
         self.grad_enabled = bool(enable_grad)
         if enable_grad:
             _abi.check(self.lib.alink_backbone_enable_grad(self.h), "alink_backbone_enable_grad")

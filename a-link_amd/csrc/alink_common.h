@@ -82,6 +82,8 @@ struct FcFinishParams {
     int S, M, E;
 };
 hipError_t launch_fc_finish(const FcFinishParams& p, hipStream_t stream);
+// epilogue of a split-K convolution: p as for the fused launch (out = the real output), slabs [S][M][Cout] f32
+hipError_t launch_conv_split_finish(int dtype, const ConvParams& p, const float* slabs, int S, hipStream_t stream);
 
 // position of natural channel c (0..63 within its 64-block) in the permuted weight rows
 static inline int perm64_row_of_channel(int c) {

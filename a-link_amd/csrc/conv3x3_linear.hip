@@ -94,7 +94,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     const int wpx = wave >> 1, wco = wave & 1;
     const int q = lane >> 4, lr = lane & 15;
     const int H = p.H, Cin = p.Cin;
-    const int ncc = Cin >> 6, nk = ncc * 9;
+    // split mode (small batches: too few workgroups to fill the chip): blockIdx.y owns ncc / splitk of the
+    // 64-channel input chunks and leaves its f32 partial sums in slab blockIdx.y (conv_split_finish_kernel
+    // adds the slabs in order and applies the epilogue)
+    const int ncc_all = Cin >> 6;
+    const int ncc = ncc_all / p.splitk, cc_first = (int)blockIdx.y * ncc;
+    const int nk = ncc * 9;
     const int K = 9 * Cin;
     const long long totpix = (long long)p.N * H * W;
 
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     // ---- W staging (K-step order [cout][chunk][tap][64], as conv3x3_direct): slot s = tid + 256 i -> row
     // (tid >> 3) + 32 i, piece tid & 7, again with an i-independent swizzle term ------------------------------------
     const unsigned woff0 = (unsigned)((tid >> 3) * K + (((tid & 7) ^ ((tid >> 4) & 7)) * 8));
-    const T* wstep = gw + (size_t)n0 * K;                              // advanced by 64 elements per K-step (uniform)
+    const T* wstep = gw + (size_t)n0 * K + (size_t)cc_first * 9 * 64;   // advanced by 64 elements per K-step (uniform)
     auto stage_w = [&](int bufoff) {
 #pragma unroll
         for (int i = 0; i < WSLOTS; ++i)
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     for (int i = tid; i < ncls * BN; i += NT) ebias[i] = p.bias[(i / BN) * p.Cout + n0 + (i % BN)];
     if (p.alpha)
         for (int i = tid; i < BN; i += NT) ealpha[i] = p.alpha[n0 + i];
-    stage_x(0);
+    stage_x(cc_first);
     stage_w(0);
     wait_dma_then_barrier();
 
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
         if (cc + 1 < ncc) {
             // single X buffer: every wave is past its last read of this chunk; refill and wait — the
             // co-resident workgroup keeps the matrix cores busy meanwhile
-            stage_x(cc + 1);
+            stage_x(cc_first + cc + 1);
             wait_dma_then_barrier();
         }
     }
@@ -228,6 +233,18 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     const int wbase = wco * (16 * TCW);
     auto chan_t = [&](int t) { return wbase + (TCW == 4 ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) : 8 * q + 4 * t); };
     auto chan_h = [&](int h) { return wbase + (TCW == 4 ? 32 * h + 8 * q : 8 * q); };
+    if (p.splitk > 1) {
+        float* slab = (float*)p.out + (size_t)blockIdx.y * (size_t)totpix * p.Cout;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const long long gp = gp0 + 16 * (wpx * TPW + u) + dl;
+            if (gp < totpix) {
+#pragma unroll
+                for (int t = 0; t < TCW; ++t) *(f32x4*)(slab + (size_t)gp * p.Cout + n0 + chan_t(t)) = acc[t][u];
+            }
+        }
+        return;
+    }
     size_t off[TPW];
     bool ok[TPW];
     int cls[TPW];
@@ -304,7 +321,7 @@ hipError_t launch_one(const ConvParams& p, hipStream_t st) {
     const long long groups = (totpix + GPX - 1) / GPX;
     const long long nwg = groups * (p.Cout / G::BN);
     if (nwg <= 0 || nwg >= (1ll << 31)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW>), dim3((unsigned)nwg), dim3(NT), G::lds_bytes(), st, p);
+    hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW>), dim3((unsigned)nwg, (unsigned)p.splitk), dim3(NT), G::lds_bytes(), st, p);
     return hipGetLastError();
 }
 template <typename T, int W, int TCW>
@@ -367,7 +384,8 @@ hipError_t linear_set_attributes() {
 }
 
 hipError_t launch_conv3x3_linear(int variant, int dtype, const ConvParams& p, hipStream_t st) {
-    if (p.ksz != 3 || p.stride != 1 || p.pad != 1 || p.splitk != 1 || p.H != p.W) return hipErrorInvalidValue;
+    if (p.ksz != 3 || p.stride != 1 || p.pad != 1 || p.H != p.W) return hipErrorInvalidValue;
+    if (p.splitk < 1 || (p.Cin / 64) % p.splitk) return hipErrorInvalidValue;      // whole chunks per split
     if ((long long)p.N * p.H * p.W * p.Cin >= (1ll << 31)) return hipErrorInvalidValue;
 #define L(W_, TCW_) (dtype == ALINK_DT_BF16 ? launch_one<__bf16, W_, TCW_>(p, st) : launch_one<_Float16, W_, TCW_>(p, st))
     switch (variant) {

@@ -8,6 +8,8 @@
 //           that the reference does on the host with sklearn (code/face_model.py:92).
 #include "alink_common.h"
 
+#include <type_traits>
+
 namespace alink {
 namespace {
 
@@ -149,6 +151,53 @@ __global__ __launch_bounds__(256) void fc_finish_kernel(const FcFinishParams p) 
     }
 }
 
+// Split-K convolutions (small batches): out[m][c] = epilogue(sum_z slab[z][m][c]) with the epilogue of the conv
+// kernels — folded-BN bias by border class, PReLU | PReLU' of the stored activation, residual, ReLU.
+// One thread per pixel and 8 consecutive channels; slabs are added in slab order (bit-reproducible).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_split_finish_kernel(const ConvParams p, const float* __restrict__ slabs, int S) {
+    typedef typename std::conditional<std::is_same<T, __bf16>::value, bf16x8, f16x8>::type vec8;
+    const int c8n = p.Cout >> 3;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)p.M * c8n) return;
+    const int m = (int)(i / c8n), c0 = (int)(i % c8n) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int z = 0; z < S; ++z) {
+        const float* sp = slabs + ((size_t)z * p.M + m) * p.Cout + c0;
+        const f32x4 a = *(const f32x4*)sp, b = *(const f32x4*)(sp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += a[j]; v[4 + j] += b[j]; }
+    }
+    int cls = 0;
+    if (p.border_cls) {
+        const int rem = m % (p.Ho * p.Wo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        cls = ((oy == 0) ? 0 : ((oy == p.Ho - 1) ? 2 : 1)) * 3 + ((ox == 0) ? 0 : ((ox == p.Wo - 1) ? 2 : 1));
+    }
+    const size_t off = (size_t)m * p.Cout + c0;
+    const T* extra = (const T*)(p.dact ? p.dact : p.resid);
+    vec8 e8;
+    if (extra) e8 = *(const vec8*)(extra + off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float x = v[j] + p.bias[(size_t)cls * p.Cout + c0 + j];
+        if (p.dact) {
+            x *= (float)e8[j] > 0.f ? 1.f : p.alpha[c0 + j];
+        } else {
+            if (p.alpha) x = x > 0.f ? x : x * p.alpha[c0 + j];
+            if (p.resid) x += (float)e8[j];
+        }
+        if (p.post_relu) x = fmaxf(x, 0.f);
+        v[j] = x;
+    }
+    vec8 o8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o8[j] = (T)v[j];
+    *(vec8*)((T*)p.out + off) = o8;
+}
+
 template <typename T>
 hipError_t launch_stem_t(const StemParams& p, hipStream_t stream) {
     const int RP = ((p.W + 2) * 3 + 7) & ~7;
@@ -174,6 +223,16 @@ hipError_t launch_stem(int dtype, const StemParams& p, hipStream_t stream) {
     if (dtype == ALINK_DT_BF16) return launch_stem_t<__bf16>(p, stream);
     if (dtype == ALINK_DT_F16) return launch_stem_t<_Float16>(p, stream);
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv_split_finish(int dtype, const ConvParams& p, const float* slabs, int S, hipStream_t stream) {
+    if (p.Cout % 8 || p.M <= 0 || S < 2 || !slabs) return hipErrorInvalidValue;
+    const long long tot = (long long)p.M * (p.Cout / 8);
+    dim3 grid((unsigned)((tot + 255) / 256), 1, 1), block(256, 1, 1);
+    if (dtype == ALINK_DT_BF16) hipLaunchKernelGGL(conv_split_finish_kernel<__bf16>, grid, block, 0, stream, p, slabs, S);
+    else if (dtype == ALINK_DT_F16) hipLaunchKernelGGL(conv_split_finish_kernel<_Float16>, grid, block, 0, stream, p, slabs, S);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 hipError_t launch_fc_finish(const FcFinishParams& p, hipStream_t stream) {

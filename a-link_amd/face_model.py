@@ -16,12 +16,14 @@ from . import weights as W
 from .backbone import IRBackbone
 
 
-def get_model(ctx, image_size, model_str, layer, dtype="bf16", max_batch=292, enable_grad=False):
+def get_model(ctx, image_size, model_str, layer, dtype="bf16", max_batch=292, enable_grad=False,
+              small_batch_split=False):
     assert layer == "fc1", "the reference slices the symbol at fc1_output (code/face_model.py:36,53)"
     params, cfg = W.resolve_model_config(model_str, image_size)
     device = ctx if isinstance(ctx, int) else 0
     return IRBackbone(params, image_size=image_size, emb=cfg["emb"], dtype=dtype, device=device, max_batch=max_batch,
-                      widths=cfg["widths"], bn_eps=cfg["bn_eps"], enable_grad=enable_grad)
+                      widths=cfg["widths"], bn_eps=cfg["bn_eps"], enable_grad=enable_grad,
+                      small_batch_split=small_batch_split)
 
 
 class FaceModel(object):
@@ -35,8 +37,9 @@ class FaceModel(object):
         if len(args.model) > 0:
             self.model = get_model(getattr(args, "gpu", 0), image_size, args.model, 'fc1',
                                    dtype=getattr(args, "dtype", "bf16"),
-                                   max_batch=getattr(args, "max_batch", 256),
-                                   enable_grad=bool(args.get("enable_grad", False)) if hasattr(args, "get") else False)
+                                   max_batch=getattr(args, "max_batch", 292),
+                                   enable_grad=bool(args.get("enable_grad", False)) if hasattr(args, "get") else False,
+                                   small_batch_split=bool(args.get("small_batch_split", False)) if hasattr(args, "get") else False)
         self.threshold = args.threshold
         self.det_minsize = 50
         self.det_threshold = [0.6, 0.7, 0.8]

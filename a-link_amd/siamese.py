@@ -194,9 +194,10 @@ class RESNET50:
 
 
 class ArcFace:
-    def __init__(self, shape, model_path, dtype="bf16", max_batch=292, enable_grad=False):
+    def __init__(self, shape, model_path, dtype="bf16", max_batch=292, enable_grad=False, small_batch_split=False):
         args = _Args({
             "enable_grad": enable_grad,
+            "small_batch_split": small_batch_split,   # latency mode for batches <= 32 (include/alink_hip.h)
             "image_size": "%d,%d" % (shape[0], shape[1]),
             "model": model_path + ",0",
             "gpu": 0,

@@ -107,6 +107,14 @@ int alink_embed_profile(alink_backbone_t* bb, const void* dev_in, int layout, in
  * alink_embed_input_grad then maps dev_demb = d(loss)/d(embedding) (n x emb, w.r.t. the L2-normalised
  * output dev_emb of that forward) to dev_dpix = d(loss)/d(pixel) (n images, float32, NHWC or NCHW). */
 int alink_backbone_enable_grad(alink_backbone_t* bb);
+
+/* Latency mode for batches of <= 32 images (FaceModel.get_feature is a batch-1 call: code/face_model.py:86-93).
+ * A 3x3 layer at batch 1 has a handful of workgroups that each walk all of K; with the switch on such layers
+ * are split over K into f32 partial slabs added in a fixed order (batch 1: 3.1 -> 1.9 ms, batch 16: 3.25 ->
+ * 2.7 ms on IR-ResNet-100).  Default OFF: a split sum rounds differently from the fused one, so an image's
+ * embedding would no longer be bit-identical whatever batch it arrives in.  Changes the workspace size:
+ * query alink_backbone_workspace_bytes after setting it. */
+int alink_backbone_set_small_batch_split(alink_backbone_t* bb, int on);
 size_t alink_backbone_grad_workspace_bytes(const alink_backbone_t* bb, int n_images);
 int alink_embed_cached(alink_backbone_t* bb, const void* dev_in, int layout, int n_images, float* dev_out,
                        void* dev_workspace, size_t workspace_bytes, void* stream);

@@ -165,3 +165,25 @@ def test_headline_depth_parity_r100_and_f16_range(gpu):
     assert (1.0 - (got * ref).sum(1)).max() < 1e-3
     with pytest.raises(_abi.AlinkError):
         IRBackbone(params, dtype="f16", max_batch=4).embed(x)
+
+
+def test_small_batch_split_k_matches_fused(gpu):
+    """Small batches run their few-workgroup convolutions split over K into f32 slabs that
+    conv_split_finish_kernel adds in order (csrc/backbone.hip plan_split): same embeddings as the fused
+    launches up to float summation order, at IR-50 depth, for batch 1, 5 and 32."""
+    from a_link_amd import _abi, weights as W
+    from a_link_amd.backbone import IRBackbone
+    params = W.synthetic_ir_params(W.ARCH_UNITS["r50"], seed=2)
+    x = np.random.default_rng(3).integers(0, 256, (32, 112, 112, 3)).astype(np.float32)
+    fused = IRBackbone(params, dtype="bf16", max_batch=32)
+    split = IRBackbone(params, dtype="bf16", max_batch=32, small_batch_split=True)
+    from oracle import ir_resnet
+    ref = ir_resnet.embed(params, x[:2], batch=2).astype(np.float64)
+    for n in (1, 5, 32):
+        a = split.embed(x[:n]).astype(np.float64)
+        b = fused.embed(x[:n]).astype(np.float64)
+        assert np.allclose(np.linalg.norm(a, axis=1), 1.0, atol=1e-5)
+        # two bf16 computations that round differently: each within ~1.4e-4 of the f32 oracle at this depth
+        assert (1.0 - (a * b).sum(1)).max() < 5e-4, n
+        assert (1.0 - (a[:2] * ref[:min(n, 2)]).sum(1)).max() < 1e-3, n
+    assert not np.array_equal(split.embed(x[:1]), fused.embed(x[:1]))   # the split path did run

@@ -11,7 +11,7 @@ import torch
 import a_link_amd  # noqa
 from a_link_amd import siamese
 
-fm = siamese.ArcFace((112, 112), "synthetic:r100")
+fm = siamese.ArcFace((112, 112), "synthetic:r100", small_batch_split="--split" in sys.argv)
 net = siamese.SiameseNetwork((512,), "m", 0.1, seed=0)
 rng = np.random.RandomState(0)
 
@@ -27,7 +27,7 @@ def med(fn, reps=30):
 img = rng.randint(0, 256, (112, 112, 3)).astype(np.float32)
 chw = fm.model.get_input(img)
 print("FaceModel.get_feature (1 image, host in/out): %.3f ms" % med(lambda: fm.model.get_feature(chw)))
-for n in (1, 8, 64):
+for n in (1, 4, 8, 16, 32, 64):
     x = rng.randint(0, 256, (n, 112, 112, 3)).astype(np.float32)
     xd = torch.from_numpy(x).cuda()
     print("ArcFace.process n=%d: host arrays %.3f ms, device tensors %.3f ms" % (

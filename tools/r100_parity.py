@@ -15,7 +15,7 @@ for arch in ("r50", "r100"):
     params = W.synthetic_ir_params(W.ARCH_UNITS[arch], seed=1)
     x = np.random.default_rng(0).integers(0, 256, (8, 112, 112, 3)).astype(np.float32)
     ref = ir_resnet.embed(params, x, batch=8).astype(np.float64)
-    for dtype in ("bf16", "f16"):
+    for dtype in ("bf16",):    # f16 overflows on these synthetic weights (IRBackbone raises): see tests/test_gpu_backbone.py
         got = IRBackbone(params, dtype=dtype, max_batch=8).embed(x).astype(np.float64)
         cos = 1.0 - (got * ref).sum(1)
         print("%s %s: 1 - cos  max %.3e  mean %.3e ; |norm - 1| max %.1e" % (arch, dtype, cos.max(), cos.mean(),
