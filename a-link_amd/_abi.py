@@ -147,8 +147,17 @@ def check(rc, what=""):
         raise AlinkError("%s failed (%d): %s" % (what or "alink call", rc, msg.decode() if msg else "?"))
 
 
+def resolve_device(device):
+    """None -> the process's current torch device (one process per GPU: torch.cuda.set_device(LOCAL_RANK))."""
+    if device is None:
+        import torch
+        return int(torch.cuda.current_device())
+    return int(device)
+
+
 def init(device=0):
     """alink_init on `device` (once per device).  Raises if no GPU is visible."""
+    device = resolve_device(device)
     lib = load()
     if device not in _inited_devices:
         check(lib.alink_init(int(device)), "alink_init")

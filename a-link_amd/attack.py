@@ -21,10 +21,11 @@ from . import _abi
 from .differential_evolution import differential_evolution
 
 
-def _perturb_device(xs, img_dev, split, device=0):
+def _perturb_device(xs, img_dev, split, device=None):
     """xs (n, 5k) float64 host, img_dev (Hc, W, 3) f32 device -> device tensor
     (n, Hc, W, 3) or, split, (2, n, Hc/2, W, 3)."""
     import torch
+    device = _abi.resolve_device(device)
     lib = _abi.init(device)
     xs = np.ascontiguousarray(np.asarray(xs, dtype=np.float64))
     n, m = xs.shape
@@ -41,7 +42,7 @@ def _perturb_device(xs, img_dev, split, device=0):
     return out
 
 
-def perturb_image(xs, img, device=0):
+def perturb_image(xs, img, device=None):
     """n perturbation vectors [x, y, r, g, b] * k -> n perturbed copies of img (code/attack.py:5-29).
     NumPy in -> NumPy out (float32); CUDA tensor image in -> CUDA tensor out."""
     import torch
@@ -49,6 +50,7 @@ def perturb_image(xs, img, device=0):
     if xs.ndim < 2:
         xs = np.array([xs])
     as_torch = isinstance(img, torch.Tensor)
+    device = _abi.resolve_device(device)
     img_d = img.to("cuda:%d" % device, torch.float32).contiguous() if as_torch else \
         torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)).to("cuda:%d" % device)
     r = xs.astype(int)[:, 0::5] if xs.shape[1] >= 5 else np.zeros((len(xs), 0), int)
@@ -63,7 +65,7 @@ def perturb_image(xs, img, device=0):
 class _DevicePairScorer(object):
     """The fused objective: population -> P(class) of the perturbed pair, all on device."""
 
-    def __init__(self, wrapped, image, device=0):
+    def __init__(self, wrapped, image, device=None):
         import torch
         from .head import DenseHead
         fm = getattr(wrapped, "feature_model", None)
@@ -78,6 +80,7 @@ class _DevicePairScorer(object):
         Hc, W, _ = image.shape
         if Hc % 2 or (Hc // 2, W) != tuple(bb.image_size):
             raise TypeError("stacked pair image %s does not match the backbone input" % (image.shape,))
+        device = _abi.resolve_device(device)
         self.img = torch.from_numpy(np.ascontiguousarray(image)).to("cuda:%d" % device)
         self.device = device
 

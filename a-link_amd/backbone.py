@@ -13,13 +13,14 @@ from . import weights as W
 
 
 class IRBackbone(object):
-    def __init__(self, params, image_size=(112, 112), emb=512, dtype="bf16", device=0, max_batch=292,
+    def __init__(self, params, image_size=(112, 112), emb=512, dtype="bf16", device=None, max_batch=292,
                  widths=W.WIDTHS, streams=4, shards_per_call=1, bn_eps=2e-5, enable_grad=False,
                  small_batch_split=False):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
             raise _abi.AlinkError("no ROCm device visible: a-link_amd computes only on the GPU (no CPU fallback)")
+        device = _abi.resolve_device(device)          # None: the current torch device
         self.device = device
         self.lib = _abi.init(device)
         self.units = W.infer_units(params)

@@ -55,10 +55,11 @@ def score_matrix(model, features, col=0, out=None, rows_per_call=1024):
     return out if as_torch else out.cpu().numpy()
 
 
-def roc_counts(score_matrix, mask, thresholds, roc_case, device=0):
+def roc_counts(score_matrix, mask, thresholds, roc_case, device=None):
     """(true_positive, false_positive, n_genuine, n_impostor): integer counts per threshold (in the
     order given) over the strict upper triangle — the loop bodies of ROC_precompute.py:24-61."""
     import torch
+    device = _abi.resolve_device(device)
     lib = _abi.init(device)
     dev = "cuda:%d" % device
     S = score_matrix if isinstance(score_matrix, torch.Tensor) else torch.from_numpy(
@@ -86,7 +87,7 @@ def roc_counts(score_matrix, mask, thresholds, roc_case, device=0):
     return tp, fp, int(h[0].sum()), int(h[1].sum())
 
 
-def roc_precompute(score_matrix, mask, thresholds, roc_case, device=0):
+def roc_precompute(score_matrix, mask, thresholds, roc_case, device=None):
     """-> (true_positive_rate, false_positive_rate) as ROC_precompute.py:51-66 saves them."""
     tp, fp, ng, ni = roc_counts(score_matrix, mask, thresholds, roc_case, device)
     if ni == 0 or ng == 0:

@@ -145,11 +145,12 @@ class DenseHead(KerasFitMixin):
     """abs(l - r) -> Dense(h1, relu) -> Dense(h2, relu) -> Dense(2) -> softmax; BCE + Adadelta.
     out_dim=1 is the baseline scripts' variant: Dense(1, sigmoid) (reference code/siamese3.py:25)."""
 
-    def __init__(self, d_in, h1=512, h2=64, lr=1.0, rho=0.95, eps=1e-8, seed=None, device=0, out_dim=2):
+    def __init__(self, d_in, h1=512, h2=64, lr=1.0, rho=0.95, eps=1e-8, seed=None, device=None, out_dim=2):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
             raise _abi.AlinkError("no ROCm device visible: a-link_amd computes only on the GPU (no CPU fallback)")
+        device = _abi.resolve_device(device)          # None: the current torch device
         self.device = "cuda:%d" % device
         self.lib = _abi.init(device)
         self.d_in, self.h1, self.h2, self.out_dim = int(d_in), int(h1), int(h2), int(out_dim)

@@ -38,11 +38,11 @@ def _ret(t, as_torch):
 
 
 class Noise(object):
-    def __init__(self, model=None, sess=None, feature_model=None, seed=None, device=0):
+    def __init__(self, model=None, sess=None, feature_model=None, seed=None, device=None):
         self.model = model
         self.sess = sess
         self.feature_model = feature_model
-        self.device = device
+        self.device = _abi.resolve_device(device)         # None: the current torch device
         self._seed = int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else int(seed)
         self._calls = 0
 
@@ -76,7 +76,7 @@ class Noise(object):
 
 
 class Gaussian(Noise):
-    def __init__(self, mean=10, var=10, model=None, sess=None, feature_model=None, seed=None, device=0):
+    def __init__(self, mean=10, var=10, model=None, sess=None, feature_model=None, seed=None, device=None):
         super(Gaussian, self).__init__(seed=seed, device=device)
         self.mean = mean
         self.var = var
@@ -92,7 +92,7 @@ class Gaussian(Noise):
 
 
 class Speckle(Noise):
-    def __init__(self, model=None, sess=None, feature_model=None, seed=None, device=0):
+    def __init__(self, model=None, sess=None, feature_model=None, seed=None, device=None):
         super(Speckle, self).__init__(seed=seed, device=device)
 
     def _apply(self, x):
@@ -105,7 +105,7 @@ class Speckle(Noise):
 
 
 class SaltPepper(Noise):
-    def __init__(self, s_vs_p=0.5, amount=0.004, model=None, sess=None, feature_model=None, seed=None, device=0):
+    def __init__(self, s_vs_p=0.5, amount=0.004, model=None, sess=None, feature_model=None, seed=None, device=None):
         super(SaltPepper, self).__init__(seed=seed, device=device)
         self.s_vs_p = s_vs_p
         self.amount = amount
@@ -128,7 +128,7 @@ class SaltPepper(Noise):
 
 
 class Poisson(Noise):
-    def __init__(self, model=None, sess=None, feature_model=None, seed=None, device=0):
+    def __init__(self, model=None, sess=None, feature_model=None, seed=None, device=None):
         super(Poisson, self).__init__(seed=seed, device=device)
         self.last_vals = None
 
@@ -150,7 +150,7 @@ class Poisson(Noise):
 
 
 class Perlin(Noise):
-    def __init__(self, model=None, sess=None, feature_model=None, seed=None, device=0):
+    def __init__(self, model=None, sess=None, feature_model=None, seed=None, device=None):
         super(Perlin, self).__init__(seed=seed, device=device)
 
     @staticmethod
@@ -182,12 +182,13 @@ class Perlin(Noise):
         return out
 
 
-def resize_images(images, new_size, device=0):
+def resize_images(images, new_size, device=None):
     """cv2.resize(image, new_size) per image (code/committee.py:22-26; readMTP.resizeImages,
     code/readMTP.py:116-119): new_size = (width, height), bilinear."""
     import torch
     if len(images) == 0:
         return np.array(images)
+    device = _abi.resolve_device(device)
     x, as_torch = _as_device(images if not isinstance(images, (list, tuple)) else np.stack(images), device)
     n, H, W, Cc = x.shape
     Wo, Ho = int(new_size[0]), int(new_size[1])
@@ -221,7 +222,7 @@ class PredictionWrappedModel:
 
 
 class AdversarialNoise(Noise):
-    def __init__(self, model, sess, feature_model, seed=None, device=0):
+    def __init__(self, model, sess, feature_model, seed=None, device=None):
         super(AdversarialNoise, self).__init__(model, sess, feature_model, seed=seed, device=device)
         from . import attack
         self.e2e_model = PredictionWrappedModel(model, feature_model)
@@ -250,7 +251,7 @@ class FGSM(Noise):
     steps, alpha, random_start = 1, None, False
 
     def __init__(self, model=None, sess=None, feature_model=None, eps=4.0, targeted=True, clip=(0.0, 255.0),
-                 seed=None, device=0):
+                 seed=None, device=None):
         super(FGSM, self).__init__(model, sess, feature_model, seed=seed, device=device)
         self.eps, self.targeted, self.clip = float(eps), bool(targeted), clip
 
@@ -314,7 +315,7 @@ class PGD(FGSM):
     eps-ball (Madry et al. 2018), optional uniform random start."""
 
     def __init__(self, model=None, sess=None, feature_model=None, eps=4.0, alpha=1.0, steps=5, random_start=True,
-                 targeted=True, clip=(0.0, 255.0), seed=None, device=0):
+                 targeted=True, clip=(0.0, 255.0), seed=None, device=None):
         super(PGD, self).__init__(model, sess, feature_model, eps=eps, targeted=targeted, clip=clip, seed=seed,
                                   device=device)
         self.alpha, self.steps, self.random_start = float(alpha), int(steps), bool(random_start)

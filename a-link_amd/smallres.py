@@ -17,11 +17,12 @@ MAXN = 256
 
 
 class SmallResNet(KerasFitMixin):
-    def __init__(self, image_shape, feat, lr=1.0, rho=0.95, eps=1e-8, seed=None, device=0, prescale=False):
+    def __init__(self, image_shape, feat, lr=1.0, rho=0.95, eps=1e-8, seed=None, device=None, prescale=False):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
             raise _abi.AlinkError("no ROCm device visible: a-link_amd computes only on the GPU (no CPU fallback)")
+        device = _abi.resolve_device(device)          # None: the current torch device
         self.device = "cuda:%d" % device
         self.lib = _abi.init(device)
         self.H, self.W = int(image_shape[0]), int(image_shape[1])

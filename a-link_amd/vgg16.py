@@ -56,11 +56,12 @@ def save_keras_h5(path, params):
 
 
 class VGGFace16(object):
-    def __init__(self, image_size=(224, 224), weights=None, dtype="bf16", device=0, max_batch=64, seed=1):
+    def __init__(self, image_size=(224, 224), weights=None, dtype="bf16", device=None, max_batch=64, seed=1):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
             raise _abi.AlinkError("no ROCm device visible: a-link_amd computes only on the GPU (no CPU fallback)")
+        device = _abi.resolve_device(device)          # None: the current torch device
         self.device = device
         self.lib = _abi.init(device)
         self.image_size = tuple(image_size)

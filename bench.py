@@ -138,7 +138,7 @@ def main():
         # all-reduce of the flat gradient buffer (+ metrics), identical Adadelta update on every rank
         from a_link_amd import distributed as D
         from a_link_amd.head import DenseHead
-        hdp = DenseHead(512, lr=0.1, seed=0)
+        hdp = DenseHead(512, lr=0.1, seed=0, device=local_rank)
         rng = np.random.RandomState(0)
         Ld = torch.from_numpy(rng.randn(16, 512).astype(np.float32)).cuda()
         Rd = torch.from_numpy(rng.randn(16, 512).astype(np.float32)).cuda()
@@ -229,7 +229,7 @@ def main():
                                                   "non_conv_ms_per_forward": float(np.median(other_ms))}}
         # ---- fine-tune step (second half of BASELINE.json's metric): head-512, batch 16
         from a_link_amd.head import DenseHead
-        hd = DenseHead(512, lr=0.1, seed=0)
+        hd = DenseHead(512, lr=0.1, seed=0, device=local_rank)
         rng = np.random.RandomState(0)
         L = torch.from_numpy(rng.randn(16, 512).astype(np.float32)).cuda()
         R = torch.from_numpy(rng.randn(16, 512).astype(np.float32)).cuda()
