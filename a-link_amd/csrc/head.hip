@@ -634,6 +634,16 @@ constexpr int TINY_PART = 2 + 64 * 2 + 2 + 4;   // floats one row group leaves: 
 // a_s: [TINY_RG][K] activations in LDS; w: [K][C] row-major; the thread's columns are c0 + 4*cl ...
 // All 16 weight loads of a 16-deep K chunk are in flight together.  K % 512 == 0.
 // Result: out[r * 64 + c] (c < 64) in `fin` (LDS, TINY_RG * 64 floats), summed in a fixed order.
+// sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), result in every lane: four v_add_f32 with a
+// DPP operand (quad xor 1, quad xor 2, half-row mirror, row mirror) — no LDS crossbar (ds_bpermute) traffic
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
 __device__ __forceinline__ const float* tiny_w_ptr(const float* __restrict__ w, int K, int C, int c0) {
     const int tid = threadIdx.x, cl = tid & 15, ks = tid >> 4;
     return w + (size_t)(ks * (K >> 5)) * C + c0 + cl * 4;
@@ -780,8 +790,9 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
     tiny_dense_core(a_s, h1, wp, 64, wv, red, z2s);
     // dZ1 below walks W2 in chunks of 128 rows staged through LDS (coalesced 16-B loads here, padded rows
     // read back per thread): the first chunk is fetched now, under the loss computation
+    const bool w2_in_regs = h1 == 512;       // one 16-deep chunk per thread: wv still holds this thread's share of W2
     f32x4 wc[4];
-    if (p.want_grads) {
+    if (p.want_grads && !w2_in_regs) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) wc[i] = *(const f32x4*)(p.w2 + (size_t)(tid + 512 * i) * 4);
     }
@@ -804,11 +815,8 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
             z[0] = fmaf(v, w3s[c * od + 0], z[0]);
             if (od == 2) z[1] = fmaf(v, w3s[c * od + 1], z[1]);
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            z[0] += __shfl_xor(z[0], o, 64);
-            z[1] += __shfl_xor(z[1], o, 64);
-        }
+        z[0] = row16_sum(z[0]);
+        z[1] = row16_sum(z[1]);
         if (l == 0) {
             float li = 0.f, ai = 0.f, d3[2] = {0.f, 0.f};
             if (row < n) {
@@ -898,8 +906,32 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
         part[2 + t] = s;
     }
     __syncthreads();
-    // dZ1[row][k] = (z1 > 0) * sum_j dZ2[row][j] W2[k][j].  Chunk of 128 W2 rows in LDS with a row pitch of
-    // 68 floats (16-B reads of 16 consecutive rows then fall on distinct banks); thread = (k, row).
+    // dZ1[row][k] = (z1 > 0) * sum_j dZ2[row][j] W2[k][j].
+    if (w2_in_regs) {
+        // The forward left W2[16 ks + i][4 cl .. 4 cl + 3] (i < 16) in this thread's registers: its four columns'
+        // share of the dot for its 16 rows k, summed over the 16 column lanes (one DPP row) by row16_sum — no
+        // second pass over W2 and no LDS traffic beyond the 4 x 16 B of dZ2.
+        const int cl = tid & 15, ks = tid >> 4;
+#pragma unroll
+        for (int r = 0; r < TINY_RG; ++r) {
+            const f32x4 dv = *(const f32x4*)(dz2s + r * 64 + cl * 4);
+            float mine = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float sdot = dv[0] * wv[i][0];
+                sdot = fmaf(dv[1], wv[i][1], sdot);
+                sdot = fmaf(dv[2], wv[i][2], sdot);
+                sdot = fmaf(dv[3], wv[i][3], sdot);
+                sdot = row16_sum(sdot);
+                if (cl == i) mine = sdot;         // lane i of the row keeps (and stores) W2 row 16 ks + i
+            }
+            const int k = ks * 16 + cl;
+            if (r0 + r < n) p.dz1[(size_t)(r0 + r) * h1 + k] = a_s[r * h1 + k] > 0.f ? mine : 0.f;
+        }
+        return;
+    }
+    // general h1: chunks of 128 W2 rows in LDS with a row pitch of 68 floats (16-B reads of 16 consecutive rows
+    // then fall on distinct banks); thread = (k, row).
     float* w2s = a_s + TINY_RG * h1 + 8 * TINY_RG * 64 + TINY_RG * 64 + 192;     // [128][68], after everything else
     const int kq = tid & 127, rq = tid >> 7;
     for (int kc = 0; kc < h1; kc += 128) {
