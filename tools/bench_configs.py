@@ -81,6 +81,7 @@ def config4(out, noises):
     conv = siamese.ArcFace((112, 112), "synthetic:r100")
     student = siamese.SiameseNetwork((512,), "/tmp/alink_student", 0.1, seed=1)
     ens = [siamese.SiameseNetwork((512,), "e1", 0.1, seed=2)]
+    np.random.seed(0)                                    # the noise objects draw their Philox seeds at construction
     nz = [noise.get_relevant_noise(n)(model=student, sess=None, feature_model=conv) for n in noises]
     bag = committee.Bagging(ens, nz)
     X_plain, X_dig = _people(16, 2, 1), _people(16, 3, 2)
