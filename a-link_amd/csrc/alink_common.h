@@ -117,6 +117,7 @@ hipError_t launch_conv3x3_direct(int variant, int dtype, const ConvParams& p, hi
 int        linear_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout);
 int        linear_variant_cpl(int v);
 hipError_t linear_set_attributes();
+hipError_t linear_check_contract();   // probes the LDS out-of-range read contract; disables the linear kernel if it fails
 hipError_t launch_conv3x3_linear(int variant, int dtype, const ConvParams& p, hipStream_t st);
 
 // backward.hip (input-gradient pass)

@@ -68,6 +68,8 @@ int init_kernels() {
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute", __FILE__, __LINE__);
     e = direct_set_attributes();
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(direct)", __FILE__, __LINE__);
+    e = linear_check_contract();
+    if (e != hipSuccess) return hip_fail(e, "LDS out-of-range read probe", __FILE__, __LINE__);
     return ALINK_OK;
 }
 

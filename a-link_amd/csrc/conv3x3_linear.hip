@@ -355,6 +355,28 @@ __global__ void lds_oob_probe_kernel(float* out) {
     if (threadIdx.x == 0) *(f32x4*)(out + 256) = b;
 }
 }  // namespace
+// Run once per device at alink_init: the linear-tile kernel is used only where the contract it rests on holds
+// (otherwise every width falls back to the row-aligned / implicit-GEMM kernels, which need no such contract).
+hipError_t linear_check_contract() {
+    float* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, 260 * sizeof(float));
+    if (e != hipSuccess) return e;
+    float h[260];
+    for (int i = 0; i < 260; ++i) h[i] = 7.f;
+    e = hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(lds_oob_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return e;
+    bool ok = h[256] == 1.f && h[257] == 2.f && h[258] == 3.f && h[259] == 4.f;
+    for (int i = 0; i < 256; ++i) ok = ok && h[i] == 0.f;
+    if (!ok) g_linear_mode = 0;
+    return hipSuccess;
+}
+
 extern "C" int alink_debug_lds_oob_probe(float* dev_out260, void* stream) {
     hipLaunchKernelGGL(lds_oob_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_out260);
     return hipGetLastError() == hipSuccess ? 0 : -1;
