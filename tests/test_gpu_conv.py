@@ -118,3 +118,36 @@ def test_lds_out_of_range_read_is_zero(gpu):
     o = out.cpu()
     assert (o[:256] == 0).all()                          # 64 lanes x 16 B read 256 KB past a 1 KB allocation
     assert o[256:260].tolist() == [1.0, 2.0, 3.0, 4.0]   # the in-range read of the same instruction pair
+
+
+def test_linear_kernel_fuzz(gpu):
+    """Seeded sweep of the linear-tile kernel: every width it serves, batch sizes whose pixel count is not a
+    multiple of the 224-pixel group (tail groups, image boundaries at every phase inside a group), one to
+    four input chunks, all epilogue modes."""
+    lib = gpu.load()
+    rng = np.random.RandomState(2024)
+    g = torch.Generator().manual_seed(99)
+    for case in range(24):
+        W = [7, 14, 28, 56][case % 4]
+        N = int(rng.randint(1, {7: 40, 14: 24, 28: 7, 56: 3}[W] + 1))
+        Ci = 64 * int(rng.randint(1, 5 if W <= 14 else 3))
+        Co = 64 if W == 56 else 128 * int(rng.randint(1, 3))
+        border, use_alpha, use_resid = int(rng.randint(0, 2)), int(rng.randint(0, 2)), int(rng.randint(0, 2))
+        x = torch.randn(N, W, W, Ci, generator=g).to(torch.bfloat16)
+        w = (torch.randn(Co, 3, 3, Ci, generator=g) * (1.0 / np.sqrt(9 * Ci))).to(torch.bfloat16)
+        bias = torch.randn(9 if border else 1, Co, generator=g)
+        alpha = torch.rand(Co, generator=g) * 0.5 if use_alpha else None
+        resid = torch.randn(N, W, W, Co, generator=g).to(torch.bfloat16) if use_resid else None
+        ref = _ref(x.float(), w.float(), bias, alpha, resid.float() if use_resid else None, 1, 1, border)
+        out = torch.full((N, W, W, Co), float("nan"), dtype=torch.bfloat16, device="cuda")
+        xd, wd, bd = x.cuda(), w.cuda(), bias.cuda()
+        ad = alpha.cuda() if use_alpha else None
+        rd = resid.cuda() if use_resid else None
+        gpu.check(lib.alink_conv_nhwc(gpu.DT_BF16, gpu.ptr(xd), gpu.ptr(wd), gpu.ptr(bd), gpu.ptr(ad), gpu.ptr(rd),
+                                      gpu.ptr(out), N, W, W, Ci, Co, 3, 1, 1, border, None), "alink_conv_nhwc")
+        got = out.float().cpu()
+        assert torch.isfinite(got).all(), (case, N, W, Ci, Co)
+        err = (got - ref).abs()
+        tol = 2.0 ** -8 * ref.abs() + 2e-3
+        assert (err <= tol).all(), "case %d N=%d W=%d Ci=%d Co=%d border=%d: excess %.4g" % (
+            case, N, W, Ci, Co, border, float((err - tol).max()))
