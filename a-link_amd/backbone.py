@@ -62,6 +62,7 @@ class IRBackbone(object):
         # matrix-core phases of the others (+8...10 % measured on r100).
         self.n_streams = max(1, int(streams))
         self._side = None
+        self._upload = None
         self._ws = {}
 
     def __del__(self):
@@ -192,8 +193,28 @@ class IRBackbone(object):
         if isinstance(x, np.ndarray):
             if x.dtype != np.uint8:
                 x = np.ascontiguousarray(x, dtype=np.float32)
-            xd = torch.from_numpy(np.ascontiguousarray(x)).to("cuda:%d" % self.device)
-            return self.embed_device(xd).cpu().numpy()
+            x = np.ascontiguousarray(x)
+            dev = "cuda:%d" % self.device
+            n = x.shape[0]
+            group = self.max_batch * self.n_streams
+            if n <= group:
+                return self.embed_device(torch.from_numpy(x).to(dev)).cpu().numpy()
+            # Large host arrays go up in groups of max_batch * streams images: the (host-blocking) upload of a
+            # group overlaps the launches already queued for the one before, and the device never holds
+            # more than two groups of pixels (a 100k-image pool is 15 GB of float32).
+            out = torch.empty((n, self.emb), dtype=torch.float32, device=dev)
+            if self._upload is None:
+                self._upload = torch.cuda.Stream(device=dev)
+            cur = torch.cuda.current_stream()
+            for i in range(0, n, group):
+                with torch.cuda.stream(self._upload):        # not ordered behind the compute already queued
+                    xd = torch.from_numpy(x[i:i + group]).to(dev)
+                    up = torch.cuda.Event()
+                    up.record(self._upload)
+                cur.wait_event(up)
+                xd.record_stream(cur)                         # allocated on the upload stream, consumed in `cur` order
+                self.embed_device(xd, out=out[i:i + group])
+            return out.cpu().numpy()
         return self.embed_device(x)
 
     def profile(self, x):
