@@ -7,6 +7,7 @@ import a_link_amd  # noqa
 from a_link_amd import _abi
 lib = _abi.init(0)
 lib.alink_debug_set_stamps.argtypes = [C.c_void_p]
+lib.alink_debug_set_linear(0)            # the stamps live in the row-aligned kernel (conv3x3_direct.hip)
 shapes = {"s2": (256, 28, 28, 128, 128), "s3": (256, 14, 14, 256, 256), "s1": (256, 56, 56, 64, 64), "s0": (256, 112, 112, 64, 64)}
 for name in sys.argv[1:] or ["s2", "s3", "s1"]:
     N, H, W, Ci, Co = shapes[name]
