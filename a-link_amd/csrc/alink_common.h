@@ -52,6 +52,8 @@ struct ConvParams {
     int splitk;           // 1 = fused epilogue; >1 = f32 partial slabs
     int ksteps_per_split;
     int post_relu;        // ReLU after the residual add (bottleneck units: relu(conv + bias + shortcut))
+    int fine;             // linear-tile kernel: 1 = 64-channel workgroups instead of 128 (small batches: twice the
+                          // workgroups, same weights, bit-identical sums)
     int ablate;           // diagnostic timing-only modes of conv3x3_direct (0 = normal)
     void* stamps;         // diagnostic: 4 x u64 s_memtime stamps per workgroup, or nullptr
 };

@@ -607,7 +607,7 @@ static int plan_split(const alink_backbone* bb, const ConvLayer& L, int N) {
     long long nwg;
     int units, kpu;                              // what a split divides: input chunks of 9 K-steps (linear) or K-steps (igemm)
     if (L.variant >= 11) {
-        const int bn = L.variant == 13 ? 64 : 128;
+        const int bn = L.variant == 13 ? 64 : 128;     // (the 64-channel form chosen for small batches doubles nwg: still <= 512)
         nwg = ((M + 223) / 224) * (L.Cout / bn);
         units = ncc; kpu = 9;
     } else if (L.variant == 0) {
@@ -695,6 +695,13 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         p.border_cls = L.border_cls ? 1 : 0; p.splitk = 1;
         p.ksteps_per_split = L.ksz * L.ksz * (L.Cin / 64);
         p.ablate = g_ablate;
+        // few images: the 128-channel workgroups of the linear-tile kernel cover only a corner of the chip and
+        // each walks all of K alone on its CU; the 64-channel form doubles their number and halves a K-step
+        // (bit-identical results: same weights, same summation order per output)
+        if (L.variant == 11 || L.variant == 12 || L.variant == 14) {
+            const long long nwg128 = (((long long)p.M + 223) / 224) * (L.Cout / 128);
+            p.fine = nwg128 <= 128 ? 1 : 0;
+        }
         const int S = plan_split(bb, L, N);
         for (int r = 0; r < reps; ++r) {
             ConvParams q = p;

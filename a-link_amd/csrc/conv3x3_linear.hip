@@ -399,7 +399,10 @@ hipError_t linear_set_attributes() {
     if ((e = set_attr_one<T, 14, 4>()) != hipSuccess) return e;           \
     if ((e = set_attr_one<T, 28, 4>()) != hipSuccess) return e;           \
     if ((e = set_attr_one<T, 56, 2>()) != hipSuccess) return e;           \
-    if ((e = set_attr_one<T, 7, 4>()) != hipSuccess) return e;
+    if ((e = set_attr_one<T, 7, 4>()) != hipSuccess) return e;            \
+    if ((e = set_attr_one<T, 14, 2>()) != hipSuccess) return e;           \
+    if ((e = set_attr_one<T, 28, 2>()) != hipSuccess) return e;           \
+    if ((e = set_attr_one<T, 7, 2>()) != hipSuccess) return e;
     A(__bf16) A(_Float16)
 #undef A
     return hipSuccess;
@@ -410,6 +413,15 @@ hipError_t launch_conv3x3_linear(int variant, int dtype, const ConvParams& p, hi
     if (p.splitk < 1 || (p.Cin / 64) % p.splitk) return hipErrorInvalidValue;      // whole chunks per split
     if ((long long)p.N * p.H * p.W * p.Cin >= (1ll << 31)) return hipErrorInvalidValue;
 #define L(W_, TCW_) (dtype == ALINK_DT_BF16 ? launch_one<__bf16, W_, TCW_>(p, st) : launch_one<_Float16, W_, TCW_>(p, st))
+    // p.fine: the 64-channel form of the same kernel (weight rows are packed per 32-channel block, so both
+    // forms read the same tensor, and every output is the same sum in the same order)
+    if (p.fine) {
+        switch (variant) {
+            case 11: return p.W == 14 ? L(14, 2) : hipErrorInvalidValue;
+            case 12: return p.W == 28 ? L(28, 2) : hipErrorInvalidValue;
+            case 14: return p.W == 7 ? L(7, 2) : hipErrorInvalidValue;
+        }
+    }
     switch (variant) {
         case 11: return p.W == 14 ? L(14, 4) : hipErrorInvalidValue;
         case 12: return p.W == 28 ? L(28, 4) : hipErrorInvalidValue;

@@ -110,8 +110,8 @@ int alink_backbone_enable_grad(alink_backbone_t* bb);
 
 /* Latency mode for batches of <= 32 images (FaceModel.get_feature is a batch-1 call: code/face_model.py:86-93).
  * A 3x3 layer at batch 1 has a handful of workgroups that each walk all of K; with the switch on such layers
- * are split over K into f32 partial slabs added in a fixed order (batch 1: 3.1 -> 1.9 ms, batch 16: 3.25 ->
- * 2.7 ms on IR-ResNet-100).  Default OFF: a split sum rounds differently from the fused one, so an image's
+ * are split over K into f32 partial slabs added in a fixed order (IR-ResNet-100: batch 1 2.3 -> 1.6 ms, batch 16
+ * 2.4 -> 2.2 ms).  Default OFF: a split sum rounds differently from the fused one, so an image's
  * embedding would no longer be bit-identical whatever batch it arrives in.  Changes the workspace size:
  * query alink_backbone_workspace_bytes after setting it. */
 int alink_backbone_set_small_batch_split(alink_backbone_t* bb, int on);
