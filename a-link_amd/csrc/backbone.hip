@@ -624,6 +624,8 @@ static int plan_split(const alink_backbone* bb, const ConvLayer& L, int N) {
     return best;
 }
 
+int g_fine_max = 384;     // measured (r100, one launch at a time): the 64-channel form wins while the 128-channel grid fills < 3/4 of the 512 slots
+extern "C" void alink_debug_set_fine_max(int n) { g_fine_max = n; }
 int g_ablate = 0;
 void* g_stamps = nullptr;
 // alink_embed_profile launches every kernel of the chain this many times back to back between its two
@@ -695,12 +697,12 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         p.border_cls = L.border_cls ? 1 : 0; p.splitk = 1;
         p.ksteps_per_split = L.ksz * L.ksz * (L.Cin / 64);
         p.ablate = g_ablate;
-        // few images: the 128-channel workgroups of the linear-tile kernel cover only a corner of the chip and
+        // few images (128-channel grid under 3/4 of the chip, g_fine_max): those workgroups cover only part of the chip and
         // each walks all of K alone on its CU; the 64-channel form doubles their number and halves a K-step
         // (bit-identical results: same weights, same summation order per output)
         if (L.variant == 11 || L.variant == 12 || L.variant == 14) {
             const long long nwg128 = (((long long)p.M + 223) / 224) * (L.Cout / 128);
-            p.fine = nwg128 <= 128 ? 1 : 0;
+            p.fine = nwg128 <= g_fine_max ? 1 : 0;
         }
         const int S = plan_split(bb, L, N);
         for (int r = 0; r < reps; ++r) {
