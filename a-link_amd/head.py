@@ -321,7 +321,10 @@ class DenseHead(KerasFitMixin):
             ya = np.asarray(y)
             # keras/engine/training.py _standardize_weights: argmax for one-hot targets, the value itself for (n, 1)
             cls = ya.argmax(axis=1) if ya.shape[1] > 1 else ya[:, 0].astype(int)
-            return np.asarray([class_weight[c] for c in cls if c in class_weight], dtype=np.float32)
+            missing = sorted(set(int(c) for c in cls) - set(class_weight))
+            if missing:                 # Keras raises here too instead of silently shortening the vector
+                raise ValueError("class_weight must contain all classes in the data; missing %s" % missing)
+            return np.asarray([class_weight[c] for c in cls], dtype=np.float32)
         return None
 
     def _staged(self, key, a):

@@ -1,172 +1,234 @@
-"""pairs — the pair-enumeration workload of one A-LINK iteration.
+"""pairs — the pair-enumeration workload of an A-LINK iteration, as INDEX lists.
 
-createMiniBatch restates reference code/readDFW.py:222-244 (identical in readMTP.py:123-135): all
-(plain_i x disguised_j) pairs, then all (disguised_i x disguised_j) pairs, label 1 iff i == j.
-createMiniBatchIndices is the de-duplicated form: the same pair list as
-indices into the unique-image array, so each image is embedded once and pairs are gathered on device.
+The reference materialises every pair's pixels on the host (reference code/readDFW.py:143-244,
+code/readMTP.py:80-135): P pairs cost 2·P image copies although only a few dozen images are distinct
+(SURVEY.md Appendix B).  Here a pair list is three integer arrays — `li`, `ri` (rows of one flat array
+holding every distinct image / feature once) and `y` — built by array arithmetic; images are embedded
+once and pairs are gathered by index on the device (alink_head_forward's index mode).
+
+    PairTable                     people -> flat rows + per-person row ranges
+    block_pairs / *_pair_indices  the enumeration orders of createMiniBatch / getNormalGenerator /
+                                  getImposterGenerator as (li, ri, y)
+    index_batches                 a pair list cut into generator batches (short tail dropped per sweep)
+    balance_rows, Pending         the 1:1 class balancing and the accumulate-until-batch_size logic of
+                                  readDFW.getGenerator / readMTP.getGenerator
+
+The reference-named callables at the bottom (createMiniBatch, getNormalGenerator, getImposterGenerator,
+getGenerator, getGeneratorMTP, splitDisguiseData) keep the reference's signatures and yield
+`[left, right], Y` by gathering rows — they are what tests/golden/generators.npz and minibatch.npz,
+recorded from the reference's own functions, are compared with.
 """
 import numpy as np
 
 
-def createMiniBatch(X_plain, X_dig):
-    X_left, X_right, Y = [], [], []
-    for i in range(len(X_plain)):
-        for j in range(len(X_dig)):
-            for x in X_plain[i]:
-                for y in X_dig[j]:
-                    X_left.append(x)
-                    X_right.append(y)
-                    Y.append([1] if i == j else [0])
-    for i in range(len(X_dig)):
-        for j in range(len(X_dig)):
-            for x in X_dig[i]:
-                for y in X_dig[j]:
-                    X_left.append(x)
-                    X_right.append(y)
-                    Y.append([1] if i == j else [0])
-    return [np.stack(X_left), np.stack(X_right)], np.stack(Y)
+class PairTable:
+    """`people`: sequence of per-person arrays (k_i, ...).  `rows` is their concatenation,
+    `start[i]:start[i+1]` person i's rows, `owner[r]` the person of row r."""
+
+    def __init__(self, people, base=0):
+        counts = np.fromiter((len(p) for p in people), dtype=np.int64, count=len(people))
+        self.start = base + np.concatenate(([0], np.cumsum(counts)))
+        self.counts = counts
+        self.people = people
+
+    @property
+    def n_rows(self):
+        return int(self.counts.sum())
+
+    def rows(self):
+        parts = [np.asarray(p) for p in self.people if len(p)]
+        return np.concatenate(parts, axis=0) if parts else np.zeros((0,))
+
+    def person_rows(self, i):
+        return np.arange(self.start[i], self.start[i + 1], dtype=np.int64)
+
+
+def block_pairs(ta, tb, label):
+    """Blocks in (person a, person b) order; inside a block every row of a against every row of b,
+    a-major.  `label(i, j)` gives the block's y.  This is the loop nest shared by createMiniBatch
+    (code/readDFW.py:224-243) and getNormalGenerator (code/readDFW.py:146-152)."""
+    li, ri, y = [], [], []
+    for i in range(len(ta.counts)):
+        a = ta.person_rows(i)
+        if not len(a):
+            continue
+        for j in range(len(tb.counts)):
+            b = tb.person_rows(j)
+            if not len(b):
+                continue
+            li.append(np.repeat(a, len(b)))
+            ri.append(np.tile(b, len(a)))
+            y.append(np.full(len(a) * len(b), label(i, j), dtype=np.int64))
+    if not li:
+        z = np.zeros(0, np.int64)
+        return z, z.copy(), z.copy()
+    return np.concatenate(li), np.concatenate(ri), np.concatenate(y)
+
+
+def _same(i, j):
+    return 1 if i == j else 0
 
 
 def createMiniBatchIndices(n_plain, n_dig):
-    """n_plain[i], n_dig[i]: image counts per person.  Returns (li, ri, y): indices into the array
-    `unique = concat(plain_0..plain_k, dig_0..dig_k)` reproducing createMiniBatch's order."""
-    n_plain, n_dig = list(n_plain), list(n_dig)
-    p_off = np.concatenate([[0], np.cumsum(n_plain)]).astype(np.int64)
-    d_off = p_off[-1] + np.concatenate([[0], np.cumsum(n_dig)]).astype(np.int64)
-    li, ri, y = [], [], []
-    for i in range(len(n_plain)):
-        for j in range(len(n_dig)):
-            a = np.arange(p_off[i], p_off[i + 1])
-            b = np.arange(d_off[j], d_off[j + 1])
-            li.append(np.repeat(a, len(b)))
-            ri.append(np.tile(b, len(a)))
-            y.append(np.full(len(a) * len(b), 1 if i == j else 0))
-    for i in range(len(n_dig)):
-        for j in range(len(n_dig)):
-            a = np.arange(d_off[i], d_off[i + 1])
-            b = np.arange(d_off[j], d_off[j + 1])
-            li.append(np.repeat(a, len(b)))
-            ri.append(np.tile(b, len(a)))
-            y.append(np.full(len(a) * len(b), 1 if i == j else 0))
-    return (np.concatenate(li).astype(np.int32), np.concatenate(ri).astype(np.int32),
-            np.concatenate(y).astype(np.int64).reshape(-1, 1))
+    """n_plain[i], n_dig[i]: image counts per person.  (li, ri, y) into `concat(plain_0.., dig_0..)`
+    in createMiniBatch's order: plain x disguised, then disguised x disguised; y = [i == j]."""
+    tp = PairTable([range(int(n)) for n in n_plain])
+    td = PairTable([range(int(n)) for n in n_dig], base=tp.n_rows)
+    parts = [block_pairs(tp, td, _same), block_pairs(td, td, _same)]
+    li, ri, y = (np.concatenate([p[k] for p in parts]) for k in range(3))
+    return li.astype(np.int32), ri.astype(np.int32), y.reshape(-1, 1)
+
+
+def normal_pair_indices(counts):
+    """All (person i x person j) pairs of one people list, y = [i == j] (getNormalGenerator's sweep)."""
+    t = PairTable([range(int(n)) for n in counts])
+    return block_pairs(t, t, _same)
+
+
+def imposter_pair_indices(plain_counts, imposter_counts):
+    """Every plain row against every impostor row, label 0 (getImposterGenerator's sweep,
+    code/readDFW.py:166-171): the person structure does not matter, so this is one outer product.
+    Right indices are offset by the number of plain rows."""
+    n_a, n_b = int(np.sum(plain_counts)), int(np.sum(imposter_counts))
+    li = np.repeat(np.arange(n_a, dtype=np.int64), n_b)
+    ri = n_a + np.tile(np.arange(n_b, dtype=np.int64), n_a)
+    return li, ri, np.zeros(n_a * n_b, np.int64)
+
+
+def index_batches(li, ri, y, batch_size, infinite=True):
+    """Generator of (li, ri, y[:, None]) slices of batch_size; the remainder of a sweep that does not
+    fill a batch is discarded before the next sweep starts (the reference resets its lists there)."""
+    full = (len(y) // batch_size) * batch_size
+    while True:
+        for s in range(0, full, batch_size):
+            e = s + batch_size
+            yield li[s:e], ri[s:e], y[s:e].reshape(-1, 1)
+        if not infinite:
+            return
+
+
+def balance_rows(y):
+    """Row selection giving as many positives as negatives: min(#pos, #neg) of each, drawn without
+    replacement — positives first, then negatives, two np.random.choice calls in that order
+    (code/readDFW.py:189-199).  None when a class is absent."""
+    flat = np.asarray(y).reshape(len(y), -1)[:, 0]
+    groups = [np.flatnonzero(flat == 1), np.flatnonzero(flat == 0)]
+    m = min(len(g) for g in groups)
+    if m == 0:
+        return None
+    return np.concatenate([np.random.choice(g, m, replace=False) for g in groups])
+
+
+class Pending:
+    """Rows waiting for a generator batch: append until at least batch_size, then flush everything."""
+
+    def __init__(self):
+        self.parts = []
+        self.n = 0
+
+    def add(self, left, right, y):
+        self.parts.append((left, right, y))
+        self.n += len(y)
+
+    def flush(self):
+        out = tuple(_cat([p[k] for p in self.parts]) for k in range(3))
+        self.parts, self.n = [], 0
+        return out
+
+
+def _cat(parts):
+    if hasattr(parts[0], "detach"):                     # device tensors stay on the device
+        import torch
+        return torch.cat(list(parts), dim=0)
+    return np.concatenate(parts, axis=0)
+
+
+def _take(rows, idx):
+    if hasattr(rows, "detach"):
+        import torch
+        return rows[torch.as_tensor(np.asarray(idx), device=rows.device, dtype=torch.long)]
+    return rows[idx]
+
+
+def mix_balanced(sources, batch_size, transform=None):
+    """`sources`: generators of ([left, right], Y).  Per round: draw one batch from every source (stop
+    when one is exhausted), join, balance classes, optionally transform the two sides, accumulate until
+    batch_size rows are waiting.  With three sources the joined labels are (Y1, Y2, Y2): the reference
+    repeats the second label block for the third source (code/readDFW.py:185) — kept."""
+    waiting = Pending()
+    while True:
+        try:
+            drawn = [next(g) for g in sources]
+        except StopIteration:
+            return
+        labels = [d[1] for d in drawn]
+        if len(labels) == 3:
+            labels[2] = labels[1]
+        y = np.concatenate(labels, axis=0)
+        sides = [_cat([d[0][s] for d in drawn]) for s in (0, 1)]
+        keep = balance_rows(y)
+        if keep is None:
+            continue
+        sides = [_take(s, keep) for s in sides]
+        if transform is not None:
+            sides = transform(sides)
+        waiting.add(sides[0], sides[1], y[keep])
+        if waiting.n >= batch_size:
+            left, right, yy = waiting.flush()
+            yield ([left, right], yy)
+
+
+# ---- the reference's names and signatures ---------------------------------------------------------------
+def _gathering(table, idx_gen):
+    rows = table
+    for li, ri, y in idx_gen:
+        yield [rows[li], rows[ri]], y
+
+
+def createMiniBatch(X_plain, X_dig):
+    """reference code/readDFW.py:222-244 (= code/readMTP.py:123-135 with one list)."""
+    tp, td = PairTable(X_plain), PairTable(X_dig, base=PairTable(X_plain).n_rows)
+    rows = np.concatenate([tp.rows(), td.rows()], axis=0)
+    parts = [block_pairs(tp, td, _same), block_pairs(td, td, _same)]
+    li, ri, y = (np.concatenate([p[k] for p in parts]) for k in range(3))
+    return [rows[li], rows[ri]], y.reshape(-1, 1)
 
 
 def splitDisguiseData(X_dig, pre_ratio=0.5):
-    """reference code/readDFW.py:212-219"""
-    X_dig_pre, X_dig_post = [], []
-    for i in range(len(X_dig)):
-        splitPoint = int(X_dig[i].shape[0] * pre_ratio)
-        X_dig_pre.append(X_dig[i][:splitPoint])
-        X_dig_post.append(X_dig[i][splitPoint:])
-    return (X_dig_pre, X_dig_post)
+    """reference code/readDFW.py:212-219: each person's first int(k*pre_ratio) images / the rest."""
+    cuts = [int(x.shape[0] * pre_ratio) for x in X_dig]
+    return ([x[:c] for x, c in zip(X_dig, cuts)], [x[c:] for x, c in zip(X_dig, cuts)])
 
 
-# ---- in-memory pair generators of the drivers (host Python, like the reference) -----------------------
 def getNormalGenerator(X_data, batch_size, infinite=True):
-    """readDFW.getNormalGenerator (code/readDFW.py:143-160): all (person i x person j) pairs in
-    order, label 1 iff i == j, cut into batches of batch_size; the tail shorter than a batch is
-    dropped at the end of a sweep."""
-    while True:
-        X_left, X_right, Y = [], [], []
-        for i in range(len(X_data)):
-            for j in range(len(X_data)):
-                for x in X_data[i]:
-                    for y in X_data[j]:
-                        X_left.append(x)
-                        X_right.append(y)
-                        Y.append([1] if i == j else [0])
-                        if len(Y) == batch_size:
-                            yield [np.stack(X_left), np.stack(X_right)], np.stack(Y)
-                            X_left, X_right, Y = [], [], []
-        if not infinite:
-            break
+    """reference code/readDFW.py:143-160."""
+    t = PairTable(X_data)
+    li, ri, y = block_pairs(t, t, _same)
+    return _gathering(t.rows(), index_batches(li, ri, y, batch_size, infinite))
 
 
 def getImposterGenerator(X_plain, X_imposter, batch_size, infinite=True):
-    """readDFW.getImposterGenerator (code/readDFW.py:163-177): every plain image x every impostor image, label 0."""
-    while True:
-        X_left, X_right, Y = [], [], []
-        for person in X_plain:
-            for x in person:
-                for imposter in X_imposter:
-                    for y in imposter:
-                        X_left.append(x)
-                        X_right.append(y)
-                        Y.append([0])
-                        if len(Y) == batch_size:
-                            yield [np.stack(X_left), np.stack(X_right)], np.stack(Y)
-                            X_left, X_right, Y = [], [], []
-        if not infinite:
-            break
-
-
-def _balanced(X, Y):
-    """1:1 positives/negatives by np.random.choice without replacement (code/readDFW.py:189-199)."""
-    Y_flat = np.stack([y[0] for y in Y])
-    pos = np.where(Y_flat == 1)[0]
-    neg = np.where(Y_flat == 0)[0]
-    minSamp = np.minimum(len(pos), len(neg))
-    if minSamp == 0:
-        return None
-    sel = np.concatenate((np.random.choice(pos, minSamp, replace=False), np.random.choice(neg, minSamp, replace=False)),
-                         axis=0)
-    return [X[0][sel], X[1][sel]], Y[sel]
+    """reference code/readDFW.py:163-177."""
+    ta, tb = PairTable(X_plain), PairTable(X_imposter)
+    li, ri, y = imposter_pair_indices(ta.counts, tb.counts)
+    rows = np.concatenate([ta.rows(), tb.rows()], axis=0)
+    return _gathering(rows, index_batches(li, ri, y, batch_size, infinite))
 
 
 def getGenerator(norGen, normImpGen, impGen, batch_size, type=0, val_ratio=0.2):
-    """readDFW.getGenerator (code/readDFW.py:180-209).  The reference labels the third block with Y2
-    again (`Y = concatenate((Y1, Y2, Y2))`, :185) — kept.  Ends (StopIteration) when a finite source
-    generator is exhausted, where the Python-3 copy yields None (code/readDFW3.py)."""
-    X_left, X_right, Y_send = [], [], []
-    while True:
-        try:
-            X1, Y1 = next(norGen)
-            X2, Y2 = next(normImpGen)
-            X3, Y3 = next(impGen)
-        except StopIteration:
-            return
-        Y = np.concatenate((Y1, Y2, Y2), axis=0)
-        X = [np.concatenate((X1[0], X2[0], X3[0]), axis=0), np.concatenate((X1[1], X2[1], X3[1]), axis=0)]
-        picked = _balanced(X, Y)
-        if picked is None:
-            continue
-        X, Y = picked
-        if len(Y_send) > 0:
-            X_left = np.concatenate((X_left, X[0]), axis=0)
-            X_right = np.concatenate((X_right, X[1]), axis=0)
-            Y_send = np.concatenate((Y_send, Y), axis=0)
-        else:
-            X_left, X_right, Y_send = np.copy(X[0]), np.copy(X[1]), np.copy(Y)
-        if len(Y_send) >= batch_size:
-            yield ([X_left, X_right], Y_send)
-            X_left, X_right, Y_send = [], [], []
+    """reference code/readDFW.py:180-209.  Ends (StopIteration) when a finite source generator is
+    exhausted, where the Python-3 copy yields None (code/readDFW3.py)."""
+    return mix_balanced([norGen, normImpGen, impGen], batch_size)
 
 
 def getGeneratorMTP(datGen, batch_size, resize_res=None, featurize=None):
-    """readMTP.getGenerator (code/readMTP.py:80-113): balance, optionally resize (bilinear, on the
-    device) and featurize each source batch, accumulate to batch_size."""
-    from . import noise as _noise
-    X_left, X_right, Y_send = [], [], []
-    while True:
-        try:
-            X, Y = next(datGen)
-        except StopIteration:
-            return
-        picked = _balanced(X, Y)
-        if picked is None:
-            continue
-        X, Y = picked
+    """reference code/readMTP.py:80-113: balance, optionally resize (bilinear, device kernel) and
+    featurize each source batch, accumulate to batch_size."""
+    def transform(sides):
         if resize_res:
-            X = [np.asarray(_noise.resize_images(X[0], resize_res)), np.asarray(_noise.resize_images(X[1], resize_res))]
+            from . import noise as _noise
+            sides = [np.asarray(_noise.resize_images(s, resize_res)) for s in sides]
         if featurize:
-            X = [featurize.process(X[0]), featurize.process(X[1])]
-        if len(Y_send) > 0:
-            X_left = np.concatenate((X_left, X[0]), axis=0)
-            X_right = np.concatenate((X_right, X[1]), axis=0)
-            Y_send = np.concatenate((Y_send, Y), axis=0)
-        else:
-            X_left, X_right, Y_send = np.copy(X[0]), np.copy(X[1]), np.copy(Y)
-        if len(Y_send) >= batch_size:
-            yield ([X_left, X_right], Y_send)
-            X_left, X_right, Y_send = [], [], []
+            sides = [featurize.process(s) for s in sides]
+        return sides
+    return mix_balanced([datGen], batch_size, transform if (resize_res or featurize) else None)

@@ -22,6 +22,17 @@ class _Args(dict):
     __getattr__ = dict.__getitem__
 
 
+def _inverse_frequency_weights(y):
+    """code/siamese.py:95-98: weight of class c = (n // count_c), the two normalised to sum 1.  The
+    reference file has no `from __future__ import division`, so `len(y) / np.sum(y == c)` FLOORS under
+    the Python 2 it was written for; an absent class divides by zero -> inf/nan weights there too."""
+    y = np.asarray(y)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        per_class = [np.int64(len(y)) // np.sum(y == c) for c in (0, 1)]
+        total = float(per_class[0] + per_class[1])
+        return {c: per_class[c] / total for c in (0, 1)}
+
+
 class SiameseNetwork:
     _identity_preprocess = True
 
@@ -58,44 +69,34 @@ class SiameseNetwork:
 
     def customTrainModel(self, dataGen, epochs, batch_size, valRatio=0.2, n_steps=320000, preprocess=False,
                          verbose=1):
+        """code/siamese.py:81-112: int(n_steps / batch_size) generator batches per epoch; each batch is
+        permuted, its first int(n * valRatio) rows are held out for test_on_batch, the rest go through
+        train_on_batch with inverse-frequency class weights.  Returns per-epoch
+        (train loss, train acc, val loss, val acc) — each a sum over steps / steps_per_epoch, so a
+        step without held-out rows counts as 0 in the val means, as in the reference."""
         steps_per_epoch = int(n_steps / batch_size)
+        net = self.siamese_net
         logs = []
-        for eno in range(epochs):
-            train_loss, val_loss = 0, 0
-            train_acc, val_acc = 0, 0
-            for i in range(steps_per_epoch):
+        for epoch in range(epochs):
+            sums = np.zeros(4)                                   # tr loss, tr acc, vl loss, vl acc
+            for step in range(1, steps_per_epoch + 1):
                 x, y = next(dataGen)
                 if preprocess:
                     x = self.preprocess(x)
-                indices = np.random.permutation(len(y))
-                splitPoint = int(len(y) * valRatio)
-                x_train, y_train = [pp[indices[splitPoint:]] for pp in x], y[indices[splitPoint:]]
-                x_test, y_test = [pp[indices[:splitPoint]] for pp in x], y[indices[:splitPoint]]
-                # Python-2 integer division in the reference (no `from __future__ import division`
-                # in code/siamese.py): len / count floors.
-                with np.errstate(divide='ignore'):
-                    class_1_weight = np.int64(len(y_train)) // np.sum(y_train == 1)
-                    class_0_weight = np.int64(len(y_train)) // np.sum(y_train == 0)
-                scaling_factor = float(class_1_weight + class_0_weight)
-                class_weight = {0: class_0_weight / scaling_factor, 1: class_1_weight / scaling_factor}
-                y_train = to_categorical(y_train, num_classes=2)
-                y_test = to_categorical(y_test, num_classes=2)
-                train_metrics = self.siamese_net.train_on_batch(x_train, y_train, class_weight=class_weight)
-                train_loss += train_metrics[0]
-                train_acc += train_metrics[1]
-                if len(y_test) > 0:
-                    val_metrics = self.siamese_net.test_on_batch(x_test, y_test)
-                    val_loss += val_metrics[0]
-                    val_acc += val_metrics[1]
+                order = np.random.permutation(len(y))
+                n_held = int(len(y) * valRatio)
+                held, used = order[:n_held], order[n_held:]
+                sums[:2] += net.train_on_batch([side[used] for side in x], to_categorical(y[used], num_classes=2),
+                                               class_weight=_inverse_frequency_weights(y[used]))[:2]
+                if n_held > 0:
+                    sums[2:] += net.test_on_batch([side[held] for side in x], to_categorical(y[held], num_classes=2))[:2]
                 if verbose:
-                    sys.stdout.write("Epoch %d : %d / %d : Tr loss: %.4f, Tr acc: %.4f, Vl loss: %.4f, Vl acc: %.4f  \r" % (
-                        eno + 1, i + 1, steps_per_epoch, train_loss / (i + 1), train_acc / (i + 1),
-                        val_loss / (i + 1), val_acc / (i + 1)))
+                    sys.stdout.write("Epoch %d : %d / %d : Tr loss: %.4f, Tr acc: %.4f, Vl loss: %.4f, Vl acc: %.4f  \r"
+                                     % ((epoch + 1, step, steps_per_epoch) + tuple(sums / step)))
                     sys.stdout.flush()
             if verbose:
                 print("\n")
-            logs.append((train_loss / steps_per_epoch, train_acc / steps_per_epoch,
-                         val_loss / steps_per_epoch, val_acc / steps_per_epoch))
+            logs.append(tuple(sums / steps_per_epoch))
         return logs
 
     def maybeLoadFromMemory(self):
