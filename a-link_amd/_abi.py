@@ -48,7 +48,7 @@ PROTOTYPES = {
     "alink_embed_cached": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "alink_embed_input_grad": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "alink_embed_profile": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
-    "alink_conv_nhwc": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
+    "alink_conv_nhwc": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "alink_resnet50_create": (_vp, [_i, _i, _i, _f]),
     "alink_resnet50_destroy": (None, [_vp]),
     "alink_resnet50_num_tensors": (_i, [_vp]),
@@ -81,6 +81,7 @@ PROTOTYPES = {
     "alink_head_grads_dev": (_vp, [_vp]),
     "alink_head_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "alink_committee_forward": (_i, [C.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "alink_committee_forward_multi": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i64, _vp, _vp]),
     "alink_pair_scores_matrix": (_i, [C.POINTER(_vp), _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "alink_roc_counts": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "alink_head_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp]),
@@ -165,9 +166,17 @@ def init(device=0):
     return lib
 
 
-def current_stream():
+def current_stream(device=None):
+    """torch's current stream ON `device` (None: the current device) — a handle's launches go to a stream of
+    the handle's own device, whatever device is current in the caller (include/alink_hip.h, device rule)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on_device(device):
+    """Context manager making `device` current: handles record the device that is current at their create call."""
+    import torch
+    return torch.cuda.device(int(device))
 
 
 def ptr(t):

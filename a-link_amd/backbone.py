@@ -37,7 +37,8 @@ class IRBackbone(object):
         cfg.dtype = {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16}[dtype]
         cfg.bn_eps = float(bn_eps)
         self.dtype = dtype
-        self.h = self.lib.alink_backbone_create(C.byref(cfg))
+        with _abi.on_device(device):                  # the handle lives on the device current at create
+            self.h = self.lib.alink_backbone_create(C.byref(cfg))
         if not self.h:
             raise _abi.AlinkError("alink_backbone_create: " + self.lib.alink_last_error().decode())
         if small_batch_split:      # latency mode: batches <= 32 split their convolutions over K (not bit-equal to fused)
@@ -114,7 +115,7 @@ class IRBackbone(object):
             out = torch.empty((n, self.emb), dtype=torch.float32, device=x.device)
         nchunks = (n + self.max_batch - 1) // self.max_batch
         if nchunks == 1 or self.n_streams == 1:
-            st = _abi.current_stream()
+            st = _abi.current_stream(self.device)
             for i in range(0, n, self.max_batch):
                 m = min(self.max_batch, n - i)
                 ws, wsb = self._workspace(m)
@@ -123,7 +124,7 @@ class IRBackbone(object):
             return self._checked(out)
         if self._side is None:
             self._side = [torch.cuda.Stream(device=x.device) for _ in range(self.n_streams)]
-        cur = torch.cuda.current_stream()
+        cur = torch.cuda.current_stream(x.device)
         ready = torch.cuda.Event()
         ready.record(cur)                       # inputs (and `out`) are valid in caller-stream order
         used = min(self.n_streams, nchunks)
@@ -167,7 +168,7 @@ class IRBackbone(object):
         out = torch.empty((n, self.emb), dtype=torch.float32, device=x.device)
         ws, wsb = self._grad_workspace(n)
         _abi.check(self.lib.alink_embed_cached(self.h, _abi.ptr(x), layout, n, _abi.ptr(out), C.c_void_p(ws), wsb,
-                                               _abi.current_stream()), "alink_embed_cached")
+                                               _abi.current_stream(self.device)), "alink_embed_cached")
         self._cached = (n, layout, out)
         return out
 
@@ -183,7 +184,7 @@ class IRBackbone(object):
         dpix = torch.empty(shape, dtype=torch.float32, device=demb.device)
         ws, wsb = self._grad_workspace(n)
         _abi.check(self.lib.alink_embed_input_grad(self.h, _abi.ptr(demb), _abi.ptr(emb), layout, n, _abi.ptr(dpix),
-                                                   C.c_void_p(ws), wsb, _abi.current_stream()), "alink_embed_input_grad")
+                                                   C.c_void_p(ws), wsb, _abi.current_stream(self.device)), "alink_embed_input_grad")
         return dpix
 
     def embed(self, x):
@@ -205,7 +206,7 @@ class IRBackbone(object):
             out = torch.empty((n, self.emb), dtype=torch.float32, device=dev)
             if self._upload is None:
                 self._upload = torch.cuda.Stream(device=dev)
-            cur = torch.cuda.current_stream()
+            cur = torch.cuda.current_stream(self.device)
             for i in range(0, n, group):
                 with torch.cuda.stream(self._upload):        # not ordered behind the compute already queued
                     xd = torch.from_numpy(x[i:i + group]).to(dev)
@@ -231,5 +232,5 @@ class IRBackbone(object):
         kd = (C.c_int * cap)()
         nl = C.c_int(cap)
         _abi.check(self.lib.alink_embed_profile(self.h, _abi.ptr(x), layout, n, _abi.ptr(out), C.c_void_p(ws), wsb,
-                                                _abi.current_stream(), ms, fl, kd, C.byref(nl)), "alink_embed_profile")
+                                                _abi.current_stream(self.device), ms, fl, kd, C.byref(nl)), "alink_embed_profile")
         return [(kd[i], ms[i], fl[i]) for i in range(nl.value)]

@@ -38,7 +38,8 @@ class Bagging:
         return np.array(predicted)
 
     def predict_indexed(self, emb_left, emb_right, li, ri):
-        """Extension: score pairs (li[p], ri[p]) gathered from embedding matrices on device."""
+        """Extension: score pairs (li[p], ri[p]) gathered from embedding matrices on device.  emb_left /
+        emb_right may be lists with one matrix per member (each member behind its own feature extractor)."""
         hs = self._device_heads()
         if hs is None:
             raise TypeError("predict_indexed needs DenseHead members")

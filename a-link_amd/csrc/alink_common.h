@@ -27,6 +27,37 @@ int  hip_fail(hipError_t e, const char* what, const char* file, int line);
         }                                       \
     } while (0)
 
+// ---- device ownership (one process per GPU, but several devices may be visible to a process) -------------
+// Every handle remembers the device that was current when it was created; every entry point that allocates,
+// copies or launches makes that device current for the duration of the call and restores the caller's
+// device afterwards.  Entry points without a handle take the device from the allocation they are handed.
+// The caller's `stream` must belong to the same device (torch: the stream of the tensor's device).
+static inline int current_device() {
+    int d = -1;
+    return hipGetDevice(&d) == hipSuccess ? d : -1;
+}
+static inline int device_of_pointer(const void* p) {
+    if (p) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeDevice) return a.device;
+        (void)hipGetLastError();                        // host / unregistered pointer: not an error here
+    }
+    return current_device();
+}
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (dev < 0 || hipGetDevice(&prev) != hipSuccess || prev == dev) return;
+        switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 // ---- vector types -------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16   bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;

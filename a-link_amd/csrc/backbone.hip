@@ -63,13 +63,17 @@ static inline uint16_t cvt(int dtype, float f) {
 }
 
 hipError_t conv_set_attributes();
+static unsigned long long g_kernels_ready = 0;       // one bit per device (function attributes and the probe are per device)
 int init_kernels() {
+    const int dev = current_device();
+    if (dev >= 0 && dev < 64 && (g_kernels_ready >> dev & 1ull)) return ALINK_OK;
     hipError_t e = conv_set_attributes();
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute", __FILE__, __LINE__);
     e = direct_set_attributes();
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(direct)", __FILE__, __LINE__);
     e = linear_check_contract();
     if (e != hipSuccess) return hip_fail(e, "LDS out-of-range read probe", __FILE__, __LINE__);
+    if (dev >= 0 && dev < 64) g_kernels_ready |= 1ull << dev;
     return ALINK_OK;
 }
 
@@ -97,6 +101,7 @@ struct ConvLayer {
 using namespace alink;
 
 struct alink_backbone {
+    int device = -1;                                           // device of every allocation / stream of this handle
     alink_ir_cfg cfg;
     std::vector<std::pair<std::string, size_t>> expected;     // name, count (load order)
     std::map<std::string, std::vector<float>> raw;
@@ -260,7 +265,13 @@ const char* alink_last_error(void) { return g_err; }
 int alink_version(void) { return 1; }
 
 int alink_init(int device) {
-    ALINK_HIP(hipSetDevice(device));
+    // prepares `device` (function attributes, hardware-contract probe) and leaves the caller's current device
+    // as it was: handles are created on whatever device is current at their create call
+    int count = 0;
+    ALINK_HIP(hipGetDeviceCount(&count));
+    ALINK_REQUIRE(device >= 0 && device < count, ALINK_EINVAL, "device %d outside the %d visible device(s)", device, count);
+    DeviceGuard dg(device);
+    ALINK_REQUIRE(current_device() == device, ALINK_EHIP, "cannot make device %d current", device);
     return init_kernels();
 }
 
@@ -281,6 +292,7 @@ alink_backbone_t* alink_backbone_create(const alink_ir_cfg* cfg) {
     }
     if (cfg->dtype != ALINK_DT_BF16 && cfg->dtype != ALINK_DT_F16) { set_error("bad dtype"); return nullptr; }
     alink_backbone* bb = new alink_backbone();
+    bb->device = current_device();
     bb->cfg = *cfg;
     if (!(bb->cfg.bn_eps > 0.f)) bb->cfg.bn_eps = 2e-5f;
 
@@ -320,7 +332,11 @@ alink_backbone_t* alink_backbone_create(const alink_ir_cfg* cfg) {
     return bb;
 }
 
-void alink_backbone_destroy(alink_backbone_t* bb) { delete bb; }
+void alink_backbone_destroy(alink_backbone_t* bb) {
+    if (!bb) return;
+    DeviceGuard dg(bb->device);
+    delete bb;
+}
 
 int alink_backbone_num_tensors(const alink_backbone_t* bb) { return bb ? (int)bb->expected.size() : 0; }
 
@@ -348,6 +364,8 @@ int alink_backbone_load(alink_backbone_t* bb, const char* name, const float* hos
 int alink_backbone_finalize(alink_backbone_t* bb) {
     ALINK_REQUIRE(bb, ALINK_EINVAL, "NULL backbone");
     ALINK_REQUIRE(!bb->finalized, ALINK_ESTATE, "backbone already finalized");
+    DeviceGuard dg(bb->device);
+    { const int rc0 = init_kernels(); if (rc0) return rc0; }
     for (const auto& e : bb->expected)
         ALINK_REQUIRE(bb->raw.count(e.first), ALINK_ESTATE, "tensor %s was never loaded", e.first.c_str());
     if (bb->grad)   // the backward pass tells the PReLU side from the sign of the stored activation
@@ -756,6 +774,7 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
 int alink_embed(alink_backbone_t* bb, const void* dev_in, int layout, int n_images, float* dev_out,
                 void* dev_workspace, size_t workspace_bytes, void* stream) {
     ALINK_REQUIRE(bb && bb->finalized, ALINK_ESTATE, "alink_embed before alink_backbone_finalize");
+    DeviceGuard dg(bb->device);
     ALINK_REQUIRE(n_images > 0, ALINK_EINVAL, "n_images must be positive");
     ALINK_REQUIRE(layout >= 0 && layout <= 2, ALINK_EINVAL, "unknown pixel layout %d", layout);
     int counts[alink_backbone::MAXSUB];
@@ -792,6 +811,8 @@ int alink_embed_profile(alink_backbone_t* bb, const void* dev_in, int layout, in
                         void* dev_workspace, size_t workspace_bytes, void* stream, float* ms, double* flops,
                         int* kind, int* n_launches) {
     ALINK_REQUIRE(ms && flops && kind && n_launches && *n_launches > 0, ALINK_EINVAL, "NULL profile buffers");
+    ALINK_REQUIRE(bb, ALINK_EINVAL, "NULL backbone");
+    DeviceGuard dg(bb->device);
     return embed_impl(bb, dev_in, layout, n_images, dev_out, dev_workspace, workspace_bytes,
                       (hipStream_t)stream, ms, flops, kind, n_launches);
 }
@@ -820,6 +841,7 @@ size_t alink_backbone_grad_workspace_bytes(const alink_backbone_t* bb, int n_ima
 int alink_embed_cached(alink_backbone_t* bb, const void* dev_in, int layout, int n_images, float* dev_out,
                        void* dev_workspace, size_t workspace_bytes, void* stream) {
     ALINK_REQUIRE(bb && bb->finalized && bb->grad, ALINK_ESTATE, "needs alink_backbone_enable_grad + finalize");
+    DeviceGuard dg(bb->device);
     GradLayout L;
     grad_layout(bb, n_images > 0 ? n_images : 1, &L);
     return embed_impl(bb, dev_in, layout, n_images, dev_out, dev_workspace, workspace_bytes, (hipStream_t)stream,
@@ -829,6 +851,7 @@ int alink_embed_cached(alink_backbone_t* bb, const void* dev_in, int layout, int
 int alink_embed_input_grad(alink_backbone_t* bb, const float* dev_demb, const float* dev_emb, int layout, int N,
                            float* dev_dpix, void* ws, size_t ws_bytes, void* stream) {
     ALINK_REQUIRE(bb && bb->finalized && bb->grad, ALINK_ESTATE, "needs alink_backbone_enable_grad + finalize");
+    DeviceGuard dg(bb->device);
     ALINK_REQUIRE(dev_demb && dev_emb && dev_dpix && ws && N > 0, ALINK_EINVAL, "bad argument");
     ALINK_REQUIRE(layout == ALINK_LAYOUT_NHWC_F32 || layout == ALINK_LAYOUT_NCHW_F32, ALINK_EINVAL,
                   "gradient layout must be float32 NHWC or NCHW");
@@ -905,8 +928,9 @@ int alink_embed_input_grad(alink_backbone_t* bb, const float* dev_demb, const fl
 // ---- diagnostic single-convolution entry (unit tests) -------------------------------------------
 int alink_conv_nhwc(int dtype, const void* dev_in, const void* dev_w, const float* dev_bias,
                     const float* dev_alpha, const void* dev_resid, void* dev_out, int N, int H, int W, int Cin,
-                    int Cout, int ksz, int stride, int pad, int border_cls, void* stream) {
+                    int Cout, int ksz, int stride, int pad, int border_cls, int fine, void* stream) {
     ALINK_REQUIRE(dev_in && dev_w && dev_bias && dev_out, ALINK_EINVAL, "NULL argument");
+    DeviceGuard dg(device_of_pointer(dev_in));
     ALINK_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, ALINK_EINVAL, "Cin/Cout must be multiples of 64");
     ALINK_REQUIRE(ksz == 1 || ksz == 3, ALINK_EINVAL, "ksz must be 1 or 3");
     ALINK_REQUIRE(!border_cls || (ksz == 3 && stride == 1 && pad == 1), ALINK_EINVAL,
@@ -940,6 +964,11 @@ int alink_conv_nhwc(int dtype, const void* dev_in, const void* dev_w, const floa
     p.stride = stride; p.ksz = ksz; p.pad = pad; p.M = N * p.Ho * p.Wo; p.border_cls = border_cls;
     p.splitk = 1; p.ksteps_per_split = ksz * ksz * (Cin / 64);
     p.ablate = g_ablate; p.stamps = g_stamps;
+    // fine: 1 / 0 force the 64- / 128-channel form of the linear-tile kernel, < 0 chooses as alink_embed does
+    if (variant == 11 || variant == 12 || variant == 14) {
+        const long long nwg128 = (((long long)p.M + 223) / 224) * (Cout / 128);
+        p.fine = fine < 0 ? (nwg128 <= g_fine_max ? 1 : 0) : (fine ? 1 : 0);
+    }
     hipError_t e = variant ? launch_conv3x3_direct(variant, dtype, p, st) : launch_conv_igemm(dtype, p, st);
     hipError_t e2 = hipStreamSynchronize(st);
     (void)hipFree(d_wp);

@@ -341,28 +341,52 @@ int g_linear_mode = 15;
 extern "C" void alink_debug_set_linear(int mode) { g_linear_mode = mode; }
 
 // Hardware contract probe: a DS read whose address lies beyond the workgroup's LDS allocation returns zero
-// (and does not fault).  out: 64 x 4 floats read 256 KB into a 1 KB allocation, then 4 floats read in range.
+// (and does not fault).  The kernel above adds border bits 18..21 (tiles 0-4), 20..23 (tile 5) or 24..27 (tile 6)
+// to an in-range operand address — one or two of them at a time (a corner pixel crosses a row AND a column
+// border) — and reads with the tile's immediate offset 2048 u, u <= 6.  The probe reads, from a 1 KB allocation:
+//   lanes  0.. 9   base + 2^(18 + lane)                                  every single bit the kernel can set
+//   lanes 10..54   base + 2^a + 2^b, 18 <= a < b <= 27                   every pair (a superset of the kernel's)
+//   lanes 55..63   base + all ten bits, base + 2^27 + 2^26 + ..., etc.   wider sums than the kernel ever forms
+// each once with immediate offset 0 and once with offset:12288 (= 2048 * 6), from a per-lane in-range base;
+// out: 64 x 8 floats that must all be zero, then 4 floats read IN range that must be the stored 1, 2, 3, 4
+// (if the DS unit dropped high address bits before its bounds check, the far reads would alias those).
 namespace {
 __global__ void lds_oob_probe_kernel(float* out) {
     __shared__ __attribute__((aligned(16))) float buf[256];
     for (int i = threadIdx.x; i < 256; i += 64) buf[i] = 1.0f + i;
     __syncthreads();
     const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)buf;   // escapes: the stores stay
-    const unsigned far = base + 0x40000u + threadIdx.x * 16u, near = base + (threadIdx.x & 3) * 16u;
-    f32x4 a, b;
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(far), "v"(near) : "memory");
-    *(f32x4*)(out + threadIdx.x * 4) = a;
-    if (threadIdx.x == 0) *(f32x4*)(out + 256) = b;
+    const int lane = threadIdx.x;
+    unsigned bits;
+    if (lane < 10) {
+        bits = 1u << (18 + lane);
+    } else if (lane < 55) {
+        int k = lane - 10, a = 18;
+        while (k >= 27 - a) { k -= 27 - a; ++a; }                       // pair index -> (a, b), a < b
+        bits = (1u << a) | (1u << (a + 1 + k));
+    } else {
+        bits = 0x0FFC0000u >> (lane - 55) & 0x0FFC0000u;                // runs of the ten bits
+    }
+    const unsigned far = base + (lane & 15) * 16u + bits, near = base + (lane & 3) * 16u;
+    f32x4 a0, a1, b;
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:12288\n\tds_read_b128 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(b) : "v"(far), "v"(near) : "memory");
+    *(f32x4*)(out + lane * 8) = a0;
+    *(f32x4*)(out + lane * 8 + 4) = a1;
+    if (lane == 0) *(f32x4*)(out + 512) = b;
 }
+constexpr int PROBE_FLOATS = 516;
+bool g_contract_ok[64] = {};      // per device: set by the probe at alink_init / finalize on that device
 }  // namespace
-// Run once per device at alink_init: the linear-tile kernel is used only where the contract it rests on holds
-// (otherwise every width falls back to the row-aligned / implicit-GEMM kernels, which need no such contract).
+// Run once per device (init_kernels): the linear-tile kernel is used on a device only where the contract it rests
+// on holds there (otherwise every width takes the row-aligned / implicit-GEMM kernels, which need no such contract).
 hipError_t linear_check_contract() {
+    const int dev = current_device();
     float* d = nullptr;
-    hipError_t e = hipMalloc((void**)&d, 260 * sizeof(float));
+    hipError_t e = hipMalloc((void**)&d, PROBE_FLOATS * sizeof(float));
     if (e != hipSuccess) return e;
-    float h[260];
-    for (int i = 0; i < 260; ++i) h[i] = 7.f;
+    float h[PROBE_FLOATS];
+    for (int i = 0; i < PROBE_FLOATS; ++i) h[i] = 7.f;
     e = hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(lds_oob_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, d);
@@ -371,20 +395,28 @@ hipError_t linear_check_contract() {
     if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return e;
-    bool ok = h[256] == 1.f && h[257] == 2.f && h[258] == 3.f && h[259] == 4.f;
-    for (int i = 0; i < 256; ++i) ok = ok && h[i] == 0.f;
-    if (!ok) g_linear_mode = 0;
+    bool ok = h[512] == 1.f && h[513] == 2.f && h[514] == 3.f && h[515] == 4.f;
+    for (int i = 0; i < 512; ++i) ok = ok && h[i] == 0.f;
+    if (dev >= 0 && dev < 64) g_contract_ok[dev] = ok;
     return hipSuccess;
 }
 
-extern "C" int alink_debug_lds_oob_probe(float* dev_out260, void* stream) {
-    hipLaunchKernelGGL(lds_oob_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_out260);
+extern "C" int alink_debug_lds_oob_probe(float* dev_out516, void* stream) {
+    DeviceGuard dg(device_of_pointer(dev_out516));
+    hipLaunchKernelGGL(lds_oob_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_out516);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// 1 if the probe passed on the current device (the debug mode setter cannot override a failed probe)
+extern "C" int alink_debug_linear_contract_ok(void) {
+    const int dev = current_device();
+    return dev >= 0 && dev < 64 && g_contract_ok[dev] ? 1 : 0;
 }
 
 // 11 / 12 / 13 / 14: linear-tile kernel for 14 / 28 / 56 / 7-wide square maps (0 = not applicable)
 int linear_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout) {
     if (ksz != 3 || stride != 1 || pad != 1 || H != W || Cin % 64) return 0;
+    const int dev = current_device();
+    if (dev < 0 || dev >= 64 || !g_contract_ok[dev]) return 0;        // the probe failed (or never ran) on this device
     if ((g_linear_mode & 4) && W == 14 && Cout % 128 == 0) return 11;
     if ((g_linear_mode & 2) && W == 28 && Cout % 128 == 0) return 12;
     if ((g_linear_mode & 1) && W == 56 && Cout % 64 == 0) return 13;

@@ -75,6 +75,7 @@ extern "C" int alink_roc_counts(const float* dev_scores, const uint8_t* dev_mask
                                 const double* dev_thr_sorted, int n_thr, int roc_case,
                                 unsigned long long* dev_hist, void* stream) {
     ALINK_REQUIRE(dev_scores && dev_mask && dev_thr_sorted && dev_hist, ALINK_EINVAL, "NULL argument");
+    DeviceGuard dg(device_of_pointer(dev_scores));
     ALINK_REQUIRE(n >= 0 && n_thr > 0, ALINK_EINVAL, "n=%d, n_thr=%d", n, n_thr);
     ALINK_REQUIRE(roc_case >= 1 && roc_case <= 3, ALINK_EINVAL, "roc_case=%d must be 1, 2 or 3", roc_case);
     hipStream_t st = (hipStream_t)stream;

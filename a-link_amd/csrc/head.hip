@@ -27,6 +27,7 @@
 using namespace alink;
 
 struct alink_head {
+    int device = -1;             // the device the handle's memory lives on (current at create)
     int D, h1, h2;
     int od = 2;                  // outputs: 2 = Dense(2)+softmax (code/siamese.py:31-32), 1 = Dense(1, sigmoid) (code/siamese3.py:25)
     float lr, rho, eps;
@@ -1211,15 +1212,16 @@ int small_pass(alink_head* h, const float* L, const float* R, const float* y, co
     return ALINK_OK;
 }
 
-bool g_head_attr_done = false;
+unsigned long long g_head_attr_done = 0;      // one bit per device: function attributes are per device
 int head_init_attrs() {
-    if (g_head_attr_done) return ALINK_OK;
+    const int dev = current_device();
+    if (dev >= 0 && dev < 64 && (g_head_attr_done >> dev & 1ull)) return ALINK_OK;
     const int lds = (int)fwd_lds_bytes(512);
     ALINK_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     ALINK_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     ALINK_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     ALINK_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    g_head_attr_done = true;
+    if (dev >= 0 && dev < 64) g_head_attr_done |= 1ull << dev;
     return ALINK_OK;
 }
 
@@ -1238,6 +1240,7 @@ alink_head_t* alink_head_create_ex(int d_in, int h1, int h2, int out_dim, float 
     if (h2 != 32 && h2 != 64) { set_error("h2=%d must be 32 or 64", h2); return nullptr; }
     if (head_init_attrs()) return nullptr;
     alink_head* h = new alink_head();
+    h->device = current_device();
     h->D = d_in; h->h1 = h1; h->h2 = h2; h->od = out_dim; h->lr = lr; h->rho = rho; h->eps = eps;
     h->oW1 = 0; h->ob1 = (size_t)d_in * h1; h->oW2 = h->ob1 + h1; h->ob2 = h->oW2 + (size_t)h1 * h2;
     h->oW3 = h->ob2 + h2; h->ob3 = h->oW3 + (size_t)h2 * out_dim; h->nparams = h->ob3 + out_dim;
@@ -1260,12 +1263,17 @@ alink_head_t* alink_head_create_ex(int d_in, int h1, int h2, int out_dim, float 
     return h;
 }
 
-void alink_head_destroy(alink_head_t* h) { delete h; }
+void alink_head_destroy(alink_head_t* h) {
+    if (!h) return;
+    DeviceGuard dg(h->device);
+    delete h;
+}
 size_t alink_head_num_params(const alink_head_t* h) { return h ? h->nparams : 0; }
 
 int alink_head_set_params(alink_head_t* h, const float* host_params, size_t count) {
     ALINK_REQUIRE(h && host_params, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(count == h->nparams, ALINK_EINVAL, "expected %zu parameters, got %zu", h->nparams, count);
+    DeviceGuard dg(h->device);
     ALINK_HIP(hipMemcpy(h->d_params, host_params, count * sizeof(float), hipMemcpyHostToDevice));
     h->packed_dirty = true;
     return ALINK_OK;
@@ -1273,12 +1281,14 @@ int alink_head_set_params(alink_head_t* h, const float* host_params, size_t coun
 int alink_head_get_params(const alink_head_t* h, float* host_params, size_t count) {
     ALINK_REQUIRE(h && host_params, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(count == h->nparams, ALINK_EINVAL, "expected %zu parameters, got %zu", h->nparams, count);
+    DeviceGuard dg(h->device);
     ALINK_HIP(hipDeviceSynchronize());
     ALINK_HIP(hipMemcpy(host_params, h->d_params, count * sizeof(float), hipMemcpyDeviceToHost));
     return ALINK_OK;
 }
 int alink_head_reset_optimizer(alink_head_t* h) {
     ALINK_REQUIRE(h, ALINK_EINVAL, "NULL head");
+    DeviceGuard dg(h->device);
     ALINK_HIP(hipMemset(h->d_acc, 0, h->nparams * sizeof(float)));
     ALINK_HIP(hipMemset(h->d_dacc, 0, h->nparams * sizeof(float)));
     return ALINK_OK;
@@ -1299,6 +1309,7 @@ float* alink_head_grads_dev(alink_head_t* h) { return h ? h->d_grads : nullptr; 
 int alink_head_forward(alink_head_t* h, const float* dev_L, const float* dev_R, const int32_t* dev_li,
                        const int32_t* dev_ri, int64_t P, float* dev_probs, void* stream) {
     ALINK_REQUIRE(h && dev_L && dev_R && dev_probs, ALINK_EINVAL, "NULL argument");
+    DeviceGuard dg(h->device);
     if (P == 0) return ALINK_OK;
     ALINK_REQUIRE(P > 0, ALINK_EINVAL, "negative pair count");
     return launch_fwd(h, dev_L, dev_R, dev_li, dev_ri, P, dev_probs, 0, 0.f, (hipStream_t)stream);
@@ -1309,6 +1320,8 @@ int alink_committee_forward(alink_head_t* const* heads, int n_heads, const float
                             void* dev_scratch, void* stream) {
     (void)dev_scratch;
     ALINK_REQUIRE(heads && n_heads > 0 && dev_L && dev_R && dev_probs, ALINK_EINVAL, "bad argument");
+    ALINK_REQUIRE(heads[0], ALINK_EINVAL, "NULL committee member 0");
+    DeviceGuard dg(heads[0]->device);
     if (P == 0) return ALINK_OK;
     for (int m = 0; m < n_heads; ++m) {
         ALINK_REQUIRE(heads[m], ALINK_EINVAL, "NULL committee member %d", m);
@@ -1320,9 +1333,30 @@ int alink_committee_forward(alink_head_t* const* heads, int n_heads, const float
     return ALINK_OK;
 }
 
+int alink_committee_forward_multi(alink_head_t* const* heads, int n_heads, const float* const* dev_L,
+                                  const float* const* dev_R, const int32_t* dev_li, const int32_t* dev_ri, int64_t P,
+                                  float* dev_probs, void* stream) {
+    ALINK_REQUIRE(heads && n_heads > 0 && dev_L && dev_R && dev_probs, ALINK_EINVAL, "bad argument");
+    ALINK_REQUIRE(heads[0], ALINK_EINVAL, "NULL committee member 0");
+    DeviceGuard dg(heads[0]->device);
+    if (P == 0) return ALINK_OK;
+    ALINK_REQUIRE(P > 0, ALINK_EINVAL, "negative pair count");
+    for (int m = 0; m < n_heads; ++m) {
+        ALINK_REQUIRE(heads[m] && dev_L[m] && dev_R[m], ALINK_EINVAL, "NULL committee member / matrix %d", m);
+        ALINK_REQUIRE(heads[m]->device == heads[0]->device, ALINK_EINVAL, "committee members live on different devices");
+        // same accumulation as alink_committee_forward: member softmaxes added in member order, one divide
+        const int rc = launch_fwd(heads[m], dev_L[m], dev_R[m], dev_li, dev_ri, P, dev_probs, m > 0,
+                                  m == n_heads - 1 ? (float)n_heads : 0.f, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return ALINK_OK;
+}
+
 int alink_pair_scores_matrix(alink_head_t* const* heads, int n_heads, const float* dev_emb, int n, int row0,
                              int nrows, int col, float* dev_scores, void* stream) {
     ALINK_REQUIRE(heads && n_heads > 0 && dev_emb && dev_scores, ALINK_EINVAL, "bad argument");
+    ALINK_REQUIRE(heads[0], ALINK_EINVAL, "NULL committee member 0");
+    DeviceGuard dg(heads[0]->device);
     ALINK_REQUIRE(n > 0 && row0 >= 0 && nrows >= 0 && row0 + nrows <= n, ALINK_EINVAL,
                   "rows [%d, %d) outside a %d x %d matrix", row0, row0 + nrows, n, n);
     ALINK_REQUIRE(col >= 0 && col < heads[0]->od, ALINK_EINVAL, "col=%d outside the model's %d output(s)", col, heads[0]->od);
@@ -1360,6 +1394,7 @@ int alink_head_train_step(alink_head_t* h, const float* dev_L, const float* dev_
                           void* stream) {
     ALINK_REQUIRE(h && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(n > 0 && n <= h->cap, ALINK_EINVAL, "batch of %d rows outside 1..%d", n, h->cap);
+    DeviceGuard dg(h->device);
     hipStream_t st = (hipStream_t)stream;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     // the legacy default stream cannot be captured, and a stream the caller is already capturing must
@@ -1405,6 +1440,7 @@ int alink_head_train_step(alink_head_t* h, const float* dev_L, const float* dev_
 
 int alink_head_apply_update(alink_head_t* h, void* stream) {
     ALINK_REQUIRE(h, ALINK_EINVAL, "NULL head");
+    DeviceGuard dg(h->device);
     hipLaunchKernelGGL(adadelta_kernel, g1((long long)h->nparams), dim3(256), 0, (hipStream_t)stream,
                        h->d_params, h->d_grads, h->d_acc, h->d_dacc, h->nparams, h->lr, h->rho, h->eps);
     ALINK_HIP(hipGetLastError());
@@ -1416,6 +1452,7 @@ int alink_head_input_grads(alink_head_t* h, const float* dev_L, const float* dev
                            float* dev_dR, void* stream) {
     ALINK_REQUIRE(h && dev_L && dev_R && dev_dL && dev_dR, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(n > 0 && n <= h->cap, ALINK_EINVAL, "batch of %d rows outside 1..%d", n, h->cap);
+    DeviceGuard dg(h->device);
     hipLaunchKernelGGL(head_input_grad_kernel, g1((long long)n * h->D), dim3(256), 0, (hipStream_t)stream, dev_L,
                        dev_R, h->d_dz1, h->d_params + h->oW1, dev_dL, dev_dR, n, h->D, h->h1);
     ALINK_HIP(hipGetLastError());
@@ -1425,6 +1462,7 @@ int alink_head_input_grads(alink_head_t* h, const float* dev_L, const float* dev
 int alink_head_eval(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y, int n,
                     float* dev_metrics, void* stream) {
     ALINK_REQUIRE(h && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
+    DeviceGuard dg(h->device);
     return small_pass(h, dev_L, dev_R, dev_y, nullptr, n, 0.f, false, dev_metrics, (hipStream_t)stream);
 }
 

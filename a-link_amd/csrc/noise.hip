@@ -364,6 +364,7 @@ extern "C" {
 int alink_noise_gaussian(const float* dev_in, float* dev_out, int64_t count, float mean, float sigma,
                          uint64_t seed, uint64_t offset, void* stream) {
     ALINK_REQUIRE(dev_in && dev_out && count >= 0, ALINK_EINVAL, "bad argument");
+    DeviceGuard dg(device_of_pointer(dev_out));
     ALINK_REQUIRE((offset & 3) == 0, ALINK_EINVAL, "offset must be a multiple of 4");
     if (count == 0) return ALINK_OK;
     AffineNoise p{dev_in, dev_out, count, seed, offset, mean, sigma, 0};
@@ -375,6 +376,7 @@ int alink_noise_gaussian(const float* dev_in, float* dev_out, int64_t count, flo
 int alink_noise_speckle(const float* dev_in, float* dev_out, int64_t count, float divisor, uint64_t seed,
                         uint64_t offset, void* stream) {
     ALINK_REQUIRE(dev_in && dev_out && count >= 0 && divisor != 0.f, ALINK_EINVAL, "bad argument");
+    DeviceGuard dg(device_of_pointer(dev_out));
     ALINK_REQUIRE((offset & 3) == 0, ALINK_EINVAL, "offset must be a multiple of 4");
     if (count == 0) return ALINK_OK;
     AffineNoise p{dev_in, dev_out, count, seed, offset, divisor, 0.f, 1};
@@ -386,6 +388,7 @@ int alink_noise_speckle(const float* dev_in, float* dev_out, int64_t count, floa
 int alink_noise_saltpepper(const float* dev_in, float* dev_out, int n_images, int H, int W, int C, int n_salt,
                            int n_pepper, uint64_t seed, void* stream) {
     ALINK_REQUIRE(dev_in && dev_out && n_images >= 0, ALINK_EINVAL, "bad argument");
+    DeviceGuard dg(device_of_pointer(dev_out));
     // np.random.randint(0, i - 1) needs i - 1 > 0 for every axis (code/noise.py:59,63)
     ALINK_REQUIRE(H >= 2 && W >= 2 && C >= 2, ALINK_EINVAL, "low >= high: image %dx%dx%d has an axis shorter than 2", H, W, C);
     ALINK_REQUIRE(n_salt >= 0 && n_pepper >= 0, ALINK_EINVAL, "negative counts");
@@ -410,6 +413,7 @@ int alink_perlin_nodes(int size, const int* ns3) {
 
 int alink_perlin_vectors(int n_images, int nodes_total, uint64_t seed, float* dev_vec, void* stream) {
     ALINK_REQUIRE(dev_vec && n_images >= 0 && nodes_total > 0, ALINK_EINVAL, "bad argument");
+    DeviceGuard dg(device_of_pointer(dev_vec));
     const long long n = (long long)n_images * nodes_total;
     if (n == 0) return ALINK_OK;
     hipLaunchKernelGGL(perlin_vectors_kernel, g1((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dev_vec, n, seed);
@@ -420,6 +424,7 @@ int alink_perlin_vectors(int n_images, int nodes_total, uint64_t seed, float* de
 int alink_noise_perlin(const float* dev_in, float* dev_out, int n_images, int size, int C, const int* ns3,
                        const float* dev_vec, void* stream) {
     ALINK_REQUIRE(dev_in && dev_out && dev_vec && ns3 && n_images >= 0 && size > 0 && C > 0, ALINK_EINVAL, "bad argument");
+    DeviceGuard dg(device_of_pointer(dev_out));
     PerlinP p{};
     p.in = dev_in; p.out = dev_out; p.vec = dev_vec; p.size = size; p.C = C;
     int off = 0;
@@ -450,6 +455,7 @@ size_t alink_noise_poisson_scratch_bytes(int n_images, int64_t per_image) {
 int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64_t per_image, uint64_t seed,
                         void* dev_scratch, size_t scratch_bytes, float* dev_vals, void* stream) {
     ALINK_REQUIRE(dev_in && dev_out && n_images >= 0 && per_image > 0, ALINK_EINVAL, "bad argument");
+    DeviceGuard dg(device_of_pointer(dev_out));
     ALINK_REQUIRE(per_image < (1ll << 30), ALINK_EINVAL, "image of %lld elements too large", (long long)per_image);
     if (n_images == 0) return ALINK_OK;
     const size_t need = alink_noise_poisson_scratch_bytes(n_images, per_image);
@@ -473,6 +479,7 @@ int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64
 int alink_resize_bilinear(const float* dev_in, float* dev_out, int n, int H, int W, int C, int Ho, int Wo,
                           void* stream) {
     ALINK_REQUIRE(dev_in && dev_out && n >= 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, ALINK_EINVAL, "bad argument");
+    DeviceGuard dg(device_of_pointer(dev_out));
     const long long total = (long long)n * Ho * Wo * C;
     if (total == 0) return ALINK_OK;
     ALINK_REQUIRE(total < (1ll << 39), ALINK_EINVAL, "output too large");
@@ -485,6 +492,7 @@ int alink_resize_bilinear(const float* dev_in, float* dev_out, int n, int H, int
 int alink_perturb_images(const float* dev_img, const double* dev_xs, int n, int k, int Hc, int W, int split,
                          float* dev_out, void* stream) {
     ALINK_REQUIRE(dev_img && dev_xs && dev_out && n >= 0 && k >= 0 && Hc > 0 && W > 0, ALINK_EINVAL, "bad argument");
+    DeviceGuard dg(device_of_pointer(dev_out));
     ALINK_REQUIRE(!split || (Hc % 2) == 0, ALINK_EINVAL, "split needs an even number of rows, got %d", Hc);
     if (n == 0) return ALINK_OK;
     PerturbP p{dev_img, dev_xs, dev_out, n, k, Hc, W, split};

@@ -202,6 +202,7 @@ struct Op {
 using namespace alink;
 
 struct alink_resnet50 {
+    int device = -1;
     int H, W, dtype;
     float eps;
     std::vector<std::pair<std::string, size_t>> expected;
@@ -307,6 +308,7 @@ alink_resnet50_t* alink_resnet50_create(int height, int width, int dtype, float 
     if (dtype != ALINK_DT_BF16 && dtype != ALINK_DT_F16) { set_error("bad dtype"); return nullptr; }
     if (height < 32 || width < 32) { set_error("input %dx%d too small", height, width); return nullptr; }
     alink_resnet50* r = new alink_resnet50();
+    r->device = current_device();
     r->H = height; r->W = width; r->dtype = dtype; r->eps = bn_eps > 0.f ? bn_eps : 1e-3f;
     r->Ho1 = same_out(height, 2); r->Wo1 = same_out(width, 2);
     r->Hp = (r->Ho1 - 3) / 2 + 1; r->Wp = (r->Wo1 - 3) / 2 + 1;
@@ -335,7 +337,11 @@ alink_resnet50_t* alink_resnet50_create(int height, int width, int dtype, float 
     return r;
 }
 
-void alink_resnet50_destroy(alink_resnet50_t* r) { delete r; }
+void alink_resnet50_destroy(alink_resnet50_t* r) {
+    if (!r) return;
+    DeviceGuard dg(r->device);
+    delete r;
+}
 int alink_resnet50_num_tensors(const alink_resnet50_t* r) { return r ? (int)r->expected.size() : 0; }
 int alink_resnet50_tensor_info(const alink_resnet50_t* r, int i, const char** name, size_t* count) {
     ALINK_REQUIRE(r && i >= 0 && i < (int)r->expected.size(), ALINK_EINVAL, "tensor index out of range");
@@ -359,6 +365,7 @@ int alink_resnet50_load(alink_resnet50_t* r, const char* name, const float* host
 
 int alink_resnet50_finalize(alink_resnet50_t* r) {
     ALINK_REQUIRE(r && !r->finalized, ALINK_ESTATE, "bad state");
+    DeviceGuard dg(r->device);
     for (const auto& e : r->expected)
         ALINK_REQUIRE(r->raw.count(e.first), ALINK_ESTATE, "tensor %s was never loaded", e.first.c_str());
     int rc = init_kernels();
@@ -508,6 +515,8 @@ static int r50_run(alink_resnet50_t* r, const float* dev_in, int n, int preproce
 
 int alink_resnet50_embed(alink_resnet50_t* r, const float* dev_in, int n_images, int preprocessed, float* dev_out,
                          void* dev_workspace, size_t workspace_bytes, void* stream) {
+    ALINK_REQUIRE(r, ALINK_EINVAL, "NULL network");
+    DeviceGuard dg(r->device);
     return r50_run(r, dev_in, n_images, preprocessed, dev_out, dev_workspace, workspace_bytes, (hipStream_t)stream,
                    nullptr, nullptr, nullptr);
 }
@@ -515,6 +524,8 @@ int alink_resnet50_embed(alink_resnet50_t* r, const float* dev_in, int n_images,
 int alink_resnet50_profile(alink_resnet50_t* r, const float* dev_in, int n_images, float* dev_out, void* dev_workspace,
                            size_t workspace_bytes, void* stream, float* ms, double* flops, int* n_ops) {
     ALINK_REQUIRE(ms && flops && n_ops && *n_ops > 0, ALINK_EINVAL, "NULL profile buffers");
+    ALINK_REQUIRE(r, ALINK_EINVAL, "NULL network");
+    DeviceGuard dg(r->device);
     return r50_run(r, dev_in, n_images, 0, dev_out, dev_workspace, workspace_bytes, (hipStream_t)stream, ms, flops, n_ops);
 }
 

@@ -195,6 +195,7 @@ extern "C" {
 int alink_score(int kind, const float* dev_probs, const float* dev_b, int col, int64_t P, int C,
                 float* dev_scores, void* stream) {
     ALINK_REQUIRE(dev_probs && dev_scores, ALINK_EINVAL, "NULL argument");
+    DeviceGuard dg(device_of_pointer(dev_probs));
     ALINK_REQUIRE(kind >= 0 && kind <= 3, ALINK_EINVAL, "unknown score kind %d", kind);
     ALINK_REQUIRE(C >= 1, ALINK_EINVAL, "C must be >= 1");
     ALINK_REQUIRE(kind != ALINK_SCORE_DISPARITY || (dev_b && col >= 0 && col < C), ALINK_EINVAL,
@@ -216,6 +217,7 @@ size_t alink_topk_scratch_bytes(int64_t P, int k) {
 int alink_topk(const float* dev_scores, int64_t P, int k, int largest, int32_t* dev_idx, float* dev_vals,
                void* dev_scratch, void* stream) {
     ALINK_REQUIRE(dev_scores && dev_idx && dev_scratch, ALINK_EINVAL, "NULL argument");
+    DeviceGuard dg(device_of_pointer(dev_scores));
     ALINK_REQUIRE(P > 0 && P < (1ll << 31), ALINK_EINVAL, "P=%lld outside 1..2^31-1", (long long)P);
     ALINK_REQUIRE(k > 0 && k <= P, ALINK_EINVAL, "k=%d outside 1..P", k);
     ALINK_REQUIRE(((uintptr_t)dev_scratch & 255) == 0, ALINK_EINVAL, "scratch must be 256-byte aligned");

@@ -98,6 +98,7 @@ __global__ void adadelta2_kernel(float* __restrict__ prm, const float* __restric
 }  // namespace
 
 struct alink_smallres {
+    int device = -1;
     int H, W, feat;
     float lr, rho, eps;
     // tower geometry
@@ -217,6 +218,7 @@ alink_smallres_t* alink_smallres_create(int img_h, int img_w, int feat, float lr
     if (img_h < 12 || img_w < 12 || img_h > 128 || img_w > 128) { set_error("image size %dx%d unsupported", img_h, img_w); return nullptr; }
     if (feat <= 0 || feat % 8) { set_error("feat must be a positive multiple of 8"); return nullptr; }
     alink_smallres* m = new alink_smallres();
+    m->device = current_device();
     m->H = img_h; m->W = img_w; m->feat = feat; m->lr = lr; m->rho = rho; m->eps = eps;
     m->H1 = img_h - 2; m->W1 = img_w - 2;
     m->P1h = m->H1 / 2; m->P1w = m->W1 / 2;
@@ -252,11 +254,16 @@ alink_smallres_t* alink_smallres_create(int img_h, int img_w, int feat, float lr
     return m;
 }
 
-void alink_smallres_destroy(alink_smallres_t* m) { delete m; }
+void alink_smallres_destroy(alink_smallres_t* m) {
+    if (!m) return;
+    DeviceGuard dg(m->device);
+    delete m;
+}
 size_t alink_smallres_num_params(const alink_smallres_t* m) { return m ? m->ntower + alink_head_num_params(m->head) : 0; }
 
 int alink_smallres_set_params(alink_smallres_t* m, const float* host, size_t count) {
     ALINK_REQUIRE(m && host, ALINK_EINVAL, "NULL argument");
+    DeviceGuard dg(m->device);
     ALINK_REQUIRE(count == alink_smallres_num_params(m), ALINK_EINVAL, "expected %zu parameters, got %zu",
                   alink_smallres_num_params(m), count);
     ALINK_HIP(hipMemcpy(m->d_p, host, m->ntower * sizeof(float), hipMemcpyHostToDevice));
@@ -265,6 +272,7 @@ int alink_smallres_set_params(alink_smallres_t* m, const float* host, size_t cou
 int alink_smallres_get_params(const alink_smallres_t* m, float* host, size_t count) {
     ALINK_REQUIRE(m && host, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(count == alink_smallres_num_params(m), ALINK_EINVAL, "bad parameter count");
+    DeviceGuard dg(m->device);
     ALINK_HIP(hipDeviceSynchronize());
     ALINK_HIP(hipMemcpy(host, m->d_p, m->ntower * sizeof(float), hipMemcpyDeviceToHost));
     return alink_head_get_params(m->head, host + m->ntower, count - m->ntower);
@@ -310,6 +318,7 @@ int alink_smallres_forward(alink_smallres_t* m, const float* dev_L, const float*
                            float* dev_probs, void* stream) {
     ALINK_REQUIRE(m && dev_L && dev_R && dev_probs, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
+    DeviceGuard dg(m->device);
     hipStream_t st = (hipStream_t)stream;
     int rc = tower_pair_fwd(m, dev_L, dev_R, n, prescale, nullptr, st, false);
     if (rc) return rc;
@@ -320,6 +329,7 @@ int alink_smallres_eval(alink_smallres_t* m, const float* dev_L, const float* de
                         int prescale, float* dev_metrics, void* stream) {
     ALINK_REQUIRE(m && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
+    DeviceGuard dg(m->device);
     int rc = tower_pair_fwd(m, dev_L, dev_R, n, prescale, nullptr, (hipStream_t)stream, false);
     if (rc) return rc;
     return alink_head_eval(m->head, m->f, m->f + (size_t)n * m->feat, dev_y, n, dev_metrics, stream);
@@ -330,6 +340,7 @@ int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const flo
                               int apply, float* dev_metrics, void* stream) {
     ALINK_REQUIRE(m && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
+    DeviceGuard dg(m->device);
     hipStream_t st = (hipStream_t)stream;
     int rc = tower_pair_fwd(m, dev_L, dev_R, n, prescale, dev_masks, st, true);
     if (rc) return rc;
@@ -389,6 +400,7 @@ int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const flo
 
 int alink_smallres_apply_update(alink_smallres_t* m, void* stream) {
     ALINK_REQUIRE(m, ALINK_EINVAL, "NULL model");
+    DeviceGuard dg(m->device);
     hipStream_t st = (hipStream_t)stream;
     // gradients are taken from the contiguous buffer (the caller may have all-reduced it)
     hipLaunchKernelGGL(adadelta2_kernel, g1((long long)m->ntower), dim3(256), 0, st, m->d_p, m->d_all_grads, m->d_a,

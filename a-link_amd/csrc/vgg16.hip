@@ -67,6 +67,7 @@ uint16_t cvt16(int dtype, float f) { return dtype == ALINK_DT_BF16 ? f32_to_bf16
 using namespace alink;
 
 struct alink_vgg16 {
+    int device = -1;
     int H, W, dtype;
     std::vector<std::pair<std::string, size_t>> expected;
     std::map<std::string, std::vector<float>> raw;
@@ -105,6 +106,7 @@ alink_vgg16_t* alink_vgg16_create(int height, int width, int dtype) {
     if (dtype != ALINK_DT_BF16 && dtype != ALINK_DT_F16) { set_error("bad dtype"); return nullptr; }
     if (height < 32 || width < 32 || height > 512 || width > 512) { set_error("input %dx%d unsupported", height, width); return nullptr; }
     alink_vgg16* r = new alink_vgg16();
+    r->device = current_device();
     r->H = height; r->W = width; r->dtype = dtype;
     int cin = 3;
     for (int b = 0; b < 5; ++b)
@@ -117,7 +119,11 @@ alink_vgg16_t* alink_vgg16_create(int height, int width, int dtype) {
     return r;
 }
 
-void alink_vgg16_destroy(alink_vgg16_t* r) { delete r; }
+void alink_vgg16_destroy(alink_vgg16_t* r) {
+    if (!r) return;
+    DeviceGuard dg(r->device);
+    delete r;
+}
 int alink_vgg16_num_tensors(const alink_vgg16_t* r) { return r ? (int)r->expected.size() : 0; }
 int alink_vgg16_tensor_info(const alink_vgg16_t* r, int i, const char** name, size_t* count) {
     ALINK_REQUIRE(r && i >= 0 && i < (int)r->expected.size(), ALINK_EINVAL, "tensor index out of range");
@@ -142,6 +148,7 @@ int alink_vgg16_load(alink_vgg16_t* r, const char* name, const float* host, size
 
 int alink_vgg16_finalize(alink_vgg16_t* r) {
     ALINK_REQUIRE(r && !r->finalized, ALINK_ESTATE, "bad state");
+    DeviceGuard dg(r->device);
     for (const auto& e : r->expected)
         ALINK_REQUIRE(r->raw.count(e.first), ALINK_ESTATE, "tensor %s was never loaded", e.first.c_str());
     int rc = init_kernels();
@@ -213,6 +220,7 @@ size_t alink_vgg16_workspace_bytes(const alink_vgg16_t* r, int n_images) {
 int alink_vgg16_embed(alink_vgg16_t* r, const float* dev_in, int n, int preprocessed, float* dev_out, void* ws,
                       size_t ws_bytes, void* stream) {
     ALINK_REQUIRE(r && r->finalized, ALINK_ESTATE, "alink_vgg16_embed before finalize");
+    DeviceGuard dg(r->device);
     ALINK_REQUIRE(dev_in && dev_out && ws && n > 0, ALINK_EINVAL, "bad argument");
     ALINK_REQUIRE(((uintptr_t)ws & 255) == 0, ALINK_EINVAL, "workspace must be 256-byte aligned");
     ALINK_REQUIRE(ws_bytes >= alink_vgg16_workspace_bytes(r, n), ALINK_ENOMEM, "workspace too small");

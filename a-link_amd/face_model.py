@@ -20,7 +20,9 @@ def get_model(ctx, image_size, model_str, layer, dtype="bf16", max_batch=292, en
               small_batch_split=False):
     assert layer == "fc1", "the reference slices the symbol at fc1_output (code/face_model.py:36,53)"
     params, cfg = W.resolve_model_config(model_str, image_size)
-    device = ctx if isinstance(ctx, int) else 0
+    # ctx: a device index as the reference passes (mx.gpu(args.gpu), code/face_model.py:46,57); None = the process's
+    # current device (one process per GPU: torch.cuda.set_device(LOCAL_RANK))
+    device = int(ctx) if isinstance(ctx, (int, np.integer)) and not isinstance(ctx, bool) else None
     return IRBackbone(params, image_size=image_size, emb=cfg["emb"], dtype=dtype, device=device, max_batch=max_batch,
                       widths=cfg["widths"], bn_eps=cfg["bn_eps"], enable_grad=enable_grad,
                       small_batch_split=small_batch_split)
@@ -35,7 +37,7 @@ class FaceModel(object):
         self.model = None
         self.ga_model = None
         if len(args.model) > 0:
-            self.model = get_model(getattr(args, "gpu", 0), image_size, args.model, 'fc1',
+            self.model = get_model(getattr(args, "gpu", None), image_size, args.model, 'fc1',
                                    dtype=getattr(args, "dtype", "bf16"),
                                    max_batch=getattr(args, "max_batch", 292),
                                    enable_grad=bool(args.get("enable_grad", False)) if hasattr(args, "get") else False,

@@ -154,7 +154,8 @@ class DenseHead(KerasFitMixin):
         self.device = "cuda:%d" % device
         self.lib = _abi.init(device)
         self.d_in, self.h1, self.h2, self.out_dim = int(d_in), int(h1), int(h2), int(out_dim)
-        self.h = self.lib.alink_head_create_ex(self.d_in, self.h1, self.h2, self.out_dim, lr, rho, eps)
+        with _abi.on_device(device):                  # the handle lives on the device current at create
+            self.h = self.lib.alink_head_create_ex(self.d_in, self.h1, self.h2, self.out_dim, lr, rho, eps)
         if not self.h:
             raise _abi.AlinkError("alink_head_create: " + self.lib.alink_last_error().decode())
         self.loss = "binary_crossentropy"               # what keras_wrapper reads off model.loss
@@ -301,7 +302,7 @@ class DenseHead(KerasFitMixin):
         if P == 0:
             return out
         _abi.check(self.lib.alink_head_forward(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(li), _abi.ptr(ri), P,
-                                               _abi.ptr(out), _abi.current_stream()), "alink_head_forward")
+                                               _abi.ptr(out), _abi.current_stream(self.device)), "alink_head_forward")
         return out
 
     def predict(self, X, batch_size=1024, verbose=0):
@@ -346,9 +347,9 @@ class DenseHead(KerasFitMixin):
         swd = self._staged("sw", sw) if sw is not None else None
         n = L.shape[0]
         _abi.check(self.lib.alink_head_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
-                                                  0.0, 1, _abi.ptr(self._metrics_host), _abi.current_stream()),
+                                                  0.0, 1, _abi.ptr(self._metrics_host), _abi.current_stream(self.device)),
                    "alink_head_train_step")
-        self.torch.cuda.current_stream().synchronize()
+        self.torch.cuda.current_stream(self.device).synchronize()
         return self._metrics_host.tolist()
 
     def input_gradients(self, L, R, y):
@@ -359,25 +360,36 @@ class DenseHead(KerasFitMixin):
         n = L.shape[0]
         dL, dR = torch.empty_like(L), torch.empty_like(R)
         _abi.check(self.lib.alink_head_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), None, n, 0.0, 0,
-                                                  _abi.ptr(self._metrics), _abi.current_stream()), "alink_head_train_step")
+                                                  _abi.ptr(self._metrics), _abi.current_stream(self.device)), "alink_head_train_step")
         _abi.check(self.lib.alink_head_input_grads(self.h, _abi.ptr(L), _abi.ptr(R), n, _abi.ptr(dL), _abi.ptr(dR),
-                                                   _abi.current_stream()), "alink_head_input_grads")
+                                                   _abi.current_stream(self.device)), "alink_head_input_grads")
         return dL, dR
 
     def test_on_batch(self, x, y):
         L, R = self._dev(x[0]), self._dev(x[1])
         yd = self._dev(y)
         _abi.check(self.lib.alink_head_eval(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), L.shape[0],
-                                            _abi.ptr(self._metrics_host), _abi.current_stream()), "alink_head_eval")
-        self.torch.cuda.current_stream().synchronize()
+                                            _abi.ptr(self._metrics_host), _abi.current_stream(self.device)), "alink_head_eval")
+        self.torch.cuda.current_stream(self.device).synchronize()
         return self._metrics_host.tolist()
 
 
 def committee_predict_device(heads, L, R, li=None, ri=None):
-    """Bagging.predict on device: sum of member softmaxes / M (reference code/committee.py:13-20)."""
+    """Bagging.predict on device: sum of member softmaxes / M (reference code/committee.py:13-20).
+    L / R: one pair of matrices shared by every member, or a list with one matrix per member (members with
+    different feature extractors) — then li / ri index every member's own matrices."""
     h0 = heads[0]
     torch = h0.torch
-    L, R = h0._dev(L), h0._dev(R)
+    per_member = isinstance(L, (list, tuple))
+    if per_member:
+        if len(L) != len(heads) or len(R) != len(heads):
+            raise ValueError("%d members but %d / %d feature matrices" % (len(heads), len(L), len(R)))
+        Ls, Rs = [h0._dev(a) for a in L], [h0._dev(a) for a in R]
+        if any(a.shape != Ls[0].shape for a in Ls) or any(a.shape != Rs[0].shape for a in Rs):
+            raise ValueError("per-member feature matrices must have one shape")
+        L, R = Ls[0], Rs[0]
+    else:
+        L, R = h0._dev(L), h0._dev(R)
     if li is not None:
         li, ri = h0._dev(li, torch.int32), h0._dev(ri, torch.int32)
         P = li.numel()
@@ -387,6 +399,13 @@ def committee_predict_device(heads, L, R, li=None, ri=None):
     if P == 0:
         return out
     arr = (C.c_void_p * len(heads))(*[h.h for h in heads])
+    if per_member:
+        la = (C.c_void_p * len(heads))(*[a.data_ptr() for a in Ls])
+        ra = (C.c_void_p * len(heads))(*[a.data_ptr() for a in Rs])
+        _abi.check(h0.lib.alink_committee_forward_multi(arr, len(heads), la, ra, _abi.ptr(li), _abi.ptr(ri), P,
+                                                        _abi.ptr(out), _abi.current_stream(h0.device)),
+                   "alink_committee_forward_multi")
+        return out
     _abi.check(h0.lib.alink_committee_forward(arr, len(heads), _abi.ptr(L), _abi.ptr(R), _abi.ptr(li), _abi.ptr(ri),
-                                              P, _abi.ptr(out), None, _abi.current_stream()), "alink_committee_forward")
+                                              P, _abi.ptr(out), None, _abi.current_stream(h0.device)), "alink_committee_forward")
     return out

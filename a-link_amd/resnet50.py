@@ -98,8 +98,9 @@ class VGGResNet50(object):
             params = load_keras_h5(weights)
         else:
             params = weights
-        self.h = self.lib.alink_resnet50_create(int(image_size[0]), int(image_size[1]),
-                                                {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16}[dtype], float(bn_eps))
+        with _abi.on_device(device):
+            self.h = self.lib.alink_resnet50_create(int(image_size[0]), int(image_size[1]),
+                                                    {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16}[dtype], float(bn_eps))
         if not self.h:
             raise _abi.AlinkError("alink_resnet50_create: " + self.lib.alink_last_error().decode())
         name, cnt = C.c_char_p(), C.c_size_t()
@@ -142,7 +143,7 @@ class VGGResNet50(object):
             m = min(self.max_batch, n - i)
             ws, wsb = self._workspace(m)
             _abi.check(self.lib.alink_resnet50_embed(self.h, _abi.ptr(x[i:i + m]), m, 1 if preprocessed else 0,
-                                                     _abi.ptr(out[i:i + m]), C.c_void_p(ws), wsb, _abi.current_stream()),
+                                                     _abi.ptr(out[i:i + m]), C.c_void_p(ws), wsb, _abi.current_stream(self.device)),
                        "alink_resnet50_embed")
         return out
 
@@ -164,5 +165,5 @@ class VGGResNet50(object):
         cap = 128
         ms, fl, k = (C.c_float * cap)(), (C.c_double * cap)(), C.c_int(cap)
         _abi.check(self.lib.alink_resnet50_profile(self.h, _abi.ptr(x), n, _abi.ptr(out), C.c_void_p(ws), wsb,
-                                                   _abi.current_stream(), ms, fl, C.byref(k)), "alink_resnet50_profile")
+                                                   _abi.current_stream(self.device), ms, fl, C.byref(k)), "alink_resnet50_profile")
         return [(self.lib.alink_resnet50_op_name(self.h, i).decode(), ms[i], fl[i]) for i in range(k.value)]

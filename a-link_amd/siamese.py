@@ -195,13 +195,16 @@ class RESNET50:
 
 
 class ArcFace:
-    def __init__(self, shape, model_path, dtype="bf16", max_batch=292, enable_grad=False, small_batch_split=False):
+    def __init__(self, shape, model_path, dtype="bf16", max_batch=292, enable_grad=False, small_batch_split=False,
+                 gpu=None):
         args = _Args({
             "enable_grad": enable_grad,
             "small_batch_split": small_batch_split,   # latency mode for batches <= 32 (include/alink_hip.h)
             "image_size": "%d,%d" % (shape[0], shape[1]),
             "model": model_path + ",0",
-            "gpu": 0,
+            # the reference hard-codes gpu 0 (code/siamese.py:223) in a single-GPU process; here None = this
+            # process's current device, so that rank k of a one-process-per-GPU job builds its model on GPU k
+            "gpu": gpu,
             "threshold": 1.24,
             "dtype": dtype,
             "max_batch": max_batch,

@@ -28,7 +28,8 @@ class SmallResNet(KerasFitMixin):
         self.H, self.W = int(image_shape[0]), int(image_shape[1])
         assert int(image_shape[2]) == 3
         self.feat = int(feat)
-        self.h = self.lib.alink_smallres_create(self.H, self.W, self.feat, lr, rho, eps)
+        with _abi.on_device(device):
+            self.h = self.lib.alink_smallres_create(self.H, self.W, self.feat, lr, rho, eps)
         if not self.h:
             raise _abi.AlinkError("alink_smallres_create: " + self.lib.alink_last_error().decode())
         self.lr = lr
@@ -131,7 +132,7 @@ class SmallResNet(KerasFitMixin):
         for s in range(0, n, MAXN):
             m = min(MAXN, n - s)
             _abi.check(self.lib.alink_smallres_forward(self.h, _abi.ptr(L[s:s + m]), _abi.ptr(R[s:s + m]), m,
-                                                       self.prescale, _abi.ptr(out[s:s + m]), _abi.current_stream()),
+                                                       self.prescale, _abi.ptr(out[s:s + m]), _abi.current_stream(self.device)),
                        "alink_smallres_forward")
         return out if as_torch else out.cpu().numpy()
 
@@ -153,7 +154,7 @@ class SmallResNet(KerasFitMixin):
         md = self.torch.from_numpy(np.ascontiguousarray(masks, np.uint8)).to(self.device) if masks is not None else None
         _abi.check(self.lib.alink_smallres_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
                                                       self.prescale, _abi.ptr(md), 0.0, 1, _abi.ptr(self._metrics),
-                                                      _abi.current_stream()), "alink_smallres_train_step")
+                                                      _abi.current_stream(self.device)), "alink_smallres_train_step")
         m = self._metrics.cpu().numpy()
         return [float(m[0]), float(m[1])]
 
@@ -164,7 +165,7 @@ class SmallResNet(KerasFitMixin):
             m = min(MAXN, L.shape[0] - s)
             _abi.check(self.lib.alink_smallres_eval(self.h, _abi.ptr(L[s:s + m]), _abi.ptr(R[s:s + m]),
                                                     _abi.ptr(yd[s:s + m]), m, self.prescale, _abi.ptr(self._metrics),
-                                                    _abi.current_stream()), "alink_smallres_eval")
+                                                    _abi.current_stream(self.device)), "alink_smallres_eval")
             tot += self._metrics.cpu().numpy() * m
             seen += m
         return [float(tot[0] / seen), float(tot[1] / seen)]

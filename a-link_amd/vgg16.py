@@ -67,8 +67,9 @@ class VGGFace16(object):
         self.image_size = tuple(image_size)
         self.max_batch = int(max_batch)
         params = synthetic_params(seed) if weights is None else (load_keras_h5(weights) if isinstance(weights, str) else weights)
-        self.h = self.lib.alink_vgg16_create(int(image_size[0]), int(image_size[1]),
-                                             {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16}[dtype])
+        with _abi.on_device(device):
+            self.h = self.lib.alink_vgg16_create(int(image_size[0]), int(image_size[1]),
+                                                 {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16}[dtype])
         if not self.h:
             raise _abi.AlinkError("alink_vgg16_create: " + self.lib.alink_last_error().decode())
         name, cnt = C.c_char_p(), C.c_size_t()
@@ -110,7 +111,7 @@ class VGGFace16(object):
             m = min(self.max_batch, n - i)
             ws, wsb = self._workspace(m)
             _abi.check(self.lib.alink_vgg16_embed(self.h, _abi.ptr(x[i:i + m]), m, 1 if preprocessed else 0,
-                                                  _abi.ptr(out[i:i + m]), C.c_void_p(ws), wsb, _abi.current_stream()),
+                                                  _abi.ptr(out[i:i + m]), C.c_void_p(ws), wsb, _abi.current_stream(self.device)),
                        "alink_vgg16_embed")
         return out
 

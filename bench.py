@@ -114,6 +114,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(out).all()
+    # parity of what was just timed (cheap part, every rank): images embedded ALONE (batch 1: the 64-channel form of
+    # the linear-tile kernel) must equal their rows of the timed batch (128-channel form, launches on several streams) bit for bit
+    probe = sorted(set([0, 1, min(B - 1, args.chunk - 1), min(B - 1, args.chunk), B - 1]))
+    alone = torch.cat([bb.embed_device(x[i:i + 1]) for i in probe])
+    parity = {"batch1_rows_bit_equal_to_timed_batch": bool(torch.equal(alone, out[probe])), "rows_checked": probe}
+    assert parity["batch1_rows_bit_equal_to_timed_batch"], "embedding depends on the batch it was computed in"
 
     from oracle import ir_resnet     # FLOP count + cpu_baseline leg only
     gflop_per_emb = ir_resnet.flops_per_image(units) / 1e9
@@ -260,24 +266,61 @@ def main():
         line["pair_scores_per_s"] = 3 * (1 << 20) / (time.perf_counter() - t1)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # ---- CPU baseline: the oracle (kind "port": our CPU restatement; the reference's MXNet path
-        # cannot be installed) on a bounded sample of the same workload
+        # ---- CPU baseline: the oracle (kind "port": our CPU restatement; the reference's MXNet /
+        # Keras path cannot be installed) on a bounded sample of the same workload, four legs
+        from oracle import siamese_head as OH
         params = W.synthetic_ir_params(units, seed=1)
         cores = torch.get_num_threads()
         xs = x[:8].float().cpu().numpy()  # bounded sample of the same pixels
         t1 = time.perf_counter()
-        ir_resnet.embed(params, xs, batch=8)
+        ref8 = ir_resnet.embed(params, xs, batch=8)
         one = time.perf_counter() - t1
-        reps = max(1, min(8, int(15.0 / max(one, 1e-3))))
+        reps = max(1, min(8, int(10.0 / max(one, 1e-3))))
         t1 = time.perf_counter()
         for _ in range(reps):
             ir_resnet.embed(params, xs, batch=8)
         cpu_dt = time.perf_counter() - t1
+        # (ii) the reference's own shape: one image per call, normalised per image (FaceModel.get_feature,
+        # reference code/face_model.py:86-93, looped by ArcFace.process, code/siamese.py:232-234)
+        n_one = 8
+        t1 = time.perf_counter()
+        for i in range(n_one):
+            ir_resnet.embed(params, xs[i:i + 1], batch=1)
+        one_dt = time.perf_counter() - t1
+        # (iii) head fine-tune step, batch 16 (Keras train_on_batch semantics, NumPy f32), median of 200
+        oh = OH.HeadModel(512, lr=0.1, seed=0)
+        rng = np.random.RandomState(0)
+        Lh, Rh = rng.randn(16, 512).astype(np.float32), rng.randn(16, 512).astype(np.float32)
+        yh = np.zeros((16, 2), np.float32)
+        yh[np.arange(16), rng.randint(0, 2, 16)] = 1
+        ts = []
+        for _ in range(200):
+            t1 = time.perf_counter()
+            oh.train_on_batch([Lh, Rh], yh)
+            ts.append(time.perf_counter() - t1)
+        # (iv) pair scoring: 2^18 pairs gathered from a 100k x 512 matrix (the GPU leg scores 2^20)
+        Ec = rng.randn(100000, 512).astype(np.float32)
+        lc, rc_ = rng.randint(0, 100000, 1 << 18), rng.randint(0, 100000, 1 << 18)
+        t1 = time.perf_counter()
+        for s0 in range(0, 1 << 18, 1 << 14):
+            oh.predict([Ec[lc[s0:s0 + (1 << 14)]], Ec[rc_[s0:s0 + (1 << 14)]]])
+        ps_dt = time.perf_counter() - t1
         line["cpu_baseline"] = {"value": reps * 8 / cpu_dt, "unit": "embeddings/s", "cores": cores, "kind": "port",
                                 "sample": "%d x batch-8 forwards of the same %s network (torch-CPU f32 oracle)"
-                                          % (reps, args.model)}
+                                          % (reps, args.model),
+                                "reference_shaped": {"value": n_one / one_dt, "unit": "embeddings/s",
+                                                     "sample": "%d batch-1 forwards, each L2-normalised on its own: the "
+                                                               "reference's get_feature loop" % n_one},
+                                "finetune_step_ms_cpu": 1e3 * float(np.median(ts)),
+                                "pair_scores_per_s_cpu": (1 << 18) / ps_dt}
+        # parity of the timed output against the oracle on the same 8 images (north_star: 1e-3 cosine)
+        got8 = out[:8].cpu().numpy().astype(np.float64)
+        parity["one_minus_cos_vs_cpu_oracle_max"] = float((1.0 - (got8 * ref8).sum(1)).max())
+        parity["oracle_rows"] = 8
+        assert parity["one_minus_cos_vs_cpu_oracle_max"] < 1e-3, parity
 
     if rank == 0:
+        line["parity"] = parity
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -46,7 +46,13 @@ extern "C" {
 #define ALINK_LAYOUT_NHWC_U8  2   /* extension: raw 8-bit pixels, 4x less input traffic              */
 
 const char* alink_last_error(void);
-int  alink_init(int device);                 /* hipSetDevice + function attributes; idempotent */
+/* Prepares `device` (function attributes, hardware-contract probe); idempotent; the caller's current device
+ * is left unchanged.  DEVICE RULE for the whole library: a handle lives on the device that was current
+ * when it was created (one process per GPU: torch.cuda.set_device(LOCAL_RANK) first); every entry point
+ * makes its handle's device current for the duration of the call and restores the caller's; entry points
+ * without a handle run on the device that owns the buffers they are given.  `stream` arguments must be
+ * streams of that same device. */
+int  alink_init(int device);
 int  alink_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -125,11 +131,13 @@ int alink_embed_input_grad(alink_backbone_t* bb, const float* dev_demb, const fl
 /* Diagnostic / unit-test entry: one fused NHWC convolution launch of the implicit-GEMM kernel
  *   out = [prelu_alpha]( conv(in, w) + bias[class] ) [+ resid]
  * dev_w is (Cout, ksz, ksz, Cin) in `dtype` in NATURAL cout order (the call permutes a private
- * copy — synchronous, test use only); dev_bias is (ncls, Cout) f32 with ncls = 9 if border_cls. */
+ * copy — synchronous, test use only); dev_bias is (ncls, Cout) f32 with ncls = 9 if border_cls.
+ * `fine`: where the linear-tile kernel applies (3x3 stride 1 on 7/14/28-wide maps), 1 / 0 force its
+ * 64- / 128-channel workgroup form, < 0 chooses by grid size exactly as alink_embed does. */
 int alink_conv_nhwc(int dtype, const void* dev_in, const void* dev_w, const float* dev_bias,
                     const float* dev_alpha, const void* dev_resid, void* dev_out,
                     int N, int H, int W, int Cin, int Cout, int ksz, int stride, int pad,
-                    int border_cls, void* stream);
+                    int border_cls, int fine, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * VGGFace2 ResNet-50 feature extractor: siamese.RESNET50 (code/siamese.py:203-216) =
@@ -216,6 +224,13 @@ int alink_head_forward(alink_head_t* h, const float* dev_L, const float* dev_R,
 int alink_committee_forward(alink_head_t* const* heads, int n_heads, const float* dev_L,
                             const float* dev_R, const int32_t* dev_li, const int32_t* dev_ri,
                             int64_t P, float* dev_probs, void* dev_scratch, void* stream);
+
+/* The same mean when every member scores the pairs on ITS OWN feature matrices (a committee whose members
+ * have different feature extractors: BASELINE configs[2], three backbones): dev_L[m] / dev_R[m] are member m's
+ * embedding matrices, the index lists are shared. */
+int alink_committee_forward_multi(alink_head_t* const* heads, int n_heads, const float* const* dev_L,
+                                  const float* const* dev_R, const int32_t* dev_li, const int32_t* dev_ri,
+                                  int64_t P, float* dev_probs, void* stream);
 
 /* The N x N verification score matrix of utilities/generateMatrixDFW.py:25-36:
  *   scores[r][j] = mean_m softmax(head_m(|E[row0 + r] - E[j]|))[col],  r < nrows, j < n

@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 BN_EPS = 2e-5
+_BN_INPUT_HOOK = None
 
 
 def _t(params, name, dtype):
@@ -24,6 +25,8 @@ def _t(params, name, dtype):
 
 def _bn(x, params, name, dtype, fix_gamma=False, eps=BN_EPS):
     """mx.sym.BatchNorm(use_global_stats / is_train=False): (x - mean) / sqrt(var + eps) * gamma + beta."""
+    if _BN_INPUT_HOOK is not None:
+        _BN_INPUT_HOOK(name, x, params)          # oracle/calibrate.py: set the statistics from this input
     g = _t(params, name + "_gamma", dtype)
     if fix_gamma:
         g = torch.ones_like(g)

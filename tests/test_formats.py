@@ -190,3 +190,33 @@ def test_resolve_model_prefers_mxnet_pair(tmp_path):
     got, cfg = W.resolve_model_config(prefix + ",0", (16, 16))
     assert cfg["bn_eps"] == 2e-5 and tuple(cfg["widths"]) == W.WIDTHS
     assert set(got) == set(params) and all(np.array_equal(got[k], params[k]) for k in params)
+
+
+def test_reader_on_independently_assembled_checkpoint():
+    """tests/golden/mxnet_tiny-*: a checkpoint assembled byte by byte from the published MXNet layout by
+    tests/golden/make_mxnet_fixture.py, which shares no code or constants with mxnet_format.py — so this is a
+    check of the READER (the round-trip tests above only compare the module with itself).  The file carries
+    what a real export does and the module's own writer does not: arrays saved from gpu(3), a float16 and a
+    float64 tensor, a classification head (fc7 + SoftmaxOutput) after the fc1 cut, `workspace` attributes."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    prefix = os.path.join(gold, "mxnet_tiny")
+    raw = open(prefix + "-0000.params", "rb").read()
+    assert raw[:8] == (0x112).to_bytes(8, "little") and raw[24:28] == bytes.fromhex("c9fa93f9")
+    sym, arg, aux = MX.load_checkpoint(prefix, 0)
+    with np.load(os.path.join(gold, "mxnet_tiny_expected.npz")) as exp:
+        assert set(exp.files) == set(arg) | set(aux) and not set(arg) & set(aux)
+        for k in exp.files:
+            got = aux[k] if k in aux else arg[k]
+            assert (k in aux) == (k.endswith("_moving_mean") or k.endswith("_moving_var"))
+            assert got.dtype == exp[k].dtype and got.shape == exp[k].shape and np.array_equal(got, exp[k])
+        assert arg["stage3_unit1_conv1_weight"].dtype == np.float16 and arg["fc1_beta"].dtype == np.float64
+    cfg = MX.ir_config_from_symbol(sym, "fc1_output")              # reference code/face_model.py:35-36
+    assert cfg == {"units": (1, 2, 1, 1), "widths": (8, 8, 16, 16, 24), "emb": 12, "bn_eps": 2e-5, "fix_gamma": ["fc1"]}
+    params, rcfg = W.resolve_model_config(prefix + ",0", (16, 16))
+    want = W.tensor_shapes(cfg["units"], cfg["widths"], (16, 16), cfg["emb"])
+    assert set(want) <= set(params) and set(params) - set(want) == {"fc7_weight"}
+    assert all(params[k].shape == tuple(s) and params[k].dtype == np.float32 for k, s in want.items())
+    # and the forward pass on it runs through the oracle (the graph the file describes is a working network)
+    from oracle import ir_resnet
+    e = ir_resnet.embed(params, np.random.default_rng(0).integers(0, 256, (2, 16, 16, 3)).astype(np.float32))
+    assert e.shape == (2, 12) and np.allclose(np.linalg.norm(e, axis=1), 1, atol=1e-6)

@@ -187,3 +187,85 @@ def test_small_batch_split_k_matches_fused(gpu):
         assert (1.0 - (a * b).sum(1)).max() < 5e-4, n
         assert (1.0 - (a[:2] * ref[:min(n, 2)]).sum(1)).max() < 1e-3, n
     assert not np.array_equal(split.embed(x[:1]), fused.embed(x[:1]))   # the split path did run
+
+
+def _embed_in_launches(bb, xd, streams):
+    """What bench.py times: the device-resident batch cut into bb.max_batch-image launches on `streams` streams."""
+    bb.n_streams = streams
+    return bb.embed_device(xd).cpu().numpy()
+
+
+def test_benchmarked_form_unit_net_at_112(gpu):
+    """The kernel forms bench.py times, end to end, on a network small enough for the CPU oracle: units (1,1,1,1)
+    at 112x112 runs the linear-tile kernel at every width it serves (56 / 28 / 14 / 7: ~84 % of the benchmark's
+    kernel time) — the 32x32 test nets have 16/8/4/2-wide maps and never reach it.  Batches 1 and 5 take the
+    64-channel `fine` form, 292 the 128-channel form (backbone.hip: nwg128 <= 384 ? fine), 600 = 292 + 292 + 16
+    on 4 streams mixes both in one call.  Checked: against the unfused f32 oracle on a subsample, and BIT-equal
+    between an image embedded alone and inside each batch — i.e. across the fine <-> coarse switch."""
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import ir_resnet
+    size = (112, 112)
+    params = W.synthetic_ir_params((1, 1, 1, 1), size=size, seed=4)
+    x = _pixels(600, size, seed=11)
+    xd = torch.from_numpy(x).cuda()
+    bb = IRBackbone(params, image_size=size, max_batch=292, streams=4)
+    e600 = _embed_in_launches(bb, xd, 4)
+    assert e600.shape == (600, 512) and np.isfinite(e600).all()
+    probe = [0, 1, 4, 137, 291, 292, 583, 584, 599]                  # both sides of every launch boundary
+    ref = ir_resnet.embed(params, x[probe])
+    d = _cos_dist(e600[probe], ref)
+    assert d.max() < COS_TOL, d
+    singles = np.concatenate([bb.embed_device(xd[i:i + 1]).cpu().numpy() for i in probe])    # batch 1: fine form
+    assert np.array_equal(singles, e600[probe])
+    e5 = bb.embed_device(xd[:5]).cpu().numpy()                                                 # batch 5: fine form
+    assert np.array_equal(e5, e600[:5])
+    e292 = _embed_in_launches(bb, xd[:292], 1)                                                 # one 128-channel launch
+    assert np.array_equal(e292, e600[:292])
+    e600_1 = _embed_in_launches(bb, xd, 1)                                                     # same launches, one stream
+    assert np.array_equal(e600_1, e600)
+    # the threshold itself: 190 images is the last batch on the fine form at 14 wide, 196 the first on the coarse one
+    for n in (190, 196, 256):
+        assert np.array_equal(bb.embed_device(xd[:n]).cpu().numpy(), e600[:n]), n
+
+
+def test_benchmarked_form_r50_at_112_292_images(gpu):
+    """BASELINE configs[1]'s network at the launch batch bench.py uses: IR-50, 292 images, 128-channel linear
+    tiles.  8 of the 292 against the f32 oracle; every one of those 8 bit-equal to its batch-1 (fine-form) embedding."""
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import ir_resnet
+    params = W.synthetic_ir_params(W.R50_UNITS, seed=1)
+    x = _pixels(292, (112, 112), seed=5)
+    xd = torch.from_numpy(x).cuda()
+    bb = IRBackbone(params, max_batch=292)
+    e = bb.embed_device(xd).cpu().numpy()
+    probe = [0, 1, 57, 145, 146, 200, 290, 291]
+    ref = ir_resnet.embed(params, x[probe], batch=8)
+    d = _cos_dist(e[probe], ref)
+    assert d.max() < COS_TOL, d
+    singles = np.concatenate([bb.embed_device(xd[i:i + 1]).cpu().numpy() for i in probe])
+    assert np.array_equal(singles, e[probe])
+    # and 256 images (configs[1] as worded: one 256-image batch) equal the same rows
+    assert np.array_equal(bb.embed_device(xd[:256]).cpu().numpy(), e[:256])
+
+
+@pytest.mark.parametrize("arch,dtype", [("r100", "bf16"), ("r100", "f16"), ("r50", "bf16")])
+def test_parity_on_calibrated_weights(gpu, capsys, arch, dtype):
+    """Parity where a real checkpoint lives: weights whose BatchNorm statistics match their activations
+    (oracle/calibrate.py: activations O(10) instead of the ~1e8 the uncalibrated SURVEY §8d weights grow to).  There
+    float16 storage works at full depth, and the bf16 margin against the 1e-3 bar is what a trained model would see
+    rather than the worst case of test_headline_depth_parity_r100_and_f16_range."""
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import calibrate, ir_resnet
+    params = calibrate.calibrated_ir_params(W.ARCH_UNITS[arch], seed=1, n_cal=16)
+    x = calibrate.calibration_pixels(4, (112, 112), seed=77)          # images of the calibrated distribution
+    x = np.concatenate([x, _pixels(4, (112, 112), seed=0)])           # and uniform-noise images off it
+    ref = ir_resnet.embed(params, x, batch=8)
+    got = IRBackbone(params, dtype=dtype, max_batch=8).embed(x)
+    d = _cos_dist(got, ref)
+    with capsys.disabled():
+        print("\n[calibrated %s %s] 1-cos max %.2e (calibration-like images %.2e, uniform-noise images %.2e), "
+              "max |activation| %.0f" % (arch, dtype, d.max(), d[:4].max(), d[4:].max(), calibrate.activation_range(params, x[:2])))
+    assert d.max() < (2e-4 if dtype == "f16" else COS_TOL), d

@@ -83,41 +83,51 @@ def test_conv_matches_cpu(gpu, dt, dma, linear):
             ad = alpha.cuda() if use_alpha else None
             rd = resid.cuda() if use_resid else None
             out = torch.full((N, Ho, Wo, Co), float("nan"), dtype=tdt, device="cuda")
-            rc = lib.alink_conv_nhwc(code, gpu.ptr(xd), gpu.ptr(wd), gpu.ptr(bd), gpu.ptr(ad), gpu.ptr(rd),
-                                     gpu.ptr(out), N, H, W, Ci, Co, k, s, p, border, None)
-            gpu.check(rc, "alink_conv_nhwc")
-            got = out.float().cpu()
-            assert torch.isfinite(got).all(), (N, H, W, Ci, Co, k, s)
-            # output rounding of T (2^-9 bf16 / 2^-12 f16 relative) + accumulation-order noise
-            rel = 2.0 ** -8 if dt == "bf16" else 2.0 ** -10
-            err = (got - ref).abs()
-            tol = rel * ref.abs() + 2e-3
-            assert (err <= tol).all(), "case %s dt=%s dma=%d: max err %.4g" % (
-                (N, H, W, Ci, Co, k, s, p, border), dt, dma, float((err - tol).max()))
+            is_linear_case = (N, H, W, Ci, Co, k, s, p, border, use_alpha, use_resid) in LINEAR_CASES
+            for fine in ((0, 1) if is_linear_case else (-1,)):      # both forms of the linear-tile kernel
+                out.fill_(float("nan"))
+                rc = lib.alink_conv_nhwc(code, gpu.ptr(xd), gpu.ptr(wd), gpu.ptr(bd), gpu.ptr(ad), gpu.ptr(rd),
+                                         gpu.ptr(out), N, H, W, Ci, Co, k, s, p, border, fine, None)
+                gpu.check(rc, "alink_conv_nhwc")
+                _check_conv(out, ref, dt, (N, H, W, Ci, Co, k, s, p, border, fine), dma)
     finally:
         lib.alink_debug_set_dma(1)
         lib.alink_debug_set_linear(15)          # library default: linear tiles at every width they support
+
+
+def _check_conv(out, ref, dt, what, dma):
+    got = out.float().cpu()
+    assert torch.isfinite(got).all(), what
+    # output rounding of T (2^-9 bf16 / 2^-12 f16 relative) + accumulation-order noise
+    rel = 2.0 ** -8 if dt == "bf16" else 2.0 ** -10
+    err = (got - ref).abs()
+    tol = rel * ref.abs() + 2e-3
+    assert (err <= tol).all(), "case %s dt=%s dma=%d: max err %.4g" % (what, dt, dma, float((err - tol).max()))
 
 
 def test_conv_rejects_bad_shapes(gpu):
     lib = gpu.load()
     x = torch.zeros(1, 4, 4, 32, dtype=torch.bfloat16, device="cuda")
     rc = lib.alink_conv_nhwc(0, gpu.ptr(x), gpu.ptr(x), gpu.ptr(x), None, None, gpu.ptr(x),
-                             1, 4, 4, 32, 64, 3, 1, 1, 0, None)
+                             1, 4, 4, 32, 64, 3, 1, 1, 0, -1, None)
     assert rc == -1 and b"multiples of 64" in lib.alink_last_error()
 
 
 def test_lds_out_of_range_read_is_zero(gpu):
-    """conv3x3_linear.hip sends border lanes to an address beyond the workgroup's LDS allocation and
-    relies on the DS read returning zero there (no fault): check that hardware contract directly."""
+    """conv3x3_linear.hip adds border bits 18..27 (one or two at a time) to a lane's operand address, which then
+    lies beyond the workgroup's LDS allocation, and relies on the DS read returning zero there (no fault, no
+    aliasing of in-range data).  The probe reads every single bit, every pair of bits and wider sums, each with
+    immediate offset 0 and 12288 (the largest tile immediate): check that hardware contract directly, and that
+    the library recorded it for this device (the linear-tile kernel is only selected where it holds)."""
     import ctypes as C
     lib = gpu.load()
-    out = torch.full((260,), 7.0, device="cuda")
+    out = torch.full((516,), 7.0, device="cuda")
     assert lib.alink_debug_lds_oob_probe(C.c_void_p(out.data_ptr()), None) == 0
     torch.cuda.synchronize()
     o = out.cpu()
-    assert (o[:256] == 0).all()                          # 64 lanes x 16 B read 256 KB past a 1 KB allocation
-    assert o[256:260].tolist() == [1.0, 2.0, 3.0, 4.0]   # the in-range read of the same instruction pair
+    assert (o[:512] == 0).all()                          # 64 address forms x 2 immediates x 16 B
+    assert o[512:516].tolist() == [1.0, 2.0, 3.0, 4.0]   # the in-range read of the same instruction group
+    assert lib.alink_debug_linear_contract_ok() == 1
 
 
 def test_linear_kernel_fuzz(gpu):
@@ -143,8 +153,16 @@ def test_linear_kernel_fuzz(gpu):
         xd, wd, bd = x.cuda(), w.cuda(), bias.cuda()
         ad = alpha.cuda() if use_alpha else None
         rd = resid.cuda() if use_resid else None
-        gpu.check(lib.alink_conv_nhwc(gpu.DT_BF16, gpu.ptr(xd), gpu.ptr(wd), gpu.ptr(bd), gpu.ptr(ad), gpu.ptr(rd),
-                                      gpu.ptr(out), N, W, W, Ci, Co, 3, 1, 1, border, None), "alink_conv_nhwc")
+        # both workgroup forms of the kernel (128- and 64-channel; the 56-wide variant has one form): each against
+        # the CPU reference, and against each other BIT FOR BIT — alink_embed switches between them by batch size
+        # (ConvParams::fine) and promises embeddings that do not depend on the batch an image arrives in
+        forms = []
+        for fine in (0, 1):
+            out.fill_(float("nan"))
+            gpu.check(lib.alink_conv_nhwc(gpu.DT_BF16, gpu.ptr(xd), gpu.ptr(wd), gpu.ptr(bd), gpu.ptr(ad), gpu.ptr(rd),
+                                          gpu.ptr(out), N, W, W, Ci, Co, 3, 1, 1, border, fine, None), "alink_conv_nhwc")
+            forms.append(out.clone())
+        assert torch.equal(forms[0].view(torch.int16), forms[1].view(torch.int16)), (case, N, W, Ci, Co)
         got = out.float().cpu()
         assert torch.isfinite(got).all(), (case, N, W, Ci, Co)
         err = (got - ref).abs()
