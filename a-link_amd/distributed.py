@@ -5,9 +5,12 @@ this is new work shaped by SURVEY.md §8e:
   * pool inference shards by image with NO data-path collective (`shard_range`, `embed_pool_sharded`);
   * pool top-k: per-rank exact top-k, ONE all-gather of k (score, global index) candidates per rank,
     identical deterministic merge on every rank (`merge_topk`);
-  * fine-tune step: each rank runs forward/backward on its slice of the batch with the GLOBAL
-    normaliser, the flat gradient buffer is all-reduced (sum), every rank applies the same Adadelta
-    update (`dp_train_on_batch`).
+  * fine-tune step (`dp_train_on_batch`): REPLICATED below DP_SHARD_MIN_ROWS rows (every rank runs the whole
+    batch: at the reference's batch 16 the step is 0.04 ms and any collective costs more than it saves); above,
+    each rank runs forward/backward on its slice of the batch with the GLOBAL normaliser, the flat gradient
+    buffer is all-reduced (sum), every rank applies the same Adadelta update;
+  * `committee_pool_topk`: the whole config-3 shape on one rank (shard -> committee of backbones + heads ->
+    uncertainty -> local top-k -> merge).
 All functions work on CPU tensors too (that is how the world-size-2 gloo tests exercise them).
 """
 import numpy as np
@@ -26,27 +29,44 @@ def _dist():
 
 
 def merge_topk(local_vals, local_global_idx, k, largest=True, group=None):
-    """local_vals/local_global_idx: this rank's candidates (any length <= k, already its local top-k).
-    Returns (vals, idx) of the global top-k, identical on every rank; ties -> lower global index."""
+    """local_vals / local_global_idx: this rank's candidates — its local top-k, sorted (ties -> lower index), any
+    length <= k.  Returns (vals, idx int64) of the global top-k, identical on every rank; ties -> lower global index.
+
+    ONE all-gather of k (score bits, index) int32 pairs per rank (k = 1024: 8 KB per rank), then the same exact
+    selection on every rank: on the GPU that is alink_topk over the world * k gathered scores.  alink_topk breaks ties
+    towards the lower POSITION; ranks own contiguous, ascending index ranges (shard_range) and each rank's list is
+    already tie-ordered, so position order among equal scores is global-index order.  Global indices must fit int32
+    (alink_topk's own limit is P < 2^31).  CPU tensors (the gloo tests) take the same exchange and a NumPy merge."""
     import torch
     dist = _dist()
     world = dist.get_world_size(group)
     dev = local_vals.device
-    pad_v = torch.full((k,), float("-inf") if largest else float("inf"), dtype=torch.float32, device=dev)
-    pad_i = torch.full((k,), np.iinfo(np.int64).max, dtype=torch.int64, device=dev)
     n = min(k, local_vals.numel())
-    pad_v[:n] = local_vals[:n].to(torch.float32)
-    pad_i[:n] = local_global_idx[:n].to(torch.int64)
-    gv = [torch.empty_like(pad_v) for _ in range(world)]
-    gi = [torch.empty_like(pad_i) for _ in range(world)]
-    dist.all_gather(gv, pad_v, group=group)
-    dist.all_gather(gi, pad_i, group=group)
-    v = torch.cat(gv).cpu().numpy()
-    i = torch.cat(gi).cpu().numpy()
-    keep = i != np.iinfo(np.int64).max
+    pad = float("-inf") if largest else float("inf")
+    mine = torch.empty((k, 2), dtype=torch.int32, device=dev)
+    mine[:, 0] = torch.full((k,), pad, dtype=torch.float32, device=dev).view(torch.int32)
+    mine[:, 1] = -1
+    if n:
+        mine[:n, 0] = local_vals[:n].to(torch.float32).contiguous().view(torch.int32)
+        mine[:n, 1] = local_global_idx[:n].to(torch.int32)
+    every = torch.empty((world * k, 2), dtype=torch.int32, device=dev)
+    if dev.type == "cuda":
+        dist.all_gather_into_tensor(every, mine, group=group)
+        from . import uncertainty as _unc
+        vals_all = every[:, 0].contiguous().view(torch.float32)
+        pos, v = _unc.topk_device(vals_all, min(k, world * k), largest=largest)
+        idx = every[:, 1][pos.long()]
+        keep = idx >= 0                                       # fewer than k real candidates in the whole job
+        return v[keep], idx[keep].to(torch.int64)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    every = torch.cat(parts).numpy()
+    v = every[:, 0].copy().view(np.float32)
+    i = every[:, 1].astype(np.int64)
+    keep = i >= 0
     v, i = v[keep], i[keep]
     order = np.lexsort((i, -v if largest else v))[:k]       # primary: score, secondary: index
-    return torch.from_numpy(v[order]).to(dev), torch.from_numpy(i[order]).to(dev)
+    return torch.from_numpy(v[order]), torch.from_numpy(i[order])
 
 
 def allreduce_sum_(t, group=None):
@@ -58,9 +78,28 @@ def dp_batch_slices(n, world):
     return [shard_range(n, r, world) for r in range(world)]
 
 
-def dp_train_on_batch(head, x, y, class_weight=None, sample_weight=None, group=None):
-    """Data-parallel Keras train_on_batch on a DenseHead: x=[L,R], y one-hot (FULL batch on every rank,
-    each rank touches only its slice).  Equivalent to the single-GPU step up to f32 summation order."""
+# Rows below which the fine-tune step is REPLICATED (every rank runs the whole batch, no communication) instead of
+# sharded: one step of the 295,618-parameter head at batch 16 is three launches, 0.039 ms on one MI355X
+# (DESIGN.md §4); sharding it adds a 1.18 MB all-reduce (ring over xGMI: >= 7 hops of latency, tens of
+# microseconds) plus a host read-back, to save a fraction of 0.039 ms.  The kernels are deterministic, so replicas
+# fed the same batch stay bit-identical.  Sharding starts to pay when a rank's slice is itself thousands of rows
+# (the generic chain at 4096 rows is ~6 GFLOP of f32 MFMA work, ~60 us): the reference never gets there
+# (batch 16, code/ALINK_arc.py:245), callers with large batches can force it with mode="sharded".
+DP_SHARD_MIN_ROWS = 2048
+
+
+def dp_train_on_batch(head, x, y, class_weight=None, sample_weight=None, group=None, mode="auto"):
+    """Keras train_on_batch on a DenseHead in a one-process-per-GPU job: x=[L,R], y one-hot — the FULL batch on
+    every rank.  mode "replicated": every rank runs the whole step (bit-identical weights, zero communication);
+    "sharded": each rank runs its slice with the GLOBAL normaliser, ONE all-reduce carries gradients + metrics,
+    every rank applies the same Adadelta update (equal to the single-GPU step up to f32 summation order);
+    "auto": replicated below DP_SHARD_MIN_ROWS rows."""
+    if mode == "auto":
+        mode = "replicated" if len(y) < DP_SHARD_MIN_ROWS else "sharded"
+    if mode == "replicated":
+        return head.train_on_batch(x, y, class_weight=class_weight, sample_weight=sample_weight)
+    if mode != "sharded":
+        raise ValueError("mode must be auto, replicated or sharded")
     import torch
     from . import _abi
     dist = _dist()
@@ -75,19 +114,47 @@ def dp_train_on_batch(head, x, y, class_weight=None, sample_weight=None, group=N
     gm = head.grads_tensor(with_metrics=True)
     m = gm[-4:]
     m.zero_()
+    st = _abi.current_stream(head.device)
     if hi > lo:
         take = lambda a: a[lo:hi] if hasattr(a, "shape") else np.asarray(a)[lo:hi]
         L, R = head._dev(take(x[0])), head._dev(take(x[1]))
         yd, swd = head._dev(take(y)), (None if sw is None else head._dev(w_all[lo:hi]))
         _abi.check(head.lib.alink_head_train_step(head.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd),
-                                                  hi - lo, 1.0 / denom, 0, _abi.ptr(m), _abi.current_stream()))
+                                                  hi - lo, 1.0 / denom, 0, _abi.ptr(m), st))
         m[1] *= (hi - lo)                                    # accuracy: local mean -> local sum
     else:
         gm.zero_()
     dist.all_reduce(gm, group=group)
-    _abi.check(head.lib.alink_head_apply_update(head.h, _abi.current_stream()))
+    _abi.check(head.lib.alink_head_apply_update(head.h, st))
     out = m[:2].cpu().numpy()
     return [float(out[0]), float(out[1] / n)]
+
+
+def committee_pool_topk(backbones, heads, pool_shard, gallery, k, shard_offset, kind="entropy", group=None):
+    """BASELINE configs[2] on one rank of a one-process-per-GPU job: this rank's pool shard
+    (n, H, W, 3) and the replicated gallery are embedded by every committee member's backbone, each member's head
+    scores the n * g (pool, gallery) pairs on its own embeddings, Bagging mean (reference code/committee.py:13-20),
+    uncertainty measure `kind` (code/uncertainty.py), local exact top-k, ONE candidate exchange (merge_topk).
+    Returns (scores, global pair index) of the job-wide top-k, identical on every rank; pair index =
+    (shard_offset + i) * g + j for pool image i of this shard and gallery image j."""
+    import torch
+    from . import head as _head
+    from . import uncertainty as _unc
+    dist = _dist()
+    n, g = len(pool_shard), len(gallery)
+    Ep = [bb.embed_device(pool_shard) if hasattr(pool_shard, "detach") else torch.as_tensor(bb.embed(pool_shard)) for bb in backbones]
+    Eg = [bb.embed_device(gallery) if hasattr(gallery, "detach") else torch.as_tensor(bb.embed(gallery)) for bb in backbones]
+    dev = heads[0].device
+    li = torch.arange(n, dtype=torch.int32, device="cuda:%d" % dev).repeat_interleave(g)
+    ri = torch.arange(g, dtype=torch.int32, device="cuda:%d" % dev).repeat(n)
+    probs = _head.committee_predict_device(heads, Ep, Eg, li, ri)
+    scores = _unc.score_device(probs, kind)
+    kk = min(k, scores.numel())
+    idx, vals = _unc.topk_device(scores, kk, largest=True)
+    gidx = idx.to(torch.int64) + int(shard_offset) * g
+    if dist.is_available() and dist.is_initialized():
+        return merge_topk(vals, gidx, k, largest=True, group=group)
+    return vals, gidx
 
 
 def embed_pool_sharded(feature_model, X, group=None, gather=True):

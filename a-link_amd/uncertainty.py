@@ -114,7 +114,7 @@ def score_device(probs, kind, b=None, col=0):
     P, Cn = probs.shape
     out = torch.empty(P, dtype=torch.float32, device=probs.device)
     _abi.check(lib.alink_score(code, _abi.ptr(probs), _abi.ptr(b.contiguous() if b is not None else None), col, P, Cn,
-                               _abi.ptr(out), _abi.current_stream()), "alink_score")
+                               _abi.ptr(out), _abi.current_stream(probs.device)), "alink_score")
     return out
 
 
@@ -132,5 +132,5 @@ def topk_device(scores, k, largest=True):
     idx = torch.empty(int(k), dtype=torch.int32, device=scores.device)
     vals = torch.empty(int(k), dtype=torch.float32, device=scores.device)
     _abi.check(lib.alink_topk(_abi.ptr(scores), P, int(k), 1 if largest else 0, _abi.ptr(idx), _abi.ptr(vals),
-                              C.c_void_p(scratch.data_ptr() + off), _abi.current_stream()), "alink_topk")
+                              C.c_void_p(scratch.data_ptr() + off), _abi.current_stream(scores.device)), "alink_topk")
     return idx, vals

@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--input", default="f32", choices=["f32", "u8"], help="pixel type resident in HBM")
     ap.add_argument("--streams", type=int, default=4, help="streams the chunks of one step are spread over")
     ap.add_argument("--linear", type=int, default=-1, help="A/B: widths on linear pixel tiles (bit0 56, bit1 28, bit2 14, bit3 7)")
+    ap.add_argument("--config3", action="store_true", help="also time the config-3 leg (3 x IR-50 committee over a pool shard) "
+                    "at N = 1; under torch.distributed.run it always runs")
+    ap.add_argument("--config3-shard", type=int, default=2336, help="pool images per GPU in the config-3 leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile / fine-tune timing")
     args = ap.parse_args()
@@ -140,30 +143,68 @@ def main():
     }
 
     if dist is not None and not args.no_extras:
-        # ---- data-parallel fine-tune step: the 16-pair batch split over the ranks, ONE RCCL
-        # all-reduce of the flat gradient buffer (+ metrics), identical Adadelta update on every rank
+        # ---- fine-tune step in a one-process-per-GPU job, both forms (a-link_amd/distributed.py):
+        # sharded = the 16-pair batch split over the ranks, ONE RCCL all-reduce of the flat gradient buffer (+ metrics),
+        # identical Adadelta update on every rank; replicated = every rank runs the whole batch, no collective
+        # (what dp_train_on_batch picks by itself below DP_SHARD_MIN_ROWS rows)
         from a_link_amd import distributed as D
         from a_link_amd.head import DenseHead
-        hdp = DenseHead(512, lr=0.1, seed=0, device=local_rank)
         rng = np.random.RandomState(0)
         Ld = torch.from_numpy(rng.randn(16, 512).astype(np.float32)).cuda()
         Rd = torch.from_numpy(rng.randn(16, 512).astype(np.float32)).cuda()
         yh = np.zeros((16, 2), np.float32)
         yh[np.arange(16), rng.randint(0, 2, 16)] = 1
         ydd = torch.from_numpy(yh).cuda()
-        for _ in range(20):
-            D.dp_train_on_batch(hdp, [Ld, Rd], ydd)
+        for mode, key in (("sharded", "finetune_step_dp_ms"), ("replicated", "finetune_step_replicated_ms")):
+            hdp = DenseHead(512, lr=0.1, seed=0, device=local_rank)
+            for _ in range(20):
+                D.dp_train_on_batch(hdp, [Ld, Rd], ydd, mode=mode)
+            torch.cuda.synchronize()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(100):
+                D.dp_train_on_batch(hdp, [Ld, Rd], ydd, mode=mode)
+            torch.cuda.synchronize()
+            barrier()
+            tdp = torch.tensor([(time.perf_counter() - t1) / 100], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tdp, op=dist.ReduceOp.MAX)
+            line[key] = 1e3 * float(tdp.item())
+            del hdp
+        line["finetune_step_dp_policy"] = "replicated below %d rows (a-link_amd/distributed.py)" % D.DP_SHARD_MIN_ROWS
+
+    if (dist is not None or args.config3) and not args.no_extras:
+        # ---- BASELINE configs[2] shape, this rank's share: a committee of THREE IR-50 backbones + heads over a pool
+        # shard against a 16-image gallery, entropy, local top-1024, one candidate exchange (device-side merge)
+        from a_link_amd import distributed as D
+        from a_link_amd.head import DenseHead
+        n_shard = args.config3_shard
+        bbs = [IRBackbone(W.synthetic_ir_params(W.R50_UNITS, seed=s_), dtype=args.dtype, device=local_rank, max_batch=args.chunk,
+                          streams=args.streams) for s_ in (1, 2, 3)]
+        hds = [DenseHead(512, lr=0.1, seed=10 + i, device=local_rank) for i in range(3)]
+        gsh = torch.Generator(device="cpu").manual_seed(1000 + rank)
+        shard = torch.randint(0, 256, (n_shard, 112, 112, 3), generator=gsh, dtype=torch.uint8).cuda()
+        gal = torch.randint(0, 256, (16, 112, 112, 3), generator=torch.Generator(device="cpu").manual_seed(100), dtype=torch.uint8).cuda()
+        lo_ = rank * n_shard
+        for _ in range(2):
+            tv, ti = D.committee_pool_topk(bbs, hds, shard, gal, 1024, lo_)
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
-        for _ in range(100):
-            D.dp_train_on_batch(hdp, [Ld, Rd], ydd)
+        reps3 = 5
+        for _ in range(reps3):
+            tv, ti = D.committee_pool_topk(bbs, hds, shard, gal, 1024, lo_)
         torch.cuda.synchronize()
         barrier()
-        tdp = torch.tensor([(time.perf_counter() - t1) / 100], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tdp, op=dist.ReduceOp.MAX)
-        line["finetune_step_dp_ms"] = 1e3 * float(tdp.item())
-        del hdp
+        t3 = torch.tensor([(time.perf_counter() - t1) / reps3], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+        line["config3"] = {"workload": "committee of 3 IR-50 + 3 heads, %d pool images per GPU x 16 gallery images, entropy, "
+                                       "top-1024, candidate all-gather + device merge" % n_shard,
+                           "ms_per_pass": 1e3 * float(t3.item()),
+                           "pool_images_per_s": world * n_shard / float(t3.item()),
+                           "backbone_forwards_per_s": 3 * world * (n_shard + 16) / float(t3.item()),
+                           "selected": int(ti.numel())}
+        del bbs, hds, shard
 
     if rank == 0 and not args.no_extras:
         # ---- roofline of the dominant kernel (conv_igemm_kernel): HIP events around every launch

@@ -168,11 +168,20 @@ def test_dp_train_step_single_rank_group(gpu):
         L, R = _data(16, 512, 42)
         y = O.to_categorical(np.random.RandomState(3).randint(0, 2, 16))
         cw = {0: 0.25, 1: 0.75}
-        mg = D.dp_train_on_batch(g, [L, R], y, class_weight=cw)
+        mg = D.dp_train_on_batch(g, [L, R], y, class_weight=cw, mode="sharded")     # the all-reduce path
         mo = o.train_on_batch([L, R], y, class_weight=cw)
         np.testing.assert_allclose(mg, mo, rtol=2e-5, atol=1e-6)
         for a, b in zip(g.get_weights(), o.get_weights()):
             np.testing.assert_allclose(a, b, atol=3e-6)
+        # "auto" at the reference's batch 16 is the replicated step: the plain train_on_batch, no collective
+        assert len(y) < D.DP_SHARD_MIN_ROWS
+        g2, o2 = _pair(lr=0.1)
+        g3, _ = _pair(lr=0.1)
+        m2 = D.dp_train_on_batch(g2, [L, R], y, class_weight=cw)
+        m3 = g3.train_on_batch([L, R], y, class_weight=cw)
+        assert m2 == m3
+        for a, b in zip(g2.get_weights(), g3.get_weights()):
+            assert np.array_equal(a, b)                       # replicas stay bit-identical
         gt = g.grads_tensor()
         assert gt.is_cuda and gt.numel() == 295618
     finally:
