@@ -145,8 +145,8 @@ def committee_pool_topk(backbones, heads, pool_shard, gallery, k, shard_offset, 
     Ep = [bb.embed_device(pool_shard) if hasattr(pool_shard, "detach") else torch.as_tensor(bb.embed(pool_shard)) for bb in backbones]
     Eg = [bb.embed_device(gallery) if hasattr(gallery, "detach") else torch.as_tensor(bb.embed(gallery)) for bb in backbones]
     dev = heads[0].device
-    li = torch.arange(n, dtype=torch.int32, device="cuda:%d" % dev).repeat_interleave(g)
-    ri = torch.arange(g, dtype=torch.int32, device="cuda:%d" % dev).repeat(n)
+    li = torch.arange(n, dtype=torch.int32, device=dev).repeat_interleave(g)
+    ri = torch.arange(g, dtype=torch.int32, device=dev).repeat(n)
     probs = _head.committee_predict_device(heads, Ep, Eg, li, ri)
     scores = _unc.score_device(probs, kind)
     kk = min(k, scores.numel())
