@@ -111,6 +111,9 @@ PROTOTYPES = {
     "alink_noise_perlin": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i), _vp, _vp]),
     "alink_resize_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "alink_perturb_images": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "alink_arcface_margin_workspace_bytes": (_sz, [_i, _i, _i]),
+    "alink_arcface_margin_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "alink_contrastive_loss": (_i, [_vp, _vp, _vp, _i64, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "alink_score": (_i, [_i, _vp, _vp, _i, _i64, _i, _vp, _vp]),
     "alink_topk_scratch_bytes": (_sz, [_i64, _i]),
     "alink_topk": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),

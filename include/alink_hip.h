@@ -364,6 +364,28 @@ int alink_resize_bilinear(const float* dev_in, float* dev_out, int n, int H, int
 int alink_perturb_images(const float* dev_img, const double* dev_xs, int n, int k, int Hc, int W,
                          int split, float* dev_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * EXTENSIONS — named by BASELINE.json's north_star, ABSENT from the reference: the reference
+ * cuts the ArcFace checkpoint at fc1_output and never builds the margin head (code/face_model.py:35-36,53),
+ * and trains its pair scorer with binary cross-entropy on |l - r| (code/siamese.py:27-35), not with a
+ * contrastive loss.  Provided for callers that fine-tune the backbone's embedding space; checked against torch
+ * autograd (tests/test_gpu_extensions.py), not against the reference.
+ * ---------------------------------------------------------------------------------------------- */
+/* Additive angular margin softmax (ArcFace): loss = mean_i CE(softmax(s * cos(theta_ij + m [j == y_i])), y_i) over
+ * L2-normalised embeddings (N x D) and class centres (C x D); where theta + m would pass pi the target logit is
+ * cos(theta) - m sin(pi - m) (easy_margin: cos(theta) itself for cos(theta) <= 0).  dev_demb (N x D) / dev_dW (C x D)
+ * receive the gradients w.r.t. the RAW (un-normalised) inputs, or are NULL. */
+size_t alink_arcface_margin_workspace_bytes(int N, int D, int C);
+int alink_arcface_margin_loss(const float* dev_emb, const float* dev_W, const int32_t* dev_labels, int N, int D,
+                              int C, float s, float m, int easy_margin, float* dev_loss, float* dev_demb,
+                              float* dev_dW, void* dev_workspace, size_t workspace_bytes, void* stream);
+/* Pairwise-L2 contrastive loss: d_p = sqrt(max(|L_p - R_p|^2, 1e-7)),
+ * loss = mean_p [ y_p d_p^2 + (1 - y_p) max(margin - d_p, 0)^2 ]  (y = 1: same identity).
+ * dev_pair_loss (P) receives the per-pair terms; dev_dL / dev_dR (P x D) the gradients, or both NULL. */
+int alink_contrastive_loss(const float* dev_L, const float* dev_R, const float* dev_y, int64_t P, int D,
+                           float margin, float* dev_loss, float* dev_pair_loss, float* dev_dL, float* dev_dR,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif
