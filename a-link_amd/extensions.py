@@ -15,6 +15,13 @@ import ctypes as C
 from . import _abi
 
 
+def _device_of(x):
+    import torch
+    if isinstance(x, torch.Tensor) and x.is_cuda:
+        return x.device
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 def _f32(t, dev):
     import torch
     return torch.as_tensor(t).to(dev, torch.float32).contiguous()
@@ -24,7 +31,7 @@ def arcface_margin_loss(emb, weight, labels, s=64.0, m=0.5, easy_margin=False, n
     """emb (N, D), weight (C, D) [raw, normalised inside], labels (N,) int.  Returns (loss, d_emb, d_weight) as CUDA
     tensors (gradients None when need_grads is False).  s, m: insightface's defaults."""
     import torch
-    dev = emb.device if hasattr(emb, "device") and emb.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    dev = _device_of(emb)
     lib = _abi.init(dev.index)
     e, w = _f32(emb, dev), _f32(weight, dev)
     y = torch.as_tensor(labels).to(dev, torch.int32).contiguous()
@@ -51,7 +58,7 @@ def contrastive_loss(left, right, y, margin=1.0, need_grads=True):
     """left, right (P, D), y (P,) or (P, 1) in {0, 1} (1 = same identity).  Returns (loss, per-pair terms, d_left,
     d_right) as CUDA tensors."""
     import torch
-    dev = left.device if hasattr(left, "device") and left.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    dev = _device_of(left)
     lib = _abi.init(dev.index)
     l, r = _f32(left, dev), _f32(right, dev)
     yy = _f32(y, dev).reshape(-1)

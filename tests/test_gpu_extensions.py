@@ -42,7 +42,7 @@ def test_arcface_margin_loss_matches_autograd(gpu, n, d, c, s, m, easy):
     tw = torch.tensor(w, dtype=torch.float64, requires_grad=True)
     ref = _arcface_ref(te, tw, torch.tensor(y, dtype=torch.long), s, m, easy)
     ref.backward()
-    assert abs(float(loss) - float(ref)) < 2e-5 * max(1.0, abs(float(ref)))
+    assert abs(float(loss) - ref.item()) < 2e-5 * max(1.0, abs(ref.item()))
     for got, want in ((de, te.grad), (dw, tw.grad)):
         scale = float(want.abs().max())
         assert float((got.cpu().double() - want).abs().max()) < 2e-5 * scale + 1e-9, scale
@@ -71,7 +71,7 @@ def test_contrastive_loss_matches_autograd(gpu, p, d, margin):
     tr = torch.tensor(r, dtype=torch.float64, requires_grad=True)
     ref, per = _contrastive_ref(tl, tr, torch.tensor(y, dtype=torch.float64), margin)
     ref.backward()
-    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, float(ref))
+    assert abs(float(loss) - ref.item()) < 1e-5 * max(1.0, ref.item())
     assert float((pair.cpu().double() - per.detach()).abs().max()) < 1e-5
     for got, want in ((dl, tl.grad), (dr, tr.grad)):
         assert float((got.cpu().double() - want).abs().max()) < 1e-5 * float(want.abs().max()) + 1e-10
