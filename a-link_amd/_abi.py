@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libalink_hip.so")
 
-DT_BF16, DT_F16 = 0, 1
+DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 LAYOUT_NHWC_F32, LAYOUT_NCHW_F32, LAYOUT_NHWC_U8 = 0, 1, 2
 SCORE_UNCERTAINTY, SCORE_MARGIN, SCORE_ENTROPY, SCORE_DISPARITY = 0, 1, 2, 3
 
@@ -75,6 +75,8 @@ PROTOTYPES = {
     "alink_head_set_params": (_i, [_vp, _vp, _sz]),
     "alink_head_get_params": (_i, [_vp, _vp, _sz]),
     "alink_head_reset_optimizer": (_i, [_vp]),
+    "alink_head_set_compute_dtype": (_i, [_vp, _i]),
+    "alink_head_get_compute_dtype": (_i, [_vp]),
     "alink_head_set_lr": (_i, [_vp, _f]),
     "alink_head_get_lr": (_f, [_vp]),
     "alink_head_params_dev": (_vp, [_vp]),

@@ -6,7 +6,7 @@
 // and the calls made on it: predict (code/siamese.py:130-131), fit/train_on_batch/test_on_batch
 // (code/siamese.py:57,103,107) and the committee mean (code/committee.py:13-20).
 //
-// Everything is f32.  The large-P forward runs on the f32-input matrix cores
+// f32 by default (bf16 compute mode: see `qmode` below).  The large-P forward runs on the f32-input matrix cores
 // (v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fmaf chain, so results match a CPU f32 matmul
 // to rounding).  Pairs are gathered by index straight from the embedding matrices (row = 2 KB at
 // D = 512, fully coalesced), so the N^2 score-matrix workload (utilities/generateMatrixDFW.py:25-36)
@@ -40,6 +40,16 @@ struct alink_head {
     float* d_w1p = nullptr;      // W1 packed for the MFMA forward: [D/8][h1][2][4]
     float* d_w2p = nullptr;      // W2 packed: [h1/8][h2][2][4]
     bool packed_dirty = true;
+    // bf16 compute mode (alink_head_set_compute_dtype; BASELINE configs[4] "bf16 fine-tune", mixed precision):
+    // master parameters, gradients and Adadelta state stay f32; the forward / backward GEMM operands are bf16 —
+    // weights from d_pq (2-byte copy of the flat parameter vector, kept current by the update kernels of the
+    // batch<=32 step, else re-quantised lazily), activations and activation gradients rounded to bf16 where they are
+    // produced; products are exact in f32 and accumulate in f32.  d_pqf holds the same bf16 values widened to f32 for
+    // the large-batch chain and the MFMA predict kernel (a derived cache like d_w1p / d_w2p).  Biases are not quantised.
+    int qmode = 0;
+    __bf16* d_pq = nullptr;
+    float* d_pqf = nullptr;
+    bool pq_dirty = true, pqf_dirty = true;
     // train/eval scratch for up to `cap` rows
     int cap = 4096;
     float *d_dm = nullptr, *d_z1 = nullptr, *d_z2 = nullptr, *d_dz1 = nullptr, *d_dz2 = nullptr,
@@ -66,6 +76,32 @@ struct alink_head {
 
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// round to bf16 and back (RNE): the value a bf16 store of x would hold
+__device__ __forceinline__ float qbf(float x) { return (float)(__bf16)x; }
+template <bool Q> __device__ __forceinline__ float qa(float x) { return Q ? qbf(x) : x; }
+__device__ __forceinline__ float qa(float x, int q) { return q ? qbf(x) : x; }
+// 4 consecutive weights starting at element `i` of a flat f32 (Q = false) or bf16 (Q = true) parameter vector
+template <bool Q> __device__ __forceinline__ f32x4 ldw4(const void* base, size_t i) {
+    if (Q) {
+        const bf16x4 v = *(const bf16x4*)((const __bf16*)base + i);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+    return *(const f32x4*)((const float*)base + i);
+}
+template <bool Q> __device__ __forceinline__ float ldw1(const void* base, size_t i) {
+    return Q ? (float)((const __bf16*)base)[i] : ((const float*)base)[i];
+}
+
+// master f32 -> bf16 copy and its widened f32 image
+__global__ void quantize_kernel(const float* __restrict__ prm, __bf16* __restrict__ pq, float* __restrict__ pqf, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const __bf16 b = (__bf16)prm[i];
+    pq[i] = b;
+    pqf[i] = (float)b;
+}
+
 constexpr int TP = 32;          // pairs per workgroup in the MFMA forward
 constexpr int ROWP = TP * 8 + 4;  // floats per k8 block in LDS (pad 4: conflict-free b128 writes)
 constexpr int KC = 512;         // K chunk staged per pass
@@ -83,6 +119,7 @@ struct HeadFwd {
     int mat_row0;
     int out_col;        // >= 0: write only this softmax column, probs is [P] (else [P][od])
     int od;             // 2: softmax over Dense(2); 1: sigmoid of Dense(1)
+    int q;              // bf16 compute mode: |l - r|, a1, a2 rounded to bf16 (the weights handed in are already)
 };
 
 // out-of-place repack W (in,out) row-major -> [in/8][out][2][4]:  k = 8*k8 + 2*s + h
@@ -142,6 +179,10 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const HeadFwd p) {
             e[1] = fabsf(l0[2] - r0[2]); o[1] = fabsf(l0[3] - r0[3]);
             e[2] = fabsf(l1[0] - r1[0]); o[2] = fabsf(l1[1] - r1[1]);
             e[3] = fabsf(l1[2] - r1[2]); o[3] = fabsf(l1[3] - r1[3]);
+            if (p.q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { e[j] = qbf(e[j]); o[j] = qbf(o[j]); }
+            }
             float* d = buf + k8 * ROWP + row * 8;
             *(f32x4*)d = e;
             *(f32x4*)(d + 4) = o;
@@ -170,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const HeadFwd p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            d[row * 8] = fmaxf(acc[c][r] + bb, 0.f);
+            d[row * 8] = qa(fmaxf(acc[c][r] + bb, 0.f), p.q);
         }
     }
     __syncthreads();
@@ -205,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const HeadFwd p) {
     for (int i = tid; i < TP * h2; i += 256) {
         float s = 0.f;
         for (int z = 0; z < nsplit; ++z) s += buf[z * (TP * h2) + i];
-        a2[i] = fmaxf(s + p.b2[i % h2], 0.f);
+        a2[i] = qa(fmaxf(s + p.b2[i % h2], 0.f), p.q);
     }
     __syncthreads();
     if (tid < 2 * TP && p.od == 2) {
@@ -282,7 +323,7 @@ __global__ __launch_bounds__(512) void dense_fwd_tiled_kernel(const float* __res
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ b, float* __restrict__ z,
                                                              int n, int K, int C, int relu_in,
-                                                             const float* __restrict__ Rm, float* __restrict__ dm_out) {
+                                                             const float* __restrict__ Rm, float* __restrict__ dm_out, int q) {
     __shared__ float part[8][64];
     const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane, r = blockIdx.y;
@@ -293,10 +334,10 @@ __global__ __launch_bounds__(512) void dense_fwd_tiled_kernel(const float* __res
     if (Rm) {
         const float* rr = Rm + (size_t)r * K + ks * kper;
         if (blockIdx.x == 0)
-            for (int k = lane; k < kper; k += 64) dm_out[(size_t)r * K + ks * kper + k] = fabsf(ar[k] - rr[k]);
+            for (int k = lane; k < kper; k += 64) dm_out[(size_t)r * K + ks * kper + k] = qa(fabsf(ar[k] - rr[k]), q);
         if (c < C) {
 #pragma unroll 8
-            for (int k = 0; k < kper; ++k) s = fmaf(fabsf(ar[k] - rr[k]), wp[(size_t)k * C], s);
+            for (int k = 0; k < kper; ++k) s = fmaf(qa(fabsf(ar[k] - rr[k]), q), wp[(size_t)k * C], s);
         }
     } else if (c < C) {
 #pragma unroll 8
@@ -312,7 +353,7 @@ __global__ __launch_bounds__(512) void dense_fwd_tiled_kernel(const float* __res
         float t = part[0][lane];
 #pragma unroll
         for (int i = 1; i < 8; ++i) t += part[i][lane];
-        z[(size_t)r * C + c] = t + b[c];
+        z[(size_t)r * C + c] = qa(t + b[c], q);     // bf16 mode: relu(z) is the next GEMM's operand, rounding commutes with relu
     }
 }
 
@@ -321,6 +362,7 @@ struct HeadLoss {
     float *probs, *dz3, *dz2, *gw3, *gb3, *metrics;
     int n, h2, want_grads, od;
     float grad_scale;   // <= 0: 1 / count(sw != 0)
+    int q;              // bf16 compute mode: dz3 / dz2 rounded to bf16 where produced
 };
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -361,7 +403,7 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const HeadLoss p) {
             if (p.want_grads) {
                 const bool inside = pr >= 1e-7f && pr <= 1.f - 1e-7f;
                 const float dp = inside ? w * scale * (pc - y) / (pc * (1.f - pc)) : 0.f;
-                p.dz3[i] = dp * pr * (1.f - pr);
+                p.dz3[i] = qa(dp * pr * (1.f - pr), p.q);
             }
             continue;
         }
@@ -394,8 +436,8 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const HeadLoss p) {
         if (p.want_grads) {
             // through softmax: dz_j = p_j * (dp_j - sum_c dp_c p_c)
             const float dot = dp[0] * pr[0] + dp[1] * pr[1];
-            p.dz3[i * 2 + 0] = pr[0] * (dp[0] - dot);
-            p.dz3[i * 2 + 1] = pr[1] * (dp[1] - dot);
+            p.dz3[i * 2 + 0] = qa(pr[0] * (dp[0] - dot), p.q);
+            p.dz3[i * 2 + 1] = qa(pr[1] * (dp[1] - dot), p.q);
         }
     }
     lsum = block_sum(lsum, red);
@@ -424,7 +466,7 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const HeadLoss p) {
         const int i = t / h2, c = t - i * h2;
         float g = 0.f;
         for (int j = 0; j < od; ++j) g = fmaf(p.dz3[i * od + j], p.w3[c * od + j], g);
-        p.dz2[t] = p.z2[t] > 0.f ? g : 0.f;
+        p.dz2[t] = p.z2[t] > 0.f ? qa(g, p.q) : 0.f;
     }
 }
 
@@ -486,7 +528,7 @@ __global__ void head_input_grad_kernel(const float* __restrict__ L, const float*
 //   blocks [nb_w, ...): dz1[r][k] = (z1 > 0) sum_c dz2[r][c] W2[k][c]          (dense_dgrad_kernel's body)
 __global__ void head_bwd_mid_kernel(const float* __restrict__ z1, const float* __restrict__ dz2,
                                     const float* __restrict__ w2, float* __restrict__ gw2, float* __restrict__ gb2,
-                                    float* __restrict__ dz1, int n, int h1, int h2, int nb_w) {
+                                    float* __restrict__ dz1, int n, int h1, int h2, int nb_w, int q) {
     if ((int)blockIdx.x < nb_w) {
         const int i = blockIdx.x * 256 + threadIdx.x;
         if (i < h1 * h2) {
@@ -509,7 +551,7 @@ __global__ void head_bwd_mid_kernel(const float* __restrict__ z1, const float* _
     const float* dr = dz2 + (size_t)r * h2;
     float s = 0.f;
     for (int c = 0; c < h2; ++c) s = fmaf(dr[c], wr[c], s);
-    dz1[i] = z1[i] > 0.f ? s : 0.f;
+    dz1[i] = z1[i] > 0.f ? qa(s, q) : 0.f;
 }
 
 __device__ __forceinline__ void adadelta_one(float* prm, float* a, float* d, size_t i, float gi, float lr, float rho,
@@ -569,11 +611,24 @@ int head_alloc(alink_head* h, float** p, size_t count) {
     return ALINK_OK;
 }
 
+// bf16 mode: bring the bf16 copy (and, if asked, its widened image) up to date with the f32 master parameters
+int ensure_q(alink_head* h, hipStream_t st, bool need_widened) {
+    if (!h->qmode) return ALINK_OK;
+    if (!h->pq_dirty && !(need_widened && h->pqf_dirty)) return ALINK_OK;
+    hipLaunchKernelGGL(quantize_kernel, g1((long long)h->nparams), dim3(256), 0, st, h->d_params, h->d_pq, h->d_pqf,
+                       h->nparams);
+    ALINK_HIP(hipGetLastError());
+    h->pq_dirty = h->pqf_dirty = false;
+    return ALINK_OK;
+}
+
 int ensure_packed(alink_head* h, hipStream_t st) {
     if (!h->packed_dirty) return ALINK_OK;
-    hipLaunchKernelGGL(pack_kernel, g1((long long)h->D * h->h1), dim3(256), 0, st, h->d_params + h->oW1,
+    if (h->qmode) { const int rc = ensure_q(h, st, true); if (rc) return rc; }
+    const float* src = h->qmode ? h->d_pqf : h->d_params;
+    hipLaunchKernelGGL(pack_kernel, g1((long long)h->D * h->h1), dim3(256), 0, st, src + h->oW1,
                        h->d_w1p, h->D, h->h1);
-    hipLaunchKernelGGL(pack_kernel, g1((long long)h->h1 * h->h2), dim3(256), 0, st, h->d_params + h->oW2,
+    hipLaunchKernelGGL(pack_kernel, g1((long long)h->h1 * h->h2), dim3(256), 0, st, src + h->oW2,
                        h->d_w2p, h->h1, h->h2);
     ALINK_HIP(hipGetLastError());
     h->packed_dirty = false;
@@ -595,7 +650,8 @@ int launch_fwd(alink_head* h, const float* L, const float* R, const int32_t* li,
     HeadFwd p{};
     p.L = L; p.R = R; p.li = li; p.ri = ri; p.P = P;
     p.w1p = h->d_w1p; p.b1 = h->d_params + h->ob1; p.w2p = h->d_w2p; p.b2 = h->d_params + h->ob2;
-    p.w3 = h->d_params + h->oW3; p.b3 = h->d_params + h->ob3; p.probs = probs;
+    p.w3 = (h->qmode ? h->d_pqf : h->d_params) + h->oW3; p.b3 = h->d_params + h->ob3; p.probs = probs;
+    p.q = h->qmode ? 1 : 0;
     p.D = h->D; p.h1 = h->h1; p.h2 = h->h2; p.accumulate = accumulate; p.final_div = final_div;
     p.matN = matN; p.mat_row0 = mat_row0; p.out_col = out_col; p.od = h->od;
     const size_t lds = fwd_lds_bytes(h->h1);
@@ -645,18 +701,22 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ const float* tiny_w_ptr(const float* __restrict__ w, int K, int C, int c0) {
+// element offset (inside a K x C weight matrix) of this thread's first 4 weights
+__device__ __forceinline__ size_t tiny_w_off(int K, int C, int c0) {
     const int tid = threadIdx.x, cl = tid & 15, ks = tid >> 4;
-    return w + (size_t)(ks * (K >> 5)) * C + c0 + cl * 4;
+    return (size_t)(ks * (K >> 5)) * C + c0 + cl * 4;
 }
-__device__ __forceinline__ void tiny_load_w(f32x4 (&wv)[16], const float* wp, int C) {
+// Q: the weights are the bf16 copy (8-byte loads, widened in registers)
+template <bool Q>
+__device__ __forceinline__ void tiny_load_w(f32x4 (&wv)[16], const void* wbase, size_t off, int C) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) wv[i] = *(const f32x4*)(wp + (size_t)i * C);
+    for (int i = 0; i < 16; ++i) wv[i] = ldw4<Q>(wbase, off + (size_t)i * C);
 }
 // `wv` holds the first 16-deep chunk (loaded by the caller before it staged a_s, so the weight loads and
 // the activation loads share one round trip).
-__device__ __forceinline__ void tiny_dense_core(const float* a_s, int K, const float* wp, int C, f32x4 (&wv)[16],
-                                                float* red /* [8][TINY_RG][64] */, float* fin) {
+template <bool Q>
+__device__ __forceinline__ void tiny_dense_core(const float* a_s, int K, const void* wbase, size_t woff, int C,
+                                                f32x4 (&wv)[16], float* red /* [8][TINY_RG][64] */, float* fin) {
     const int tid = threadIdx.x, cl = tid & 15, ks = tid >> 4;
     const int kper = K >> 5;
     float acc[TINY_RG][4];
@@ -666,7 +726,7 @@ __device__ __forceinline__ void tiny_dense_core(const float* a_s, int K, const f
         for (int j = 0; j < 4; ++j) acc[r][j] = 0.f;
     const float* ap = a_s + ks * kper;
     for (int k0 = 0; k0 < kper; k0 += 16) {
-        if (k0) tiny_load_w(wv, wp + (size_t)k0 * C, C);
+        if (k0) tiny_load_w<Q>(wv, wbase, woff + (size_t)k0 * C, C);
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
 #pragma unroll
@@ -704,8 +764,9 @@ __device__ __forceinline__ void tiny_dense_core(const float* a_s, int K, const f
     __syncthreads();
 }
 
+template <bool Q>
 __global__ __launch_bounds__(512) void tiny_dense1_kernel(const float* __restrict__ L, const float* __restrict__ R,
-                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const void* __restrict__ w1, const float* __restrict__ b1,
                                                          float* __restrict__ z1, float* __restrict__ dm, int n, int D,
                                                          int h1) {
     extern __shared__ __attribute__((aligned(16))) float tiny_lds[];
@@ -713,9 +774,9 @@ __global__ __launch_bounds__(512) void tiny_dense1_kernel(const float* __restric
     float* red = a_s + TINY_RG * D;               // [8][TINY_RG][64]
     float* fin = red + 8 * TINY_RG * 64;          // [TINY_RG][64]
     const int tid = threadIdx.x, r0 = blockIdx.y * TINY_RG, c0 = blockIdx.x * 64;
-    const float* wp = tiny_w_ptr(w1, D, h1, c0);
+    const size_t woff = tiny_w_off(D, h1, c0);
     f32x4 wv[16];
-    tiny_load_w(wv, wp, h1);
+    tiny_load_w<Q>(wv, w1, woff, h1);
     const float bias = tid < TINY_RG * 64 ? b1[c0 + (tid & 63)] : 0.f;
     for (int i = tid; i < TINY_RG * D / 4; i += 512) {
         const int r = (i * 4) / D, k = (i * 4) - r * D, row = r0 + r;
@@ -723,27 +784,30 @@ __global__ __launch_bounds__(512) void tiny_dense1_kernel(const float* __restric
         if (row < n) {
             const f32x4 l = *(const f32x4*)(L + (size_t)row * D + k), q = *(const f32x4*)(R + (size_t)row * D + k);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fabsf(l[j] - q[j]);
+            for (int j = 0; j < 4; ++j) v[j] = qa<Q>(fabsf(l[j] - q[j]));
             if (blockIdx.x == 0) *(f32x4*)(dm + (size_t)row * D + k) = v;
         }
         *(f32x4*)(a_s + i * 4) = v;
     }
     __syncthreads();
-    tiny_dense_core(a_s, D, wp, h1, wv, red, fin);
+    tiny_dense_core<Q>(a_s, D, w1, woff, h1, wv, red, fin);
     if (tid < TINY_RG * 64) {
         const int r = tid >> 6, c = tid & 63, row = r0 + r;
-        if (row < n) z1[(size_t)row * h1 + c0 + c] = fin[tid] + bias;
+        if (row < n) z1[(size_t)row * h1 + c0 + c] = qa<Q>(fin[tid] + bias);     // relu(q(z)) == q(relu(z))
     }
 }
 
 struct TinyLoss {
-    const float *z1, *w2, *b2, *w3, *b3, *y, *sw;
+    const void* wbase;        // flat parameter vector the WEIGHTS are read from: f32 master, or its bf16 copy (Q)
+    size_t oW2, oW3;
+    const float *z1, *b2, *b3, *y, *sw;
     float *z2, *probs, *dz2, *dz3, *dz1, *part;
     int n, h1, od, want_grads;
     float grad_scale;
 };
 
 // h2 == 64.  One workgroup per TINY_RG rows.
+template <bool Q>
 __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p) {
     extern __shared__ __attribute__((aligned(16))) float tiny_lds[];
     const int h1 = p.h1, n = p.n, od = p.od;
@@ -758,11 +822,14 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
     float* sws = ys + TINY_RG * 2;                // [TINY_RG]
     const int tid = threadIdx.x, r0 = blockIdx.x * TINY_RG;
     // every small operand is fetched now, together with the weights: nothing later waits on global memory
-    const float* wp = tiny_w_ptr(p.w2, h1, 64, 0);
+    const size_t woff = p.oW2 + tiny_w_off(h1, 64, 0);
     f32x4 wv[16];
-    tiny_load_w(wv, wp, 64);
+    tiny_load_w<Q>(wv, p.wbase, woff, 64);
     const float bias = tid < TINY_RG * 64 ? p.b2[tid & 63] : 0.f;
-    if (tid >= 64 && tid < 64 + 64 * od + od) w3s[tid - 64] = p.w3[tid - 64];
+    if (tid >= 64 && tid < 64 + 64 * od + od) {       // W3 (quantised in Q mode) then b3 (never quantised)
+        const int t = tid - 64;
+        w3s[t] = t < 64 * od ? ldw1<Q>(p.wbase, p.oW3 + t) : p.b3[t - 64 * od];
+    }
     if (tid >= 256 && tid < 256 + TINY_RG * od) {
         const int t = tid - 256, row = r0 + t / od;
         ys[t] = row < n ? p.y[(size_t)row * od + t % od] : 0.f;
@@ -788,18 +855,18 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
         if (tid == 0) cnts[0] = c;
     }
     __syncthreads();
-    tiny_dense_core(a_s, h1, wp, 64, wv, red, z2s);
+    tiny_dense_core<Q>(a_s, h1, p.wbase, woff, 64, wv, red, z2s);
     // dZ1 below walks W2 in chunks of 128 rows staged through LDS (coalesced 16-B loads here, padded rows
     // read back per thread): the first chunk is fetched now, under the loss computation
     const bool w2_in_regs = h1 == 512;       // one 16-deep chunk per thread: wv still holds this thread's share of W2
     f32x4 wc[4];
     if (p.want_grads && !w2_in_regs) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wc[i] = *(const f32x4*)(p.w2 + (size_t)(tid + 512 * i) * 4);
+        for (int i = 0; i < 4; ++i) wc[i] = ldw4<Q>(p.wbase, p.oW2 + (size_t)(tid + 512 * i) * 4);
     }
     if (tid < TINY_RG * 64) {
         const int r = tid >> 6, c = tid & 63, row = r0 + r;
-        const float v = z2s[tid] + bias;
+        const float v = qa<Q>(z2s[tid] + bias);
         z2s[tid] = v;
         if (row < n) p.z2[(size_t)row * 64 + c] = v;
     }
@@ -835,7 +902,7 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
                     ai = (rintf(pr) == y) ? 1.f : 0.f;
                     const bool inside = pr >= 1e-7f && pr <= 1.f - 1e-7f;
                     const float dp = inside ? w * scale * (pc - y) / (pc * (1.f - pc)) : 0.f;
-                    d3[0] = dp * pr * (1.f - pr);
+                    d3[0] = qa<Q>(dp * pr * (1.f - pr));
                 } else {
                     const float z0 = z[0] + b3s[0], z1v = z[1] + b3s[1];
                     const float m = fmaxf(z0, z1v);
@@ -857,8 +924,8 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
                     li = 0.5f * lsum * w;
                     ai = 0.5f * acc;
                     const float dot = dp[0] * pr[0] + dp[1] * pr[1];
-                    d3[0] = pr[0] * (dp[0] - dot);
-                    d3[1] = pr[1] * (dp[1] - dot);
+                    d3[0] = qa<Q>(pr[0] * (dp[0] - dot));
+                    d3[1] = qa<Q>(pr[1] * (dp[1] - dot));
                 }
                 if (p.want_grads) {
                     p.dz3[row * od + 0] = d3[0];
@@ -888,7 +955,7 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
         const int r = tid >> 6, c = tid & 63, row = r0 + r;
         float g = dz3s[r * 2] * w3s[c * od];
         if (od == 2) g = fmaf(dz3s[r * 2 + 1], w3s[c * od + 1], g);
-        g = z2s[tid] > 0.f ? g : 0.f;
+        g = z2s[tid] > 0.f ? qa<Q>(g) : 0.f;
         dz2s[tid] = g;
         if (row < n) p.dz2[(size_t)row * 64 + c] = g;
     } else if (tid < TINY_RG * 64 + 64 * od + od) {
@@ -927,7 +994,7 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
                 if (cl == i) mine = sdot;         // lane i of the row keeps (and stores) W2 row 16 ks + i
             }
             const int k = ks * 16 + cl;
-            if (r0 + r < n) p.dz1[(size_t)(r0 + r) * h1 + k] = a_s[r * h1 + k] > 0.f ? mine : 0.f;
+            if (r0 + r < n) p.dz1[(size_t)(r0 + r) * h1 + k] = a_s[r * h1 + k] > 0.f ? qa<Q>(mine) : 0.f;
         }
         return;
     }
@@ -944,7 +1011,7 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
         __syncthreads();
         if (kc + 128 < h1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wc[i] = *(const f32x4*)(p.w2 + (size_t)(kc + 128) * 64 + (size_t)(tid + 512 * i) * 4);
+            for (int i = 0; i < 4; ++i) wc[i] = ldw4<Q>(p.wbase, p.oW2 + (size_t)(kc + 128) * 64 + (size_t)(tid + 512 * i) * 4);
         }
         float sdot = 0.f;
 #pragma unroll
@@ -954,7 +1021,7 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) sdot = fmaf(dv[j], wv4[j], sdot);
         }
-        if (r0 + rq < n) p.dz1[(size_t)(r0 + rq) * h1 + kc + kq] = a_s[rq * h1 + kc + kq] > 0.f ? sdot : 0.f;
+        if (r0 + rq < n) p.dz1[(size_t)(r0 + rq) * h1 + kc + kq] = a_s[rq * h1 + kc + kq] > 0.f ? qa<Q>(sdot) : 0.f;
         __syncthreads();
     }
 }
@@ -962,6 +1029,7 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
 struct TinyBwd {
     const float *z1, *dz1, *dz2, *dm, *part, *sw;
     float *prm, *g, *a, *d, *metrics;
+    __bf16* pq;               // bf16 copy of the parameters, refreshed with every update (nullptr in f32 mode)
     size_t oW1, ob1, oW2, ob2, oW3, ob3;
     int n, D, h1, od, apply, ngroups;
     float lr, rho, eps, grad_scale;
@@ -988,6 +1056,7 @@ __device__ __forceinline__ void tiny_update4(const TinyBwd& p, size_t i, const f
         *(f32x4*)(p.prm + i) = w;
         *(f32x4*)(p.a + i) = a;
         *(f32x4*)(p.d + i) = d;
+        if (p.pq) *(bf16x4*)(p.pq + i) = bf16x4{(__bf16)w[0], (__bf16)w[1], (__bf16)w[2], (__bf16)w[3]};
     }
 }
 
@@ -1075,7 +1144,9 @@ __global__ __launch_bounds__(256) void tiny_wgrad_update_kernel(const TinyBwd p)
         if (tid < 64) {
             p.g[p.ob1 + c0 + tid] = gb1;
             if (p.apply) {
-                p.prm[p.ob1 + c0 + tid] = tiny_adadelta(b1w, gb1, b1a, b1d, p.lr, p.rho, p.eps);
+                const float nb1 = tiny_adadelta(b1w, gb1, b1a, b1d, p.lr, p.rho, p.eps);
+                p.prm[p.ob1 + c0 + tid] = nb1;
+                if (p.pq) p.pq[p.ob1 + c0 + tid] = (__bf16)nb1;
                 p.a[p.ob1 + c0 + tid] = b1a;
                 p.d[p.ob1 + c0 + tid] = b1d;
             }
@@ -1130,7 +1201,9 @@ __global__ __launch_bounds__(256) void tiny_wgrad_update_kernel(const TinyBwd p)
     if (is_b2 || is_w3) {
         p.g[pi] = s;
         if (p.apply) {
-            p.prm[pi] = tiny_adadelta(w_, s, a_, d_, p.lr, p.rho, p.eps);
+            const float nw = tiny_adadelta(w_, s, a_, d_, p.lr, p.rho, p.eps);
+            p.prm[pi] = nw;
+            if (p.pq) p.pq[pi] = (__bf16)nw;
             p.a[pi] = a_;
             p.d[pi] = d_;
         }
@@ -1148,7 +1221,7 @@ size_t tiny_lds_bytes(int K, bool with_w2 = false) {
 
 bool tiny_ok(const alink_head* h, int n) {
     return g_use_tiny && n <= TINY_N && h->h2 == 64 && h->h1 % 512 == 0 && h->D % 512 == 0 && h->D <= 2048 &&
-           h->h1 <= 1024 && h->oW1 == 0;     // LDS: 43 KB (A at D = 2048), 61 KB (B at h1 = 1024) of the 64 KB default
+           h->h1 <= 1024 && h->oW1 == 0 && (!h->qmode || h->h1 == 512);     // LDS: 43 KB (A at D = 2048), 61 KB (B at h1 = 1024) of the 64 KB default
 }
 
 // the three launches; gradients are always left in d_grads, parameters updated when `apply`
@@ -1156,17 +1229,25 @@ int tiny_train(alink_head* h, const float* L, const float* R, const float* y, co
                float grad_scale, bool apply, float* metrics, hipStream_t st) {
     const int D = h->D, h1 = h->h1;
     float* P = h->d_params;
+    const bool Q = h->qmode != 0;
+    if (Q) { const int rc = ensure_q(h, st, false); if (rc) return rc; }
+    const void* WB = Q ? (const void*)h->d_pq : (const void*)P;      // where the WEIGHTS are read from (oW1 == 0)
     const int ngroups = (n + TINY_RG - 1) / TINY_RG;
-    hipLaunchKernelGGL(tiny_dense1_kernel, dim3(h1 / 64, ngroups), dim3(512), tiny_lds_bytes(D), st, L, R, P + h->oW1,
-                       P + h->ob1, h->d_z1, h->d_dm, n, D, h1);
+    if (Q) hipLaunchKernelGGL(tiny_dense1_kernel<true>, dim3(h1 / 64, ngroups), dim3(512), tiny_lds_bytes(D), st, L, R, WB,
+                              P + h->ob1, h->d_z1, h->d_dm, n, D, h1);
+    else   hipLaunchKernelGGL(tiny_dense1_kernel<false>, dim3(h1 / 64, ngroups), dim3(512), tiny_lds_bytes(D), st, L, R, WB,
+                              P + h->ob1, h->d_z1, h->d_dm, n, D, h1);
     TinyLoss lp{};
-    lp.z1 = h->d_z1; lp.w2 = P + h->oW2; lp.b2 = P + h->ob2; lp.w3 = P + h->oW3; lp.b3 = P + h->ob3; lp.y = y;
+    lp.wbase = WB; lp.oW2 = h->oW2; lp.oW3 = h->oW3;
+    lp.z1 = h->d_z1; lp.b2 = P + h->ob2; lp.b3 = P + h->ob3; lp.y = y;
     lp.sw = sw; lp.z2 = h->d_z2; lp.probs = h->d_p; lp.dz2 = h->d_dz2; lp.dz3 = h->d_dz3; lp.dz1 = h->d_dz1;
     lp.part = h->d_tiny; lp.n = n; lp.h1 = h1; lp.od = h->od; lp.want_grads = 1; lp.grad_scale = grad_scale;
-    hipLaunchKernelGGL(tiny_dense2_loss_kernel, dim3(ngroups), dim3(512), tiny_lds_bytes(h1, true), st, lp);
+    if (Q) hipLaunchKernelGGL(tiny_dense2_loss_kernel<true>, dim3(ngroups), dim3(512), tiny_lds_bytes(h1, true), st, lp);
+    else   hipLaunchKernelGGL(tiny_dense2_loss_kernel<false>, dim3(ngroups), dim3(512), tiny_lds_bytes(h1, true), st, lp);
     TinyBwd bp{};
     bp.z1 = h->d_z1; bp.dz1 = h->d_dz1; bp.dz2 = h->d_dz2; bp.dm = h->d_dm; bp.part = h->d_tiny; bp.sw = sw;
     bp.prm = P; bp.g = h->d_grads; bp.a = h->d_acc; bp.d = h->d_dacc; bp.metrics = metrics;
+    bp.pq = Q ? h->d_pq : nullptr;
     bp.oW1 = h->oW1; bp.ob1 = h->ob1; bp.oW2 = h->oW2; bp.ob2 = h->ob2; bp.oW3 = h->oW3; bp.ob3 = h->ob3;
     bp.n = n; bp.D = D; bp.h1 = h1; bp.od = h->od; bp.apply = apply ? 1 : 0; bp.ngroups = ngroups;
     bp.lr = h->lr; bp.rho = h->rho; bp.eps = h->eps; bp.grad_scale = grad_scale;
@@ -1185,19 +1266,23 @@ int small_pass(alink_head* h, const float* L, const float* R, const float* y, co
     const int D = h->D, h1 = h->h1, h2 = h->h2;
     float* P = h->d_params;
     float* G = h->d_grads;
-    hipLaunchKernelGGL(dense_fwd_tiled_kernel, dim3((h1 + 63) / 64, n), dim3(512), 0, st, L, P + h->oW1,
-                       P + h->ob1, h->d_z1, n, D, h1, 0, R, h->d_dm);
-    hipLaunchKernelGGL(dense_fwd_tiled_kernel, dim3((h2 + 63) / 64, n), dim3(512), 0, st, h->d_z1, P + h->oW2,
-                       P + h->ob2, h->d_z2, n, h1, h2, 1, (const float*)nullptr, (float*)nullptr);
+    const int q = h->qmode ? 1 : 0;
+    if (q) { const int rc = ensure_q(h, st, true); if (rc) return rc; }
+    const float* WF = q ? h->d_pqf : P;            // weights: the bf16 values widened to f32 in bf16 mode; biases: master
+    hipLaunchKernelGGL(dense_fwd_tiled_kernel, dim3((h1 + 63) / 64, n), dim3(512), 0, st, L, WF + h->oW1,
+                       P + h->ob1, h->d_z1, n, D, h1, 0, R, h->d_dm, q);
+    hipLaunchKernelGGL(dense_fwd_tiled_kernel, dim3((h2 + 63) / 64, n), dim3(512), 0, st, h->d_z1, WF + h->oW2,
+                       P + h->ob2, h->d_z2, n, h1, h2, 1, (const float*)nullptr, (float*)nullptr, q);
     HeadLoss lp{};
-    lp.z2 = h->d_z2; lp.w3 = P + h->oW3; lp.b3 = P + h->ob3; lp.y = y; lp.sw = sw; lp.probs = h->d_p;
+    lp.q = q;
+    lp.z2 = h->d_z2; lp.w3 = WF + h->oW3; lp.b3 = P + h->ob3; lp.y = y; lp.sw = sw; lp.probs = h->d_p;
     lp.dz3 = h->d_dz3; lp.dz2 = h->d_dz2; lp.gw3 = G + h->oW3; lp.gb3 = G + h->ob3; lp.metrics = metrics;
     lp.n = n; lp.h2 = h2; lp.want_grads = want_grads ? 1 : 0; lp.grad_scale = grad_scale; lp.od = h->od;
     hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(256), 0, st, lp);
     if (want_grads) {
         const int nb_w = (h1 * h2 + h2 + 255) / 256, nb_d = (n * h1 + 255) / 256;
-        hipLaunchKernelGGL(head_bwd_mid_kernel, dim3(nb_w + nb_d), dim3(256), 0, st, h->d_z1, h->d_dz2, P + h->oW2,
-                           G + h->oW2, G + h->ob2, h->d_dz1, n, h1, h2, nb_w);
+        hipLaunchKernelGGL(head_bwd_mid_kernel, dim3(nb_w + nb_d), dim3(256), 0, st, h->d_z1, h->d_dz2, WF + h->oW2,
+                           G + h->oW2, G + h->ob2, h->d_dz1, n, h1, h2, nb_w, q);
         if (fused_update) {
             const size_t n_first = (size_t)D * h1 + h1;            // W1 and b1 are the first parameters (oW1 = 0)
             const int nb_first = (int)((n_first + 255) / 256), nb_rest = (int)((h->nparams - n_first + 255) / 256);
@@ -1275,7 +1360,7 @@ int alink_head_set_params(alink_head_t* h, const float* host_params, size_t coun
     ALINK_REQUIRE(count == h->nparams, ALINK_EINVAL, "expected %zu parameters, got %zu", h->nparams, count);
     DeviceGuard dg(h->device);
     ALINK_HIP(hipMemcpy(h->d_params, host_params, count * sizeof(float), hipMemcpyHostToDevice));
-    h->packed_dirty = true;
+    h->packed_dirty = h->pq_dirty = h->pqf_dirty = true;
     return ALINK_OK;
 }
 int alink_head_get_params(const alink_head_t* h, float* host_params, size_t count) {
@@ -1301,7 +1386,7 @@ int alink_head_set_lr(alink_head_t* h, float lr) {
 float alink_head_get_lr(const alink_head_t* h) { return h ? h->lr : 0.f; }
 float* alink_head_params_dev(alink_head_t* h) {
     if (!h) return nullptr;
-    h->packed_dirty = true;      // the caller may write through it: re-pack the forward's weight copies on next use
+    h->packed_dirty = h->pq_dirty = h->pqf_dirty = true;      // the caller may write through it: re-derive every weight copy on next use
     return h->d_params;
 }
 float* alink_head_grads_dev(alink_head_t* h) { return h ? h->d_grads : nullptr; }
@@ -1377,7 +1462,10 @@ static int train_step_launches(alink_head_t* h, const float* dev_L, const float*
     int rc = tiny_ok(h, n) ? tiny_train(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, apply != 0, dev_metrics, st)
                            : small_pass(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, true, dev_metrics, st, apply != 0);
     if (rc) return rc;
-    if (apply) h->packed_dirty = true;
+    if (apply) {
+        h->packed_dirty = h->pqf_dirty = true;
+        if (!tiny_ok(h, n)) h->pq_dirty = true;        // the batch<=32 step writes the bf16 copy itself
+    }
     return ALINK_OK;
 }
 
@@ -1399,7 +1487,7 @@ int alink_head_train_step(alink_head_t* h, const float* dev_L, const float* dev_
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     // the legacy default stream cannot be captured, and a stream the caller is already capturing must
     // simply receive the launches
-    const bool can_graph = h->use_graph && st != nullptr &&
+    const bool can_graph = h->use_graph && !h->qmode && st != nullptr &&
                            hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
     if (!can_graph) return train_step_launches(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, apply, dev_metrics, st);
     for (auto& g : h->graphs)
@@ -1444,14 +1532,31 @@ int alink_head_apply_update(alink_head_t* h, void* stream) {
     hipLaunchKernelGGL(adadelta_kernel, g1((long long)h->nparams), dim3(256), 0, (hipStream_t)stream,
                        h->d_params, h->d_grads, h->d_acc, h->d_dacc, h->nparams, h->lr, h->rho, h->eps);
     ALINK_HIP(hipGetLastError());
-    h->packed_dirty = true;
+    h->packed_dirty = h->pq_dirty = h->pqf_dirty = true;
     return ALINK_OK;
 }
+
+int alink_head_set_compute_dtype(alink_head_t* h, int dtype) {
+    ALINK_REQUIRE(h, ALINK_EINVAL, "NULL head");
+    ALINK_REQUIRE(dtype == ALINK_DT_F32 || dtype == ALINK_DT_BF16, ALINK_EINVAL, "compute dtype must be ALINK_DT_F32 or ALINK_DT_BF16");
+    DeviceGuard dg(h->device);
+    if (dtype == ALINK_DT_BF16 && !h->d_pq) {
+        ALINK_HIP(hipMalloc((void**)&h->d_pq, h->nparams * sizeof(__bf16)));
+        h->allocs.push_back(h->d_pq);
+        ALINK_HIP(hipMalloc((void**)&h->d_pqf, h->nparams * sizeof(float)));
+        h->allocs.push_back(h->d_pqf);
+    }
+    h->qmode = dtype == ALINK_DT_BF16 ? 1 : 0;
+    h->packed_dirty = h->pq_dirty = h->pqf_dirty = true;
+    return ALINK_OK;
+}
+int alink_head_get_compute_dtype(const alink_head_t* h) { return h && h->qmode ? ALINK_DT_BF16 : ALINK_DT_F32; }
 
 int alink_head_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, int n, float* dev_dL,
                            float* dev_dR, void* stream) {
     ALINK_REQUIRE(h && dev_L && dev_R && dev_dL && dev_dR, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(n > 0 && n <= h->cap, ALINK_EINVAL, "batch of %d rows outside 1..%d", n, h->cap);
+    ALINK_REQUIRE(!h->qmode, ALINK_ESTATE, "input gradients (the SmallRes tower) are float32 only");
     DeviceGuard dg(h->device);
     hipLaunchKernelGGL(head_input_grad_kernel, g1((long long)n * h->D), dim3(256), 0, (hipStream_t)stream, dev_L,
                        dev_R, h->d_dz1, h->d_params + h->oW1, dev_dL, dev_dR, n, h->D, h->h1);

@@ -145,7 +145,8 @@ class DenseHead(KerasFitMixin):
     """abs(l - r) -> Dense(h1, relu) -> Dense(h2, relu) -> Dense(2) -> softmax; BCE + Adadelta.
     out_dim=1 is the baseline scripts' variant: Dense(1, sigmoid) (reference code/siamese3.py:25)."""
 
-    def __init__(self, d_in, h1=512, h2=64, lr=1.0, rho=0.95, eps=1e-8, seed=None, device=None, out_dim=2):
+    def __init__(self, d_in, h1=512, h2=64, lr=1.0, rho=0.95, eps=1e-8, seed=None, device=None, out_dim=2,
+                 compute_dtype="f32"):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
@@ -158,6 +159,8 @@ class DenseHead(KerasFitMixin):
             self.h = self.lib.alink_head_create_ex(self.d_in, self.h1, self.h2, self.out_dim, lr, rho, eps)
         if not self.h:
             raise _abi.AlinkError("alink_head_create: " + self.lib.alink_last_error().decode())
+        self.compute_dtype = "f32"
+        self.set_compute_dtype(compute_dtype)
         self.loss = "binary_crossentropy"               # what keras_wrapper reads off model.loss
         self.metrics_names = ["loss", "acc"]
         self.stop_training = False
@@ -179,6 +182,13 @@ class DenseHead(KerasFitMixin):
                 self.h = None
         except Exception:
             pass
+
+    def set_compute_dtype(self, compute_dtype):
+        """"f32" (default; Keras' floatx, what the reference trains in) or "bf16": mixed precision — f32 master
+        weights, gradients and Adadelta state, bf16 GEMM operands (include/alink_hip.h, alink_head_set_compute_dtype)."""
+        code = {"f32": _abi.DT_F32, "bf16": _abi.DT_BF16}[compute_dtype]
+        _abi.check(self.lib.alink_head_set_compute_dtype(self.h, code), "alink_head_set_compute_dtype")
+        self.compute_dtype = compute_dtype
 
     # -- parameters --------------------------------------------------------------------------------
     def _shapes(self):

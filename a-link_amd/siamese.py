@@ -36,13 +36,15 @@ def _inverse_frequency_weights(y):
 class SiameseNetwork:
     _identity_preprocess = True
 
-    def __init__(self, shape, modelName, learningRate=1.0, seed=None, adadelta_epsilon=1e-8):
+    def __init__(self, shape, modelName, learningRate=1.0, seed=None, adadelta_epsilon=1e-8, compute_dtype="f32"):
         self.learningRate = learningRate
         self.modelName = modelName
         self.shape = shape
         # abs(l - r) -> Dense(512, relu) -> Dense(64, relu) -> Dense(2) -> softmax,
         # loss binary_crossentropy, optimizer Adadelta(learningRate) (code/siamese.py:24-35)
-        self.siamese_net = DenseHead(shape[0], 512, 64, lr=learningRate, rho=0.95, eps=adadelta_epsilon, seed=seed)
+        # compute_dtype="bf16": mixed-precision fine-tune (BASELINE configs[4]); the reference's Keras model is float32
+        self.siamese_net = DenseHead(shape[0], 512, 64, lr=learningRate, rho=0.95, eps=adadelta_epsilon, seed=seed,
+                                     compute_dtype=compute_dtype)
 
     def getDenseBarebones(self):
         """(code/siamese.py:37-42) layer specs as (units, activation) — there is no Keras here."""

@@ -292,6 +292,17 @@ def main():
             hd.train_on_batch([L, R], yd)      # fwd + BCE + bwd + Adadelta + metrics read-back
             ts.append(time.perf_counter() - t1)
         line["finetune_step_ms"] = 1e3 * float(np.median(ts))
+        # the same step in the head's bf16 compute mode (configs[4]: f32 masters + Adadelta, bf16 GEMM operands)
+        hq = DenseHead(512, lr=0.1, seed=0, device=local_rank, compute_dtype="bf16")
+        for _ in range(20):
+            hq.train_on_batch([L, R], yd)
+        ts = []
+        for _ in range(200):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hq.train_on_batch([L, R], yd)
+            ts.append(time.perf_counter() - t1)
+        line["finetune_step_bf16_ms"] = 1e3 * float(np.median(ts))
         # pair scoring throughput (K6): 1M pairs gathered from a 100k x 512 embedding matrix
         E = torch.randn(100000, 512, device="cuda")
         E = E / E.norm(dim=1, keepdim=True)

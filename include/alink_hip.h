@@ -39,6 +39,7 @@ extern "C" {
 /* activation / weight storage type of the backbone GEMMs (accumulation is always f32) */
 #define ALINK_DT_BF16 0
 #define ALINK_DT_F16  1
+#define ALINK_DT_F32  2   /* pair-head compute type only (alink_head_set_compute_dtype) */
 
 /* input pixel layouts accepted by alink_embed */
 #define ALINK_LAYOUT_NHWC_F32 0   /* what siamese.ArcFace.process receives (code/siamese.py:232-234) */
@@ -203,6 +204,14 @@ size_t alink_head_num_params(const alink_head_t* h);   /* W1,b1,W2,b2,W3,b3 flat
 int alink_head_set_params(alink_head_t* h, const float* host_params, size_t count);
 int alink_head_get_params(const alink_head_t* h, float* host_params, size_t count);
 int alink_head_reset_optimizer(alink_head_t* h);
+/* Compute type of the head's forward / backward GEMMs: ALINK_DT_F32 (default: exact-f32 MFMA, Keras' floatx) or
+ * ALINK_DT_BF16 — BASELINE configs[4]'s "bf16 fine-tune", mixed precision: parameters, gradients and Adadelta state stay
+ * f32 (get/set_params, params_dev, grads_dev unchanged: the all-reduce buffer is f32); the GEMM operands are bf16 —
+ * a 2-byte copy of the weights (refreshed by the update kernels) and activations / activation gradients rounded to
+ * bf16 where they are produced — with exact products accumulated in f32; biases are not quantised.  Applies to
+ * predict, eval and the train step alike.  The reference trains in float32 (code/siamese.py:33-35). */
+int alink_head_set_compute_dtype(alink_head_t* h, int dtype);
+int alink_head_get_compute_dtype(const alink_head_t* h);
 /* keras.callbacks.ReduceLROnPlateau hook (code/siamese.py:54): change Adadelta's lr */
 int alink_head_set_lr(alink_head_t* h, float lr);
 float alink_head_get_lr(const alink_head_t* h);

@@ -17,6 +17,15 @@ All arithmetic in float32 (Keras floatx), float64 optionally for a tighter refer
 import numpy as np
 
 
+def bf16_round(x):
+    """float32 -> nearest bfloat16 (ties to even) -> float32: the value a 2-byte store of x holds."""
+    x = np.ascontiguousarray(x, np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    out = (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32).reshape(x.shape)
+    return np.where(np.isfinite(x), out, x).astype(np.float32)
+
+
 def glorot_uniform(rng, fan_in, fan_out):
     lim = np.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-lim, lim, (fan_in, fan_out)).astype(np.float32)
@@ -33,13 +42,18 @@ def softmax(z):
     return e / e.sum(axis=1, keepdims=True)
 
 
-def forward(ws, L, R, dtype=np.float32, cache=False):
-    """code/siamese.py:27-32: abs(L-R) -> Dense relu -> Dense relu -> Dense -> softmax."""
+def forward(ws, L, R, dtype=np.float32, cache=False, quant=None):
+    """code/siamese.py:27-32: abs(L-R) -> Dense relu -> Dense relu -> Dense -> softmax.
+    quant="bf16" restates the build's mixed-precision mode (NOT the reference, which is float32): every GEMM
+    operand — weights, |l - r|, activations — rounded to bfloat16, products and sums in float32, biases untouched."""
+    q = bf16_round if quant == "bf16" else (lambda v: v)
     W1, b1, W2, b2, W3, b3 = [np.asarray(w, dtype) for w in ws]
-    d = np.abs(np.asarray(L, dtype) - np.asarray(R, dtype))
-    z1 = d @ W1 + b1
+    if quant:
+        W1, W2, W3 = q(W1), q(W2), q(W3)
+    d = q(np.abs(np.asarray(L, dtype) - np.asarray(R, dtype)))
+    z1 = q(d @ W1 + b1)                 # stored rounded: relu(q(z)) == q(relu(z))
     a1 = np.maximum(z1, 0)
-    z2 = a1 @ W2 + b2
+    z2 = q(a1 @ W2 + b2)
     a2 = np.maximum(z2, 0)
     z3 = a2 @ W3 + b3
     # Dense(2) + softmax (code/siamese.py:31-32) or Dense(1, sigmoid) (code/siamese3.py:25)
@@ -74,10 +88,13 @@ def loss_and_metrics(y, p, sw=None):
     return loss, acc
 
 
-def gradients(ws, L, R, y, sw=None, dtype=np.float32):
+def gradients(ws, L, R, y, sw=None, dtype=np.float32, quant=None):
+    q = bf16_round if quant == "bf16" else (lambda v: v)
     W1, b1, W2, b2, W3, b3 = [np.asarray(w, dtype) for w in ws]
+    if quant:
+        W1, W2, W3 = q(W1), q(W2), q(W3)
     y = np.asarray(y, dtype)
-    p, (d, z1, a1, z2, a2) = forward(ws, L, R, dtype, cache=True)
+    p, (d, z1, a1, z2, a2) = forward(ws, L, R, dtype, cache=True, quant=quant)
     n = len(y)
     w = np.ones(n, dtype) if sw is None else np.asarray(sw, dtype)
     denom = (w != 0).sum()
@@ -87,10 +104,11 @@ def gradients(ws, L, R, y, sw=None, dtype=np.float32):
     od = p.shape[1]
     dp = np.where(inside, (pc - y) / (pc * (1 - pc)) / dtype(od), 0) * (w / denom)[:, None]
     dz3 = p * (dp - (dp * p).sum(axis=1, keepdims=True)) if od > 1 else dp * p * (1 - p)
+    dz3 = q(dz3.astype(dtype))          # activation gradients are GEMM operands too: rounded where produced
     gW3, gb3 = a2.T @ dz3, dz3.sum(axis=0)
-    dz2 = (dz3 @ W3.T) * (z2 > 0)
+    dz2 = q(((dz3 @ W3.T) * (z2 > 0)).astype(dtype))
     gW2, gb2 = a1.T @ dz2, dz2.sum(axis=0)
-    dz1 = (dz2 @ W2.T) * (z1 > 0)
+    dz1 = q(((dz2 @ W2.T) * (z1 > 0)).astype(dtype))
     gW1, gb1 = d.T @ dz1, dz1.sum(axis=0)
     loss, acc = loss_and_metrics(y, p, sw)
     return [gW1, gb1, gW2, gb2, gW3, gb3], loss, acc
@@ -118,8 +136,10 @@ class Adadelta(object):
 class HeadModel(object):
     """The slice of keras.models.Model used on `siamese_net`."""
 
-    def __init__(self, d_in, h1=512, h2=64, lr=1.0, rho=0.95, epsilon=1e-8, seed=0, dtype=np.float32, out_dim=2):
+    def __init__(self, d_in, h1=512, h2=64, lr=1.0, rho=0.95, epsilon=1e-8, seed=0, dtype=np.float32, out_dim=2,
+                 quant=None):
         self.dtype = dtype
+        self.quant = quant              # "bf16": the build's mixed-precision mode (master weights / Adadelta stay float32)
         self.ws = [w.astype(dtype) for w in init_weights(d_in, h1, h2, seed, out_dim)]
         self.opt = Adadelta([w.shape for w in self.ws], lr, rho, epsilon, dtype)
         self.stop_training = False
@@ -137,18 +157,18 @@ class HeadModel(object):
         self.opt.lr = self.dtype(lr)
 
     def predict(self, X, batch_size=1024):
-        return forward(self.ws, X[0], X[1], self.dtype)
+        return forward(self.ws, X[0], X[1], self.dtype, quant=self.quant)
 
     def train_on_batch(self, x, y, class_weight=None, sample_weight=None):
         sw = sample_weight
         if sw is None and class_weight is not None:
             sw = np.asarray([class_weight[c] for c in np.asarray(y).argmax(axis=1)], self.dtype)
-        gs, loss, acc = gradients(self.ws, x[0], x[1], y, sw, self.dtype)
+        gs, loss, acc = gradients(self.ws, x[0], x[1], y, sw, self.dtype, quant=self.quant)
         self.ws = self.opt.step(self.ws, gs)
         return [float(loss), float(acc)]
 
     def test_on_batch(self, x, y):
-        p = forward(self.ws, x[0], x[1], self.dtype)
+        p = forward(self.ws, x[0], x[1], self.dtype, quant=self.quant)
         loss, acc = loss_and_metrics(np.asarray(y, self.dtype), p)
         return [float(loss), float(acc)]
 

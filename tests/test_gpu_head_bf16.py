@@ -1,0 +1,133 @@
+"""GPU: the pair head's bf16 compute mode (alink_head_set_compute_dtype: BASELINE configs[4]'s "bf16 fine-tune" —
+f32 master weights, gradients and Adadelta state; bf16 GEMM operands) against
+  (a) the oracle restating exactly that arithmetic (oracle.siamese_head quant="bf16": same rounding points, products
+      and sums in float32) — tight, and
+  (b) the float32 oracle, i.e. what the reference's Keras model computes (code/siamese.py:27-35,52-58) — with the
+      STATED tolerance of the mode: after 10 fine-tune steps at batch 16, |d loss| <= 2e-3 and max |d weight| <= 2e-3
+      (measured ~1e-4 and ~4e-4), probabilities within 1e-2."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(n, d, seed):
+    rs = np.random.RandomState(seed)
+    return rs.randn(n, d).astype(np.float32), rs.randn(n, d).astype(np.float32)
+
+
+def _pair(d_in=512, lr=0.1, seed=3, out_dim=2):
+    from a_link_amd.head import DenseHead
+    from oracle import siamese_head as O
+    g = DenseHead(d_in, lr=lr, seed=seed, out_dim=out_dim, compute_dtype="bf16")
+    oq = O.HeadModel(d_in, lr=lr, out_dim=out_dim, quant="bf16")
+    of = O.HeadModel(d_in, lr=lr, out_dim=out_dim)
+    ws = g.get_weights()
+    ws = [w + (0.05 * np.random.RandomState(9).randn(*w.shape).astype(np.float32) if w.ndim == 1 else 0) for w in ws]
+    g.set_weights(ws)
+    oq.set_weights(ws)
+    of.set_weights(ws)
+    return g, oq, of
+
+
+@pytest.mark.parametrize("d_in,n", [(512, 16), (512, 32), (512, 64), (2048, 16), (512, 700)])
+def test_bf16_train_steps_match_the_bf16_oracle(gpu, d_in, n):
+    """batch <= 32: the three-launch step reading the 2-byte weights; larger: the generic chain on their widened
+    image; both must be the arithmetic the oracle restates."""
+    from oracle import siamese_head as O
+    g, oq, of = _pair(d_in)
+    L, R = _data(n, d_in, 1)
+    rs = np.random.RandomState(2)
+    for step in range(10):
+        y = O.to_categorical(rs.randint(0, 2, n))
+        cw = {0: 0.3, 1: 0.7} if step % 2 else None
+        mg = g.train_on_batch([L, R], y, class_weight=cw)
+        mq = oq.train_on_batch([L, R], y, class_weight=cw)
+        assert abs(mg[0] - mq[0]) < 5e-5 and abs(mg[1] - mq[1]) < 1e-6, (step, mg, mq)
+    for a, b in zip(g.get_weights(), oq.get_weights()):
+        # a GEMM operand whose float32 value sits on a bf16 rounding boundary may round the other way (summation
+        # order): one bf16 ulp on one operand; through Adadelta's normalised step that is < 1e-4 on a weight
+        assert np.abs(a - b).max() < 1e-4
+    pg = g.predict([L, R])
+    np.testing.assert_allclose(pg, oq.predict([L, R]), atol=2e-4)
+    eg, eq = g.test_on_batch([L, R], y), oq.test_on_batch([L, R], y)
+    assert abs(eg[0] - eq[0]) < 5e-5 and eg[1] == eq[1]
+
+
+def test_bf16_finetune_stated_tolerance_vs_f32_reference_arithmetic(gpu, capsys):
+    from oracle import siamese_head as O
+    g, oq, of = _pair(512)
+    L, R = _data(16, 512, 4)
+    rs = np.random.RandomState(5)
+    dl = 0.0
+    for step in range(10):
+        y = O.to_categorical(rs.randint(0, 2, 16))
+        mg = g.train_on_batch([L, R], y)
+        mf = of.train_on_batch([L, R], y)
+        dl = max(dl, abs(mg[0] - mf[0]))
+    dw = max(np.abs(a - b).max() for a, b in zip(g.get_weights(), of.get_weights()))
+    dp = np.abs(g.predict([L, R]) - of.predict([L, R])).max()
+    with capsys.disabled():
+        print("\n[bf16 fine-tune vs float32 oracle, 10 steps, batch 16] max |d loss| %.2e  max |d weight| %.2e  max |d p| %.2e" % (dl, dw, dp))
+    assert dl <= 2e-3 and dw <= 2e-3 and dp <= 1e-2
+
+
+def test_bf16_predict_index_gather_and_committee(gpu):
+    from a_link_amd import committee, siamese
+    from oracle import al_logic as OA
+    from oracle import siamese_head as O
+    rs = np.random.RandomState(0)
+    E = rs.randn(300, 512).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    li = rs.randint(0, 300, 5000).astype(np.int32)
+    ri = rs.randint(0, 300, 5000).astype(np.int32)
+    nets = [siamese.SiameseNetwork((512,), "b%d" % i, 0.1, seed=i, compute_dtype="bf16") for i in range(3)]
+    refs = []
+    for nnet in nets:
+        o = O.HeadModel(512, quant="bf16")
+        o.set_weights(nnet.siamese_net.get_weights())
+        refs.append(o.predict([E[li], E[ri]]))
+    got = committee.Bagging(nets, []).predict_indexed(E, E, li, ri).cpu().numpy()
+    np.testing.assert_allclose(got, OA.bagging_predict(refs), atol=1e-4)
+
+
+def test_masters_stay_f32_and_mode_switch(gpu):
+    from a_link_amd.head import DenseHead
+    from oracle import siamese_head as O
+    g = DenseHead(512, lr=0.1, seed=7, compute_dtype="bf16")
+    ws = g.get_weights()
+    assert any(not np.array_equal(w, O.bf16_round(w)) for w in ws)         # what comes back is the f32 master
+    L, R = _data(16, 512, 8)
+    y = O.to_categorical(np.random.RandomState(1).randint(0, 2, 16))
+    f = DenseHead(512, lr=0.1, seed=7)
+    f.set_weights(ws)
+    g.set_compute_dtype("f32")
+    assert np.array_equal(g.predict([L, R]), f.predict([L, R]))            # back in f32: bit-equal to an f32 head
+    assert g.train_on_batch([L, R], y) == f.train_on_batch([L, R], y)
+    g.set_compute_dtype("bf16")
+    o = O.HeadModel(512, lr=0.1, quant="bf16")
+    o.set_weights(g.get_weights())
+    o.opt.a = [a.copy() for a in _adadelta_state(f)[0]]
+    o.opt.d = [d.copy() for d in _adadelta_state(f)[1]]
+    mg, mo = g.train_on_batch([L, R], y), o.train_on_batch([L, R], y)
+    assert abs(mg[0] - mo[0]) < 5e-5
+    gt = g.grads_tensor()
+    assert gt.dtype == torch.float32 and gt.numel() == 295618               # the all-reduce buffer stays f32
+
+
+def _adadelta_state(head):
+    """Adadelta accumulators after ONE step from zero state, recomputed from the gradient buffer:
+    a = (1 - rho) g^2, d = (1 - rho) u^2 with u = g sqrt(eps) / sqrt(a + eps)."""
+    g = head.grads_tensor().cpu().numpy().astype(np.float32)
+    rho, eps = np.float32(0.95), np.float32(1e-8)
+    a = (np.float32(1) - rho) * g * g
+    u = g * np.sqrt(eps) / np.sqrt(a + eps)
+    d = (np.float32(1) - rho) * u * u
+    out_a, out_d, o = [], [], 0
+    for s in head._shapes():
+        n = int(np.prod(s))
+        out_a.append(a[o:o + n].reshape(s))
+        out_d.append(d[o:o + n].reshape(s))
+        o += n
+    return out_a, out_d
