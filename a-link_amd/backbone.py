@@ -34,16 +34,39 @@ class IRBackbone(object):
         cfg.widths[:] = list(widths)
         cfg.height, cfg.width = int(image_size[0]), int(image_size[1])
         cfg.emb = emb
-        cfg.dtype = {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16}[dtype]
         cfg.bn_eps = float(bn_eps)
-        self.dtype = dtype
-        with _abi.on_device(device):                  # the handle lives on the device current at create
+        self.grad_enabled = bool(enable_grad)
+        # dtype "auto": float16 storage (11 significant bits: 1 - cos ~4e-6 against the f32 arithmetic at IR-100 depth,
+        # and selection sets that follow it: DESIGN.md §5) when the network's activations fit its range, else bfloat16
+        # (8 significant bits, f32's range: 1 - cos ~3e-4).  The range is probed on three images at build time (uniform
+        # noise, all 0, all 255); later inputs that leave it raise AlinkError in embed (never NaN embeddings).
+        order = ["f16", "bf16"] if dtype == "auto" else [dtype]
+        for dt in order:
+            cfg.dtype = {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16}[dt]
+            self.dtype = dt
+            self._build(cfg, params, small_batch_split, enable_grad)
+            if dtype != "auto" or dt == "bf16" or self._range_probe_ok():
+                break
+            self.lib.alink_backbone_destroy(self.h)
+            self.h = None
+            self._ws = {}
+        _abi.check(self.lib.alink_backbone_set_streams(self.h, int(shards_per_call)), "alink_backbone_set_streams")
+        # Inputs larger than max_batch are cut into max_batch-image chunks issued round-robin on
+        # `streams` side streams (each with its own workspace) and joined once at the end: chunks are
+        # independent, and de-synchronising them lets the HBM bursts of one chunk's tiles overlap the
+        # matrix-core phases of the others (+8...10 % measured on r100).
+        self.n_streams = max(1, int(streams))
+        self._side = None
+        self._upload = None
+        self._ws = {}
+
+    def _build(self, cfg, params, small_batch_split, enable_grad):
+        with _abi.on_device(self.device):             # the handle lives on the device current at create
             self.h = self.lib.alink_backbone_create(C.byref(cfg))
         if not self.h:
             raise _abi.AlinkError("alink_backbone_create: " + self.lib.alink_last_error().decode())
         if small_batch_split:      # latency mode: batches <= 32 split their convolutions over K (not bit-equal to fused)
             _abi.check(self.lib.alink_backbone_set_small_batch_split(self.h, 1), "alink_backbone_set_small_batch_split")
-        self.grad_enabled = bool(enable_grad)
         if enable_grad:
             _abi.check(self.lib.alink_backbone_enable_grad(self.h), "alink_backbone_enable_grad")
         n = self.lib.alink_backbone_num_tensors(self.h)
@@ -56,15 +79,18 @@ class IRBackbone(object):
             a = np.ascontiguousarray(params[key], dtype=np.float32)
             _abi.check(self.lib.alink_backbone_load(self.h, name.value, _abi.ptr(a), a.size), "load " + key)
         _abi.check(self.lib.alink_backbone_finalize(self.h), "alink_backbone_finalize")
-        _abi.check(self.lib.alink_backbone_set_streams(self.h, int(shards_per_call)), "alink_backbone_set_streams")
-        # Inputs larger than max_batch are cut into max_batch-image chunks issued round-robin on
-        # `streams` side streams (each with its own workspace) and joined once at the end: chunks are
-        # independent, and de-synchronising them lets the HBM bursts of one chunk's tiles overlap the
-        # matrix-core phases of the others (+8...10 % measured on r100).
-        self.n_streams = max(1, int(streams))
-        self._side = None
-        self._upload = None
-        self._ws = {}
+
+    def _range_probe_ok(self):
+        torch = self.torch
+        h, w = self.image_size
+        g = torch.Generator(device="cpu").manual_seed(0)
+        x = torch.stack([torch.randint(0, 256, (h, w, 3), generator=g).float(), torch.zeros(h, w, 3),
+                         torch.full((h, w, 3), 255.0)]).to("cuda:%d" % self.device)
+        saved, self.dtype = self.dtype, "probe"       # _checked must not raise here
+        self._ws, self._side, self._upload, self.n_streams = {}, None, None, 1
+        out = self.embed_device(x)
+        self.dtype = saved
+        return bool(torch.isfinite(out).all())
 
     def __del__(self):
         try:

@@ -52,9 +52,15 @@ def main():
                     "14-wide linear-tile kernel for the chip's 512 slots, 1022 for 1024 at 28 wide (chunks of a step are "
                     "issued round-robin on --streams streams)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--weights", default="survey", choices=["survey", "normalized"], help="survey: the SURVEY §8d draw (BatchNorm "
+                    "statistics random: activations grow to ~1e8, bf16 only); normalized: the same draw with BatchNorm statistics "
+                    "matching the activations like a trained checkpoint's (a-link_amd/weights.py) — float16 storage works there")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"], help="pixel type resident in HBM")
     ap.add_argument("--streams", type=int, default=4, help="streams the chunks of one step are spread over")
     ap.add_argument("--linear", type=int, default=-1, help="A/B: widths on linear pixel tiles (bit0 56, bit1 28, bit2 14, bit3 7)")
+    ap.add_argument("--shards", type=int, default=1, help="A/B: image shards one alink_embed call is split into on the "
+                    "library's internal streams (alink_backbone_set_streams)")
+    ap.add_argument("--fine-max", type=int, default=-1, help="A/B: largest 128-channel grid that still takes the 64-channel form")
     ap.add_argument("--config3", action="store_true", help="also time the config-3 leg (3 x IR-50 committee over a pool shard) "
                     "at N = 1; under torch.distributed.run it always runs")
     ap.add_argument("--config3-shard", type=int, default=2336, help="pool images per GPU in the config-3 leg")
@@ -85,10 +91,13 @@ def main():
     if args.linear >= 0:
         from a_link_amd import _abi
         _abi.load().alink_debug_set_linear(args.linear)
+    if args.fine_max >= 0:
+        from a_link_amd import _abi
+        _abi.load().alink_debug_set_fine_max(args.fine_max)
     units = W.ARCH_UNITS[args.model]
-    params = W.synthetic_ir_params(units, seed=1)
+    params = W.synthetic_ir_params(units, seed=1, normalized=args.weights == "normalized")
     bb = IRBackbone(params, image_size=(112, 112), dtype=args.dtype, device=local_rank, max_batch=args.chunk,
-                    streams=args.streams)
+                    streams=args.streams, shards_per_call=args.shards)
     del params
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(rank)           # rank 0 == seed 0
@@ -135,7 +144,7 @@ def main():
         "config": {"workload": "LResNet%sE-IR embed, %d x 3x112x112 images per step per GPU (as %d-image launches "
                                "round-robin on %d streams), %s pixels resident in HBM"
                                % (args.model[1:], B, args.chunk, args.streams, args.input),
-                   "arch": args.model, "units": list(units), "batch_per_gpu": B, "global_batch": B * world,
+                   "arch": args.model, "weights": args.weights, "units": list(units), "batch_per_gpu": B, "global_batch": B * world,
                    "gflop_per_embedding": gflop_per_emb, "sharding": "images (dp%d), no collective" % world,
                    "images_per_launch": args.chunk, "intra_gpu_streams": args.streams},
         "tflops_end_to_end": emb_per_s * gflop_per_emb / 1e3,
@@ -321,7 +330,7 @@ def main():
         # ---- CPU baseline: the oracle (kind "port": our CPU restatement; the reference's MXNet /
         # Keras path cannot be installed) on a bounded sample of the same workload, four legs
         from oracle import siamese_head as OH
-        params = W.synthetic_ir_params(units, seed=1)
+        params = W.synthetic_ir_params(units, seed=1, normalized=args.weights == "normalized")
         cores = torch.get_num_threads()
         xs = x[:8].float().cpu().numpy()  # bounded sample of the same pixels
         t1 = time.perf_counter()

@@ -269,3 +269,24 @@ def test_parity_on_calibrated_weights(gpu, capsys, arch, dtype):
         print("\n[calibrated %s %s] 1-cos max %.2e (calibration-like images %.2e, uniform-noise images %.2e), "
               "max |activation| %.0f" % (arch, dtype, d.max(), d[:4].max(), d[4:].max(), calibrate.activation_range(params, x[:2])))
     assert d.max() < (2e-4 if dtype == "f16" else COS_TOL), d
+
+
+def test_normalized_synthetic_weights_f16_and_auto_dtype(gpu, capsys):
+    """weights.synthetic_ir_params(normalized=True): the SURVEY §8d draw with BatchNorm statistics set (closed-form
+    moment propagation, product side, no data) to match the activations — IR-100 then stays inside float16.
+    dtype="auto" picks f16 there and bf16 for the un-normalised draw (whose activations reach ~1e8)."""
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import ir_resnet
+    x = _pixels(4, (112, 112), seed=0)
+    pn = W.synthetic_ir_params(W.R100_UNITS, seed=1, normalized=True)
+    ref = ir_resnet.embed(pn, x, batch=4)
+    auto = IRBackbone(pn, dtype="auto", max_batch=4)
+    assert auto.dtype == "f16"
+    d16 = _cos_dist(auto.embed(x), ref)
+    dbf = _cos_dist(IRBackbone(pn, dtype="bf16", max_batch=4).embed(x), ref)
+    with capsys.disabled():
+        print("\n[normalized r100] 1-cos max: f16 %.2e, bf16 %.2e" % (d16.max(), dbf.max()))
+    assert d16.max() < 2e-5 and dbf.max() < COS_TOL
+    ps = W.synthetic_ir_params(W.R100_UNITS, seed=1)
+    assert IRBackbone(ps, dtype="auto", max_batch=4).dtype == "bf16"
