@@ -14,7 +14,7 @@ from . import weights as W
 
 class IRBackbone(object):
     def __init__(self, params, image_size=(112, 112), emb=512, dtype="bf16", device=None, max_batch=292,
-                 widths=W.WIDTHS, streams=4, shards_per_call=1, bn_eps=2e-5, enable_grad=False,
+                 widths=W.WIDTHS, streams=4, shards_per_call=None, bn_eps=2e-5, enable_grad=False,
                  small_batch_split=False):
         import torch
         self.torch = torch
@@ -40,6 +40,7 @@ class IRBackbone(object):
         # and selection sets that follow it: DESIGN.md §5) when the network's activations fit its range, else bfloat16
         # (8 significant bits, f32's range: 1 - cos ~3e-4).  The range is probed on three images at build time (uniform
         # noise, all 0, all 255); later inputs that leave it raise AlinkError in embed (never NaN embeddings).
+        self._shards_fixed = None if shards_per_call is None else int(shards_per_call)
         order = ["f16", "bf16"] if dtype == "auto" else [dtype]
         for dt in order:
             cfg.dtype = {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16}[dt]
@@ -50,7 +51,11 @@ class IRBackbone(object):
             self.lib.alink_backbone_destroy(self.h)
             self.h = None
             self._ws = {}
-        _abi.check(self.lib.alink_backbone_set_streams(self.h, int(shards_per_call)), "alink_backbone_set_streams")
+        # shards_per_call: image shards ONE alink_embed call is split into on the library's internal streams.  None
+        # (default) = 2 for a call that is alone on its stream and has >= 192 images — two half-launches de-phase each
+        # other's prologue / epilogue bursts: IR-50, one 256-image batch per step 65.9k -> 72.0k embeddings/s, IR-100 at
+        # 292 images +1.5 % — and 1 for the chunks of a multi-stream call, which already overlap (sharding those costs 11 %).
+        self._set_shards(self._shards_fixed or 1)
         # Inputs larger than max_batch are cut into max_batch-image chunks issued round-robin on
         # `streams` side streams (each with its own workspace) and joined once at the end: chunks are
         # independent, and de-synchronising them lets the HBM bursts of one chunk's tiles overlap the
@@ -79,6 +84,7 @@ class IRBackbone(object):
             a = np.ascontiguousarray(params[key], dtype=np.float32)
             _abi.check(self.lib.alink_backbone_load(self.h, name.value, _abi.ptr(a), a.size), "load " + key)
         _abi.check(self.lib.alink_backbone_finalize(self.h), "alink_backbone_finalize")
+        self._shards_now = None                       # a new handle: its shard count is not set yet
 
     def _range_probe_ok(self):
         torch = self.torch
@@ -91,6 +97,11 @@ class IRBackbone(object):
         out = self.embed_device(x)
         self.dtype = saved
         return bool(torch.isfinite(out).all())
+
+    def _set_shards(self, n):
+        if n != self._shards_now:
+            _abi.check(self.lib.alink_backbone_set_streams(self.h, int(n)), "alink_backbone_set_streams")
+            self._shards_now = n
 
     def __del__(self):
         try:
@@ -144,6 +155,7 @@ class IRBackbone(object):
             st = _abi.current_stream(self.device)
             for i in range(0, n, self.max_batch):
                 m = min(self.max_batch, n - i)
+                self._set_shards(self._shards_fixed or (2 if m >= 192 else 1))
                 ws, wsb = self._workspace(m)
                 _abi.check(self.lib.alink_embed(self.h, _abi.ptr(x[i:i + m]), layout, m, _abi.ptr(out[i:i + m]),
                                                 C.c_void_p(ws), wsb, st), "alink_embed")
@@ -154,6 +166,7 @@ class IRBackbone(object):
         ready = torch.cuda.Event()
         ready.record(cur)                       # inputs (and `out`) are valid in caller-stream order
         used = min(self.n_streams, nchunks)
+        self._set_shards(self._shards_fixed or 1)
         for s in self._side[:used]:
             s.wait_event(ready)
         for j, i in enumerate(range(0, n, self.max_batch)):

@@ -85,6 +85,7 @@ struct ConvParams {
     int post_relu;        // ReLU after the residual add (bottleneck units: relu(conv + bias + shortcut))
     int fine;             // linear-tile kernel: 1 = 64-channel workgroups instead of 128 (small batches: twice the
                           // workgroups, same weights, bit-identical sums)
+    int stagger;          // linear-tile kernel: the workgroup in the CU's second wave slot starts this many x 1024 cycles late
     int ablate;           // diagnostic timing-only modes of conv3x3_direct (0 = normal)
     void* stamps;         // diagnostic: 4 x u64 s_memtime stamps per workgroup, or nullptr
 };

@@ -645,6 +645,8 @@ static int plan_split(const alink_backbone* bb, const ConvLayer& L, int N) {
 int g_fine_max = 384;     // measured (r100, one launch at a time): the 64-channel form wins while the 128-channel grid fills < 3/4 of the 512 slots
 extern "C" void alink_debug_set_fine_max(int n) { g_fine_max = n; }
 int g_ablate = 0;
+int g_stagger = 0;
+extern "C" void alink_debug_set_stagger(int n) { g_stagger = n < 0 ? 0 : n; }
 void* g_stamps = nullptr;
 // alink_embed_profile launches every kernel of the chain this many times back to back between its two
 // events (all launches are idempotent: no kernel writes a buffer it reads) and reports the mean, so
@@ -715,6 +717,7 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         p.border_cls = L.border_cls ? 1 : 0; p.splitk = 1;
         p.ksteps_per_split = L.ksz * L.ksz * (L.Cin / 64);
         p.ablate = g_ablate;
+        p.stagger = g_stagger;
         // few images (128-channel grid under 3/4 of the chip, g_fine_max): those workgroups cover only part of the chip and
         // each walks all of K alone on its CU; the 64-channel form doubles their number and halves a K-step
         // (bit-identical results: same weights, same summation order per output)

@@ -92,6 +92,17 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wpx = wave >> 1, wco = wave & 1;
+    if (p.stagger > 0) {
+        // Two workgroups share a CU, one wave each per SIMD.  In a launch that fills every slot at once they run in
+        // lockstep: the same K-step, the same barrier, the same input refill and the same epilogue at the same time, so
+        // nothing of one covers the other's waits.  The workgroup whose first wave sits in an odd wave slot of its SIMD
+        // (HW_ID.WAVE_ID) starts late by `stagger` x 1024 cycles; the K-step barriers then keep the offset.
+        __shared__ int s_late;
+        if (tid == 0) s_late = (int)(__builtin_amdgcn_s_getreg(6148) & 1u);       // hwreg(HW_REG_HW_ID, 0, 4) = WAVE_ID
+        __syncthreads();
+        if (s_late)
+            for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     const int q = lane >> 4, lr = lane & 15;
     const int H = p.H, Cin = p.Cin;
     // split mode (small batches: too few workgroups to fill the chip): blockIdx.y owns ncc / splitk of the

@@ -58,9 +58,10 @@ def main():
     ap.add_argument("--input", default="f32", choices=["f32", "u8"], help="pixel type resident in HBM")
     ap.add_argument("--streams", type=int, default=4, help="streams the chunks of one step are spread over")
     ap.add_argument("--linear", type=int, default=-1, help="A/B: widths on linear pixel tiles (bit0 56, bit1 28, bit2 14, bit3 7)")
-    ap.add_argument("--shards", type=int, default=1, help="A/B: image shards one alink_embed call is split into on the "
+    ap.add_argument("--shards", type=int, default=0, help="A/B: image shards one alink_embed call is split into on the "
                     "library's internal streams (alink_backbone_set_streams)")
     ap.add_argument("--fine-max", type=int, default=-1, help="A/B: largest 128-channel grid that still takes the 64-channel form")
+    ap.add_argument("--stagger", type=int, default=-1, help="A/B: start delay (x 1024 cycles) of the second workgroup on a CU in the linear-tile kernel")
     ap.add_argument("--config3", action="store_true", help="also time the config-3 leg (3 x IR-50 committee over a pool shard) "
                     "at N = 1; under torch.distributed.run it always runs")
     ap.add_argument("--config3-shard", type=int, default=2336, help="pool images per GPU in the config-3 leg")
@@ -91,13 +92,16 @@ def main():
     if args.linear >= 0:
         from a_link_amd import _abi
         _abi.load().alink_debug_set_linear(args.linear)
+    if args.stagger >= 0:
+        from a_link_amd import _abi
+        _abi.load().alink_debug_set_stagger(args.stagger)
     if args.fine_max >= 0:
         from a_link_amd import _abi
         _abi.load().alink_debug_set_fine_max(args.fine_max)
     units = W.ARCH_UNITS[args.model]
     params = W.synthetic_ir_params(units, seed=1, normalized=args.weights == "normalized")
     bb = IRBackbone(params, image_size=(112, 112), dtype=args.dtype, device=local_rank, max_batch=args.chunk,
-                    streams=args.streams, shards_per_call=args.shards)
+                    streams=args.streams, shards_per_call=args.shards or None)
     del params
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(rank)           # rank 0 == seed 0
