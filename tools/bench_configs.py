@@ -33,39 +33,26 @@ def sync_time(fn, reps=1):
 
 
 def config3(pool_n, out):
-    import numpy as np
+    """The product path bench.py times under torchrun (distributed.committee_pool_topk), at the full per-GPU shard."""
     import torch
-    from a_link_amd import committee, siamese, uncertainty as U
+    from a_link_amd import distributed as D, siamese
     members = [siamese.ArcFace((112, 112), "synthetic:r50:%d" % s) for s in (1, 2, 3)]
     heads = [siamese.SiameseNetwork((512,), "h%d" % i, 0.1, seed=i) for i in range(3)]
-    bag = committee.Bagging(heads, [])
     g = torch.Generator().manual_seed(0)
     pool = torch.randint(0, 256, (pool_n, 112, 112, 3), generator=g, dtype=torch.uint8).cuda()
-    gallery = pool[:16]
-    li = torch.arange(pool_n, dtype=torch.int32).repeat_interleave(16).cuda()
-    ri = torch.arange(16, dtype=torch.int32).repeat(pool_n).cuda()
+    gallery = torch.randint(0, 256, (16, 112, 112, 3), generator=g, dtype=torch.uint8).cuda()
+    bbs = [m.model.model for m in members]
+    hds = [h.siamese_net for h in heads]
 
     def run():
-        probs = None
-        embs = []
-        for m in members:                                   # every member embeds the shard (no model parallelism)
-            bb = m.model.model
-            embs.append((bb.embed_device(pool), bb.embed_device(gallery)))
-        # each head scores its own backbone's embeddings; committee mean (code/committee.py:13-20)
-        for h, (ep, eg) in zip(heads, embs):
-            p = h.siamese_net.predict_device(ep, eg, li, ri)
-            probs = p if probs is None else probs + p
-        probs = probs / len(heads)
-        ent = U.score_device(probs, "entropy")
-        idx, vals = U.topk_device(ent, 1024, largest=True)
-        return probs, idx
+        return D.committee_pool_topk(bbs, hds, pool, gallery, 1024, shard_offset=0)
     run()
-    dt, (probs, idx) = sync_time(run, 2)
-    assert bool(torch.isfinite(probs).all()) and idx.numel() == 1024
+    dt, (vals, idx) = sync_time(run, 2)
+    assert bool(torch.isfinite(vals).all()) and idx.numel() == 1024
     out["config3_committee_pool_shard"] = {
         "pool_images_per_gpu": pool_n, "members": 3, "arch": "r50", "gallery": 16, "pairs": pool_n * 16, "s": dt,
         "pool_images_per_s": pool_n / dt, "backbone_forwards_per_s": 3 * (pool_n + 16) / dt}
-    del members, heads, bag
+    del members, heads
 
 
 def _people(n, k, seed):
@@ -74,12 +61,12 @@ def _people(n, k, seed):
     return [rng.randint(0, 256, (k, 112, 112, 3)).astype(np.float32) for _ in range(n)]
 
 
-def config4(out, noises):
+def config4(out, noises, student_dtype="f32"):
     import numpy as np
     import torch
     from a_link_amd import alink_loop as AL, committee, noise, pairs, siamese
     conv = siamese.ArcFace((112, 112), "synthetic:r100")
-    student = siamese.SiameseNetwork((512,), "/tmp/alink_student", 0.1, seed=1)
+    student = siamese.SiameseNetwork((512,), "/tmp/alink_student", 0.1, seed=1, compute_dtype=student_dtype)
     ens = [siamese.SiameseNetwork((512,), "e1", 0.1, seed=2)]
     np.random.seed(0)                                    # the noise objects draw their Philox seeds at construction
     nz = [noise.get_relevant_noise(n)(model=student, sess=None, feature_model=conv) for n in noises]
@@ -97,8 +84,8 @@ def config4(out, noises):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
     P = st.un_size
-    out["config4_alink_iteration_r100"] = {
-        "persons": 16, "unique_images": 80, "pairs": P, "noises": list(noises), "s": dt,
+    out["config4_alink_iteration_r100" + ("" if student_dtype == "f32" else "_student_" + student_dtype)] = {
+        "student_compute_dtype": student_dtype, "persons": 16, "unique_images": 80, "pairs": P, "noises": list(noises), "s": dt,
         "backbone_forwards": 80 + 2 * P * len(noises), "backbone_forwards_per_s": (80 + 2 * P * len(noises)) / dt,
         "oracle_queries": st.active_count, "finetunes": st.finetunes,
         "reference_shape_forwards": 2 * P * (1 + len(noises))}
@@ -169,6 +156,9 @@ def main():
     conv = student = None
     if "4" not in a.skip:
         conv, student = config4(out, a.noises.split(","))
+        del conv, student
+        # configs[4]: the same iteration with the student fine-tuned in the head's bf16 compute mode
+        conv, student = config4(out, a.noises.split(","), student_dtype="bf16")
     if "5" not in a.skip:
         if conv is None:
             from a_link_amd import siamese
