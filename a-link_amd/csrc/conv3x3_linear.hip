@@ -105,6 +105,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     }
     const int q = lane >> 4, lr = lane & 15;
     const int H = p.H, Cin = p.Cin;
+    // diagnostic (alink_debug_set_stamps; nullptr in every product call): 6 x u64 per workgroup — start, main loop
+    // entered, main loop left, end, cycles inside the input refills, number of refills
+    unsigned long long* const stamps = (unsigned long long*)p.stamps;
+    unsigned long long refill_cycles = 0;
+    if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 6 + 0] = __builtin_amdgcn_s_memtime();
     // split mode (small batches: too few workgroups to fill the chip): blockIdx.y owns ncc / splitk of the
     // 64-channel input chunks and leaves its f32 partial sums in slab blockIdx.y (conv_split_finish_kernel
     // adds the slabs in order and applies the epilogue)
@@ -150,6 +155,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
         wstep += 64;
     };
 
+    // The first input span and the first weight tile are requested NOW: the per-lane border bits (integer divisions),
+    // the accumulator clear and the bias / slope tables below all run under their flight instead of before it
+    // (stamps: the prologue of a 512-workgroup stage-3 launch took 9.0 k of the workgroup's 100 k cycles).
+    stage_x(cc_first);
+    stage_w(0);
+
     // ---- per-lane fragment offsets and border bits --------------------------------------------------------------
     const int dl = delta(lr);
     // operand offset of tap (ky, kx), lower K half (the upper half is ^ 64): position s = dl + ky W + kx,
@@ -185,9 +196,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     for (int i = tid; i < ncls * BN; i += NT) ebias[i] = p.bias[(i / BN) * p.Cout + n0 + (i % BN)];
     if (p.alpha)
         for (int i = tid; i < BN; i += NT) ealpha[i] = p.alpha[n0 + i];
-    stage_x(cc_first);
-    stage_w(0);
     wait_dma_then_barrier();
+    if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 6 + 1] = __builtin_amdgcn_s_memtime();
 
     int wtog = 0;
     for (int cc = 0; cc < ncc; ++cc) {
@@ -234,9 +244,16 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
         if (cc + 1 < ncc) {
             // single X buffer: every wave is past its last read of this chunk; refill and wait — the
             // co-resident workgroup keeps the matrix cores busy meanwhile
+            const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
             stage_x(cc_first + cc + 1);
             wait_dma_then_barrier();
+            if (stamps) refill_cycles += __builtin_amdgcn_s_memtime() - t0;
         }
+    }
+    if (stamps && tid == 0) {
+        stamps[(size_t)blockIdx.x * 6 + 2] = __builtin_amdgcn_s_memtime();
+        stamps[(size_t)blockIdx.x * 6 + 4] = refill_cycles;
+        stamps[(size_t)blockIdx.x * 6 + 5] = (unsigned long long)(ncc - 1);
     }
 
     // ---- epilogue (as conv3x3_direct: bias by border class, PReLU | PReLU', residual, 16-B stores) -----------
@@ -322,6 +339,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
                 *(vec8*)((T*)p.out + off[u] + chan_h(h)) = o8;
             }
         }
+    }
+    if (stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamps[(size_t)blockIdx.x * 6 + 3] = __builtin_amdgcn_s_memtime();
     }
 }
 
