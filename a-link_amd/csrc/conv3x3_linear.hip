@@ -105,11 +105,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     }
     const int q = lane >> 4, lr = lane & 15;
     const int H = p.H, Cin = p.Cin;
-    // diagnostic (alink_debug_set_stamps; nullptr in every product call): 6 x u64 per workgroup — start, main loop
-    // entered, main loop left, end, cycles inside the input refills, number of refills
+    // diagnostic (alink_debug_set_stamps; nullptr in every product call): 8 x u64 per workgroup — start, main loop
+    // entered, main loop left, end (stores drained), cycles inside the input refills, number of refills, residual
+    // loads returned, last store issued
     unsigned long long* const stamps = (unsigned long long*)p.stamps;
     unsigned long long refill_cycles = 0;
-    if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 6 + 0] = __builtin_amdgcn_s_memtime();
+    if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
     // split mode (small batches: too few workgroups to fill the chip): blockIdx.y owns ncc / splitk of the
     // 64-channel input chunks and leaves its f32 partial sums in slab blockIdx.y (conv_split_finish_kernel
     // adds the slabs in order and applies the epilogue)
@@ -171,9 +172,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     unsigned border = 0;
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
+        // all by the compile-time W: the maps are square (H == W is a launch condition) and a group starts on a row
+        // boundary (GPX % W == 0), so the group's first row is grp * (GPX / W).  (With the runtime H and the 64-bit
+        // pixel index this was ~130 instructions of integer division per tile: 5 k of the prologue's 9 k cycles.)
         const int pl = 16 * (wpx * TPW + u) + dl;
         const int col = pl % W;
-        const int y = (int)((gp0 / W + pl / W) % H);
+        const int y = (int)(((unsigned)grp * (unsigned)(GPX / W) + (unsigned)(pl / W)) % (unsigned)W);
         border |= ((y == 0 ? 1u : 0u) | (y == H - 1 ? 2u : 0u) | (col == 0 ? 4u : 0u) | (col == W - 1 ? 8u : 0u)) << (4 * u);
     }
     int wl[2];
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     if (p.alpha)
         for (int i = tid; i < BN; i += NT) ealpha[i] = p.alpha[n0 + i];
     wait_dma_then_barrier();
-    if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 6 + 1] = __builtin_amdgcn_s_memtime();
+    if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
 
     int wtog = 0;
     for (int cc = 0; cc < ncc; ++cc) {
@@ -251,9 +255,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
         }
     }
     if (stamps && tid == 0) {
-        stamps[(size_t)blockIdx.x * 6 + 2] = __builtin_amdgcn_s_memtime();
-        stamps[(size_t)blockIdx.x * 6 + 4] = refill_cycles;
-        stamps[(size_t)blockIdx.x * 6 + 5] = (unsigned long long)(ncc - 1);
+        stamps[(size_t)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
+        stamps[(size_t)blockIdx.x * 8 + 4] = refill_cycles;
+        stamps[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)(ncc - 1);
     }
 
     // ---- epilogue (as conv3x3_direct: bias by border class, PReLU | PReLU', residual, 16-B stores) -----------
@@ -293,6 +297,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
         for (int u = 0; u < TPW; ++u)
 #pragma unroll
             for (int h = 0; h < CPL / 8; ++h) res[u][h] = *(const vec8*)(extra + off[u] + chan_h(h));
+    }
+    if (stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime();
     }
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
@@ -341,8 +349,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
         }
     }
     if (stamps && tid == 0) {
+        stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamps[(size_t)blockIdx.x * 6 + 3] = __builtin_amdgcn_s_memtime();
+        stamps[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memtime();
     }
 }
 

@@ -65,3 +65,35 @@ def test_config3_leg_on_one_rank(rccl_group):
     # per-member matrices really are per member: a shared-embedding committee gives a different answer
     shared = committee.Bagging(nets, []).predict_indexed(Ep[0], Eg[0], li, ri)
     assert not torch.equal(shared, probs)
+
+
+def test_handles_live_on_their_own_device(gpu):
+    """Device rule of the C ABI (include/alink_hip.h): a handle lives on the device current at its create call, every
+    entry point switches to it for the call and back.  Needs two visible GPUs (a one-GPU box skips): models built
+    while device 1 is current run there and leave the caller's current device alone; ArcFace's gpu=None means "this
+    process's device", which is what rank 1 of a one-process-per-GPU job has set."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    from a_link_amd import siamese, weights as W
+    from a_link_amd.backbone import IRBackbone
+    from a_link_amd.head import DenseHead
+    size = (32, 32)
+    params = W.synthetic_ir_params((1, 1, 1, 1), size=size, seed=3)
+    x = np.random.default_rng(0).integers(0, 256, (5, 32, 32, 3)).astype(np.float32)
+    ref = IRBackbone(params, image_size=size, device=0, max_batch=8).embed(x)
+    with torch.cuda.device(1):
+        fm = siamese.ArcFace(size, "synthetic:r18:3", max_batch=8)           # gpu=None -> current device = 1
+        assert fm.model.model.device == 1
+        bb1 = IRBackbone(params, image_size=size, max_batch=8)
+        h1 = DenseHead(512, seed=1)
+    assert torch.cuda.current_device() == 0
+    bb1_from0 = IRBackbone(params, image_size=size, device=1, max_batch=8)      # explicit device while 0 is current
+    assert torch.cuda.current_device() == 0
+    for bb in (bb1, bb1_from0):
+        got = bb.embed_device(torch.from_numpy(x).to("cuda:1"))
+        assert got.device.index == 1 and np.array_equal(got.cpu().numpy(), ref)
+    assert torch.cuda.current_device() == 0
+    h0 = DenseHead(512, seed=1, device=0)
+    L = np.random.RandomState(0).randn(8, 512).astype(np.float32)
+    p1 = h1.predict([L, L[::-1].copy()])
+    assert np.array_equal(p1, h0.predict([L, L[::-1].copy()])) and torch.cuda.current_device() == 0

@@ -18,19 +18,21 @@ for name in sys.argv[1:] or ["s3", "s2", "s4", "s1"]:
     r = torch.randn(N, H, W, Co, device="cuda").bfloat16()
     out = torch.empty(N, H, W, Co, device="cuda", dtype=torch.bfloat16)
     nwg = 16384
-    st = torch.zeros(nwg * 6, dtype=torch.int64, device="cuda")
+    st = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
     for rep in range(3):
         lib.alink_debug_set_stamps(C.c_void_p(st.data_ptr()) if rep == 2 else None)
         _abi.check(lib.alink_conv_nhwc(0, _abi.ptr(x), _abi.ptr(w), _abi.ptr(b), None, _abi.ptr(r), _abi.ptr(out),
                                        N, H, W, Ci, Co, 3, 1, 1, 1, 0, None))
     lib.alink_debug_set_stamps(None)
-    s = st.cpu().numpy().reshape(-1, 6)
+    s = st.cpu().numpy().reshape(-1, 8)
     s = s[s[:, 0] != 0]
     d = np.diff(s[:, :4], axis=1).astype(np.float64)
     span = s[:, 3].max() - s[:, 0].min()
     print("%s: %d workgroups; median cycles: prologue %.0f | loop %.0f (of which %d refills %.0f) | epilogue %.0f | total %.0f ; launch span %.0f"
           % (name, len(s), np.median(d[:, 0]), np.median(d[:, 1]), int(np.median(s[:, 5])), np.median(s[:, 4]), np.median(d[:, 2]),
              np.median(d.sum(1)), span))
+    print("    epilogue split: loop end -> residual loads back %.0f | -> last store issued %.0f | -> stores drained %.0f"
+          % (np.median(s[:, 6] - s[:, 2]), np.median(s[:, 7] - s[:, 6]), np.median(s[:, 3] - s[:, 7])))
     print("    p10/p90: prologue %.0f/%.0f loop %.0f/%.0f epilogue %.0f/%.0f ; start spread %.0f ; end spread %.0f"
           % (np.percentile(d[:, 0], 10), np.percentile(d[:, 0], 90), np.percentile(d[:, 1], 10), np.percentile(d[:, 1], 90),
              np.percentile(d[:, 2], 10), np.percentile(d[:, 2], 90), s[:, 0].max() - s[:, 0].min(), s[:, 3].max() - s[:, 3].min()))
