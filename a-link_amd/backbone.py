@@ -43,7 +43,7 @@ class IRBackbone(object):
         self._shards_fixed = None if shards_per_call is None else int(shards_per_call)
         order = ["f16", "bf16"] if dtype == "auto" else [dtype]
         for dt in order:
-            cfg.dtype = {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16}[dt]
+            cfg.dtype = {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16, "f32": _abi.DT_F32}[dt]
             self.dtype = dt
             self._build(cfg, params, small_batch_split, enable_grad)
             if dtype != "auto" or dt == "bf16" or self._range_probe_ok():

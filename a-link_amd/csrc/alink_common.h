@@ -169,3 +169,16 @@ uint16_t f32_to_f16_rne(float f);
 int init_kernels();   // function attributes (dynamic LDS sizes)
 
 }  // namespace alink
+#include <map>
+#include <string>
+#include <vector>
+namespace alink {
+// backbone_f32.hip: the float32 precision mode of the IR backbone (alink_ir_cfg.dtype = ALINK_DT_F32)
+struct F32Net;
+F32Net* f32net_build(const std::map<std::string, std::vector<float>>& raw, const alink_ir_cfg& cfg);
+void    f32net_destroy(F32Net* n);
+size_t  f32net_workspace_bytes(const F32Net* n, int N);
+int     f32net_embed(const F32Net* n, const void* dev_in, int layout, int N, float* dev_out, void* ws, size_t ws_bytes,
+                     hipStream_t st);
+
+}  // namespace alink

@@ -120,6 +120,7 @@ struct alink_backbone {
     // input-gradient support
     bool grad = false;
     bool split_small = false;   // alink_backbone_set_small_batch_split
+    F32Net* f32 = nullptr;      // cfg.dtype == ALINK_DT_F32: the float32 precision mode (backbone_f32.hip) runs every call
     void*  d_fc_wb = nullptr;                                  // T [C*Hf*Wf][emb]: FC transposed (rows permuted)
     float* d_stem_wf = nullptr;                                // f32 [64][27] folded stem weights
     float* d_zero_bias = nullptr;                              // zeros, >= 9 * max width floats
@@ -135,6 +136,7 @@ struct alink_backbone {
     hipEvent_t ev_start = nullptr, ev_done[MAXSUB] = {};
 
     ~alink_backbone() {
+        if (f32) f32net_destroy(f32);
         for (void* p : allocs) (void)hipFree(p);
         for (int i = 0; i < MAXSUB; ++i) {
             if (sub[i]) (void)hipStreamDestroy(sub[i]);
@@ -290,7 +292,7 @@ alink_backbone_t* alink_backbone_create(const alink_ir_cfg* cfg) {
         set_error("input size %dx%d must be a multiple of 16 (four stride-2 stages)", cfg->height, cfg->width);
         return nullptr;
     }
-    if (cfg->dtype != ALINK_DT_BF16 && cfg->dtype != ALINK_DT_F16) { set_error("bad dtype"); return nullptr; }
+    if (cfg->dtype != ALINK_DT_BF16 && cfg->dtype != ALINK_DT_F16 && cfg->dtype != ALINK_DT_F32) { set_error("bad dtype"); return nullptr; }
     alink_backbone* bb = new alink_backbone();
     bb->device = current_device();
     bb->cfg = *cfg;
@@ -379,6 +381,14 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
     const alink_ir_cfg& cfg = bb->cfg;
     const int dt = cfg.dtype;
     const int* w = cfg.widths;
+    if (dt == ALINK_DT_F32) {      // float32 precision mode: its own (unfused-bn1, f32 GEMM) network, nothing of the bf16 path
+        ALINK_REQUIRE(!bb->grad && !bb->split_small, ALINK_ESTATE, "the float32 mode has no gradient pass and no small-batch split");
+        bb->f32 = f32net_build(bb->raw, cfg);
+        ALINK_REQUIRE(bb->f32, ALINK_ENOMEM, "could not build the float32 network (device memory)");
+        bb->raw.clear();
+        bb->finalized = true;
+        return ALINK_OK;
+    }
 
     // zero page
     ALINK_HIP(hipMalloc(&bb->d_zero, 4096));
@@ -598,6 +608,7 @@ static int split_plan(const alink_backbone* bb, int N, int counts[alink_backbone
 
 size_t alink_backbone_workspace_bytes(const alink_backbone_t* bb, int n_images) {
     if (!bb || !bb->finalized || n_images <= 0) return 0;
+    if (bb->f32) return f32net_workspace_bytes(bb->f32, n_images);
     size_t off[7], total, single;
     ws_layout(bb, n_images, off, &single);
     // any stream count up to MAXSUB may be selected later: take the worst case
@@ -780,6 +791,7 @@ int alink_embed(alink_backbone_t* bb, const void* dev_in, int layout, int n_imag
     DeviceGuard dg(bb->device);
     ALINK_REQUIRE(n_images > 0, ALINK_EINVAL, "n_images must be positive");
     ALINK_REQUIRE(layout >= 0 && layout <= 2, ALINK_EINVAL, "unknown pixel layout %d", layout);
+    if (bb->f32) return f32net_embed(bb->f32, dev_in, layout, n_images, dev_out, dev_workspace, workspace_bytes, (hipStream_t)stream);
     int counts[alink_backbone::MAXSUB];
     const int S = split_plan(bb, n_images, counts);
     hipStream_t st = (hipStream_t)stream;
@@ -815,6 +827,7 @@ int alink_embed_profile(alink_backbone_t* bb, const void* dev_in, int layout, in
                         int* kind, int* n_launches) {
     ALINK_REQUIRE(ms && flops && kind && n_launches && *n_launches > 0, ALINK_EINVAL, "NULL profile buffers");
     ALINK_REQUIRE(bb, ALINK_EINVAL, "NULL backbone");
+    ALINK_REQUIRE(!bb->f32, ALINK_ESTATE, "per-launch profiling is for the bf16 / f16 kernels, not the float32 mode");
     DeviceGuard dg(bb->device);
     return embed_impl(bb, dev_in, layout, n_images, dev_out, dev_workspace, workspace_bytes,
                       (hipStream_t)stream, ms, flops, kind, n_launches);

@@ -18,9 +18,13 @@ struct GemmP {
     // convolution geometry (A_CONV / A_CONVT): the gathered tensor is [n][H][W][Ci]; (Ho, Wo) are the
     // spatial dims of the OTHER side (output pixels for A_CONV, dz pixels for A_CONVT); 3x3 taps, `pad`
     int H, W, Ci, Ho, Wo, pad, prescale;
+    int ks, cstride;          // A_CONV only: kernel size 3 (0 = 3) or 1, and stride 1 (0 = 1) or 2 (the f32 backbone mode)
+    float pre_sub, pre_mul;   // prescale = 2: (x - pre_sub) * pre_mul on load instead of SmallRes' (x - 128) / 128
     // epilogue (applied by the kernel, or by the reduction when split): + bias[n], ReLU, mask act[m][n] > 0
     const float* bias;
     const float* act;
+    const float* alpha;       // per-column PReLU slopes applied after the bias: v > 0 ? v : v * alpha[n]
+    const float* resid;       // [M][ldc] added last (residual connection)
     int relu;
     int accumulate;           // C += result (after the epilogue terms) instead of C = result
     int splitk, kper;         // grid.z slabs of kper (multiple of 16) reduction steps

@@ -30,6 +30,7 @@ namespace {
 constexpr int BK = 16;
 
 __device__ __forceinline__ float prescale_px(float x) { return (x - 128.f) / 128.f; }
+__device__ __forceinline__ float prescale_px(float x, const GemmP& p) { return p.prescale == 2 ? (x - p.pre_sub) * p.pre_mul : (x - 128.f) / 128.f; }
 
 // WN = waves along N: 2 -> 64 x 64 tile (2 x 2 waves), 1 -> 128 x 32 tile (4 x 1 waves; layers with <= 32 outputs)
 template <int AMODE, int BMODE, int WN>
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
         cn = r / p.Ho;
     }
     const int Kc = 9 * p.Ci;   // im2col width (conv modes)
+    const int ks = p.ks ? p.ks : 3, cstr = p.cstride ? p.cstride : 1;      // A_CONV geometry (defaults: 3x3, stride 1)
 
     auto load_a = [&](int k0, int j, float v[4]) {
         v[0] = v[1] = v[2] = v[3] = 0.f;
@@ -91,21 +93,21 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
             if ((p.Ci & 3) == 0) {
                 if (k >= kend) return;
                 const int tap = k / p.Ci, ci = k - tap * p.Ci;
-                const int iy = coy + tap / 3 - p.pad, ix = cox + tap % 3 - p.pad;
+                const int iy = coy * cstr + tap / ks - p.pad, ix = cox * cstr + tap % ks - p.pad;
                 if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
                     const f32x4 t = *(const f32x4*)(p.A + (((size_t)cn * p.H + iy) * p.W + ix) * p.Ci + ci);
                     v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-                    if (p.prescale) for (int i = 0; i < 4; ++i) v[i] = prescale_px(v[i]);
+                    if (p.prescale) for (int i = 0; i < 4; ++i) v[i] = prescale_px(v[i], p);
                 }
             } else {
                 for (int i = 0; i < 4; ++i) {
                     const int kk = k + i;
                     if (kk >= kend) break;
                     const int tap = kk / p.Ci, ci = kk - tap * p.Ci;
-                    const int iy = coy + tap / 3 - p.pad, ix = cox + tap % 3 - p.pad;
+                    const int iy = coy * cstr + tap / ks - p.pad, ix = cox * cstr + tap % ks - p.pad;
                     if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
                         const float x = p.A[(((size_t)cn * p.H + iy) * p.W + ix) * p.Ci + ci];
-                        v[i] = p.prescale ? prescale_px(x) : x;
+                        v[i] = p.prescale ? prescale_px(x, p) : x;
                     }
                 }
             }
@@ -214,8 +216,10 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
         const size_t idx = (size_t)row * p.ldc + col;
         if (p.splitk == 1) {
             v += bias;
+            if (p.alpha) v = v > 0.f ? v : v * p.alpha[col];
             if (p.relu) v = fmaxf(v, 0.f);
             if (p.act) v = p.act[idx] > 0.f ? v : 0.f;
+            if (p.resid) v += p.resid[idx];
             if (p.accumulate) v += C[idx];
         }
         C[idx] = v;
@@ -225,14 +229,17 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
 // out[m][n] = epilogue( sum_z part[z][m][n] ), z ascending
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long long MN, int ldc,
                                      int N, int S, const float* __restrict__ bias, int relu,
-                                     const float* __restrict__ act, int accumulate) {
+                                     const float* __restrict__ act, int accumulate, const float* __restrict__ alpha,
+                                     const float* __restrict__ resid) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= MN) return;
     float s = 0.f;
     for (int z = 0; z < S; ++z) s += part[(size_t)z * MN + i];
     if (bias) s += bias[i % ldc];
+    if (alpha) s = s > 0.f ? s : s * alpha[i % ldc];
     if (relu) s = fmaxf(s, 0.f);
     if (act) s = act[i] > 0.f ? s : 0.f;
+    if (resid) s += resid[i];
     if (accumulate) s += out[i];
     (void)N;
     out[i] = s;
@@ -291,7 +298,7 @@ hipError_t launch_gemm32(const GemmP& p, float* workspace, hipStream_t st) {
     if (p.splitk > 1) {
         const long long MN = (long long)p.M * p.N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, workspace, out, MN,
-                           p.ldc, p.N, p.splitk, p.bias, p.relu, p.act, p.accumulate);
+                           p.ldc, p.N, p.splitk, p.bias, p.relu, p.act, p.accumulate, p.alpha, p.resid);
         e = hipGetLastError();
     }
     return e;

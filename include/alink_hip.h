@@ -39,7 +39,7 @@ extern "C" {
 /* activation / weight storage type of the backbone GEMMs (accumulation is always f32) */
 #define ALINK_DT_BF16 0
 #define ALINK_DT_F16  1
-#define ALINK_DT_F32  2   /* pair-head compute type only (alink_head_set_compute_dtype) */
+#define ALINK_DT_F32  2   /* pair head: alink_head_set_compute_dtype; IR backbone: the float32 precision mode */
 
 /* input pixel layouts accepted by alink_embed */
 #define ALINK_LAYOUT_NHWC_F32 0   /* what siamese.ArcFace.process receives (code/siamese.py:232-234) */
@@ -68,7 +68,8 @@ typedef struct {
     int widths[5];     /* {64,64,128,256,512}: stem width then one per stage (multiples of 64) */
     int height, width; /* input size; "112,112" in code/siamese.py:222                       */
     int emb;           /* embedding size (512), multiple of 64                               */
-    int dtype;         /* ALINK_DT_BF16 | ALINK_DT_F16                                       */
+    int dtype;         /* ALINK_DT_BF16 | ALINK_DT_F16 | ALINK_DT_F32 (the reference's own precision:  */
+                       /* exact-f32 MFMA GEMMs, ~1/20 of the bf16 rate; embed only, no profile / gradient) */
     float bn_eps;      /* 2e-5 in the insightface symbol                                     */
 } alink_ir_cfg;
 

@@ -290,3 +290,40 @@ def test_normalized_synthetic_weights_f16_and_auto_dtype(gpu, capsys):
     assert d16.max() < 2e-5 and dbf.max() < COS_TOL
     ps = W.synthetic_ir_params(W.R100_UNITS, seed=1)
     assert IRBackbone(ps, dtype="auto", max_batch=4).dtype == "bf16"
+
+
+def test_float32_precision_mode(gpu, capsys):
+    """IRBackbone(dtype="f32"): the reference's own precision (exact-f32 MFMA GEMMs, bn1 unfused like the symbol).
+    Against the f32 CPU oracle the two differ only by summation order: 1 - cos at the 1e-7 level at IR-50 / IR-100
+    depth on either kind of weights, every layout, batch-invariant bit for bit."""
+    from a_link_amd import _abi, weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import ir_resnet
+    size = (32, 32)
+    params = W.synthetic_ir_params((2, 2, 2, 2), size=size, seed=3)
+    bb = IRBackbone(params, image_size=size, dtype="f32", max_batch=8)
+    x = _pixels(5, size, seed=1)
+    ref = ir_resnet.embed(params, x)
+    got = bb.embed(x)
+    assert np.abs(got - ref).max() < 5e-6 and _cos_dist(got, ref).max() < 1e-6
+    assert np.array_equal(got, bb.embed(np.ascontiguousarray(np.transpose(x, (0, 3, 1, 2)))))      # NCHW
+    assert np.array_equal(got, bb.embed(x.astype(np.uint8)))                                         # u8
+    assert np.array_equal(bb.embed(x[2:3])[0], got[2])                                               # batch-invariant
+    x19 = _pixels(19, size, seed=7)
+    assert np.array_equal(bb.embed(x19)[9], bb.embed(x19[9:10])[0])                                  # chunked (max_batch 8)
+    with pytest.raises(_abi.AlinkError):
+        bb.profile(torch.from_numpy(x).cuda())
+    with pytest.raises(_abi.AlinkError):
+        IRBackbone(params, image_size=size, dtype="f32", enable_grad=True)
+    out = {}
+    for arch, normalized in (("r50", False), ("r100", True), ("r100", False)):
+        p = W.synthetic_ir_params(W.ARCH_UNITS[arch], seed=1, normalized=normalized)
+        xi = _pixels(6, (112, 112), seed=2)
+        r = ir_resnet.embed(p, xi, batch=6)
+        g = IRBackbone(p, dtype="f32", max_batch=6).embed(xi)
+        out[(arch, normalized)] = (float(_cos_dist(g, r).max()), float(np.abs(g - r).max()))
+    with capsys.disabled():
+        print("\n[f32 mode vs f32 oracle @112] " + "; ".join("%s %s: 1-cos %.1e max|d| %.1e" % (a, "normalized" if nrm else "survey", c, d)
+                                                            for (a, nrm), (c, d) in out.items()))
+    for (a, nrm), (c, d) in out.items():
+        assert c < 2e-6 and d < (2e-5 if nrm else 2e-4), (a, nrm, c, d)
