@@ -5,7 +5,8 @@
 // Why it exists: BASELINE.json's north_star asks for "identical top-k active-learning selection indices".  A selection
 // is a set of threshold decisions; with bf16 activations (1 - cos ~3e-4) a third of config 3's 1,024 most uncertain
 // pairs differ from the f32 arithmetic, with f16 (4e-6) 5 % do.  Only the reference's own precision
-// reproduces its decisions; this mode is that, at about a twentieth of the bf16 throughput — for audits, for settling
+// reproduces its decisions; this mode is that, at about a twelfth of the bf16 throughput (IR-100: 3.8 k embeddings/s =
+// 92 TFLOP/s, 58 % of the f32 MFMA peak) — for audits, for settling
 // pairs that sit on a cut, and as an on-device cross-check of the reduced-precision kernels at full depth.
 //
 // Every convolution and the FC layer is the exact-f32 MFMA GEMM of sgemm.hip (v_mfma_f32_32x32x2_f32: bit for bit an
@@ -235,7 +236,8 @@ size_t f32net_workspace_bytes(const F32Net* n, int N) {
 int f32net_embed(const F32Net* n, const void* dev_in, int layout, int N, float* dev_out, void* ws, size_t ws_bytes,
                  hipStream_t st) {
     ALINK_REQUIRE(n && dev_in && dev_out && ws && N > 0, ALINK_EINVAL, "bad argument");
-    ALINK_REQUIRE((long long)N * n->H * n->W * 64 < (1ll << 31), ALINK_EINVAL, "batch of %d images too large for the float32 mode; split it", N);
+    ALINK_REQUIRE((long long)N * n->H * n->W * 64 < (1ll << 31) && ((long long)N * n->H * n->W + 63) / 64 <= 65535, ALINK_EINVAL,
+                  "batch of %d images too large for one float32 launch chain (grid rows); split it", N);
     alink_ir_cfg dummy{};
     const WsLayout WL = ws_layout(n, N, dummy);
     ALINK_REQUIRE(ws_bytes >= WL.total, ALINK_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, WL.total);
@@ -273,7 +275,11 @@ int f32net_embed(const F32Net* n, const void* dev_in, int layout, int N, float* 
         g.A = buf(n->last_buf); g.B = n->d_fc_w; g.C = (float*)(base + WL.fc);
         g.M = N; g.N = n->emb; g.K = n->fcK; g.lda = n->fcK; g.ldb = n->emb; g.ldc = n->emb;
         g.amode = A_ROW; g.bmode = B_ROW;
-        gemm32_plan_split(g, 32);
+        // a FIXED split (16 slabs whatever the batch): an image's embedding must not depend on the batch it arrives in,
+        // and the plan that fills the chip best would choose the split by the number of rows
+        g.splitk = 16;
+        g.kper = ((g.K + g.splitk - 1) / g.splitk + 15) / 16 * 16;
+        g.splitk = (g.K + g.kper - 1) / g.kper;
         ALINK_REQUIRE(gemm32_workspace_floats(g) * 4 <= GEMM_WS_BYTES, ALINK_ENOMEM, "FC split workspace too small");
         ALINK_HIP(launch_gemm32(g, gws, st));
         FcFinishParams f{};

@@ -69,7 +69,7 @@ typedef struct {
     int height, width; /* input size; "112,112" in code/siamese.py:222                       */
     int emb;           /* embedding size (512), multiple of 64                               */
     int dtype;         /* ALINK_DT_BF16 | ALINK_DT_F16 | ALINK_DT_F32 (the reference's own precision:  */
-                       /* exact-f32 MFMA GEMMs, ~1/20 of the bf16 rate; embed only, no profile / gradient) */
+                       /* exact-f32 MFMA GEMMs, ~1/12 of the bf16 rate; embed only, no profile / gradient) */
     float bn_eps;      /* 2e-5 in the insightface symbol                                     */
 } alink_ir_cfg;
 

@@ -311,6 +311,9 @@ def test_float32_precision_mode(gpu, capsys):
     assert np.array_equal(bb.embed(x[2:3])[0], got[2])                                               # batch-invariant
     x19 = _pixels(19, size, seed=7)
     assert np.array_equal(bb.embed(x19)[9], bb.embed(x19[9:10])[0])                                  # chunked (max_batch 8)
+    big = IRBackbone(params, image_size=size, dtype="f32", max_batch=300)
+    x300 = _pixels(300, size, seed=8)
+    assert np.array_equal(big.embed(x300)[[0, 150, 299]], np.concatenate([bb.embed(x300[i:i + 1]) for i in (0, 150, 299)]))
     with pytest.raises(_abi.AlinkError):
         bb.profile(torch.from_numpy(x).cuda())
     with pytest.raises(_abi.AlinkError):
