@@ -82,7 +82,10 @@ struct Lin {
     static_assert(GPX % W == 0, "a workgroup covers whole rows");
 };
 
-template <typename T, int W, int TCW>
+// EPI: the epilogue a launch needs, fixed at compile time for the two forms the forward pass uses — 1: bias + PReLU
+// (a unit's conv1), 2: bias + residual (conv2) — so that neither carries the other's loads, selects and branches;
+// 0: every mode by run-time flags (PReLU', post-ReLU, split partial sums, both at once).
+template <typename T, int W, int TCW, int EPI>
 __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams p) {
     typedef typename Vec8<T>::type vec8;
     typedef Lin<W, TCW> G;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     const int wbase = wco * (16 * TCW);
     auto chan_t = [&](int t) { return wbase + (TCW == 4 ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) : 8 * q + 4 * t); };
     auto chan_h = [&](int h) { return wbase + (TCW == 4 ? 32 * h + 8 * q : 8 * q); };
-    if (p.splitk > 1) {
+    if (EPI == 0 && p.splitk > 1) {
         float* slab = (float*)p.out + (size_t)blockIdx.y * (size_t)totpix * p.Cout;
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
@@ -291,8 +294,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
         cls[u] = p.border_cls ? rc * 3 + ccl : 0;
     }
     vec8 res[TPW][CPL / 8];
-    const T* extra = (const T*)(p.dact ? p.dact : p.resid);
-    if (extra) {
+    const T* extra = EPI == 1 ? (const T*)nullptr : (const T*)((EPI == 0 && p.dact) ? p.dact : p.resid);
+    if (EPI == 2 || (EPI == 0 && extra)) {
 #pragma unroll
         for (int u = 0; u < TPW; ++u)
 #pragma unroll
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[4 * t + j] = acc[t][u][j] + b4[j];
         }
-        if (p.dact) {
+        if (EPI == 0 && p.dact) {
 #pragma unroll
             for (int t = 0; t < TCW; ++t) {
                 const f32x4 a4 = *(const f32x4*)(ealpha + chan_t(t));
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
                 for (int j = 0; j < 4; ++j) v[4 * t + j] *= (float)res[u][(4 * t + j) / 8][(4 * t + j) % 8] > 0.f ? 1.f : a4[j];
             }
         } else {
-            if (p.alpha) {
+            if (EPI == 1 || (EPI == 0 && p.alpha)) {
 #pragma unroll
                 for (int t = 0; t < TCW; ++t) {
                     const f32x4 a4 = *(const f32x4*)(ealpha + chan_t(t));
@@ -327,14 +330,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
                     for (int j = 0; j < 4; ++j) v[4 * t + j] = v[4 * t + j] > 0.f ? v[4 * t + j] : v[4 * t + j] * a4[j];
                 }
             }
-            if (p.resid) {
+            if (EPI == 2 || (EPI == 0 && p.resid)) {
 #pragma unroll
                 for (int h = 0; h < CPL / 8; ++h)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[8 * h + i] += (float)res[u][h][i];
             }
         }
-        if (p.post_relu) {
+        if (EPI == 0 && p.post_relu) {
 #pragma unroll
             for (int i = 0; i < CPL; ++i) v[i] = fmaxf(v[i], 0.f);
         }
@@ -355,6 +358,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     }
 }
 
+bool g_generic_epilogue = false;      // A/B: every launch on the run-time-flag epilogue (EPI = 0)
+
 template <typename T, int W, int TCW>
 hipError_t launch_one(const ConvParams& p, hipStream_t st) {
     typedef Lin<W, TCW> G;
@@ -362,13 +367,23 @@ hipError_t launch_one(const ConvParams& p, hipStream_t st) {
     const long long groups = (totpix + GPX - 1) / GPX;
     const long long nwg = groups * (p.Cout / G::BN);
     if (nwg <= 0 || nwg >= (1ll << 31)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW>), dim3((unsigned)nwg, (unsigned)p.splitk), dim3(NT), G::lds_bytes(), st, p);
+    const dim3 grid((unsigned)nwg, (unsigned)p.splitk);
+    const bool plain = p.splitk == 1 && !p.dact && !p.post_relu && !p.stamps && !g_generic_epilogue;
+    if (plain && p.alpha && !p.resid)
+        hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 1>), grid, dim3(NT), G::lds_bytes(), st, p);
+    else if (plain && !p.alpha && p.resid)
+        hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 2>), grid, dim3(NT), G::lds_bytes(), st, p);
+    else
+        hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 0>), grid, dim3(NT), G::lds_bytes(), st, p);
     return hipGetLastError();
 }
 template <typename T, int W, int TCW>
 hipError_t set_attr_one() {
-    return hipFuncSetAttribute((const void*)conv3x3_linear_kernel<T, W, TCW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)Lin<W, TCW>::lds_bytes());
+    const int lds = (int)Lin<W, TCW>::lds_bytes();
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<T, W, TCW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<T, W, TCW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<T, W, TCW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return e;
 }
 
 // Which map widths take the linear-tile kernel: bit 0 = 56, bit 1 = 28, bit 2 = 14, bit 3 = 7 (default: all).
@@ -380,6 +395,7 @@ int g_linear_mode = 15;
 }  // namespace
 
 extern "C" void alink_debug_set_linear(int mode) { g_linear_mode = mode; }
+extern "C" void alink_debug_set_generic_epilogue(int on) { g_generic_epilogue = on != 0; }
 
 // Hardware contract probe: a DS read whose address lies beyond the workgroup's LDS allocation returns zero
 // (and does not fault).  The kernel above adds border bits 18..21 (tiles 0-4), 20..23 (tile 5) or 24..27 (tile 6)

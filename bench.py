@@ -63,6 +63,7 @@ def main():
                     "library's internal streams (alink_backbone_set_streams)")
     ap.add_argument("--fine-max", type=int, default=-1, help="A/B: largest 128-channel grid that still takes the 64-channel form")
     ap.add_argument("--stagger", type=int, default=-1, help="A/B: start delay (x 1024 cycles) of the second workgroup on a CU in the linear-tile kernel")
+    ap.add_argument("--generic-epilogue", action="store_true", help="A/B: linear-tile kernel with the run-time-flag epilogue everywhere")
     ap.add_argument("--config3", action="store_true", help="also time the config-3 leg (3 x IR-50 committee over a pool shard) "
                     "at N = 1; under torch.distributed.run it always runs")
     ap.add_argument("--config3-shard", type=int, default=2336, help="pool images per GPU in the config-3 leg")
@@ -96,6 +97,9 @@ def main():
     if args.stagger >= 0:
         from a_link_amd import _abi
         _abi.load().alink_debug_set_stagger(args.stagger)
+    if args.generic_epilogue:
+        from a_link_amd import _abi
+        _abi.load().alink_debug_set_generic_epilogue(1)
     if args.fine_max >= 0:
         from a_link_amd import _abi
         _abi.load().alink_debug_set_fine_max(args.fine_max)
