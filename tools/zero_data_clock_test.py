@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Is the embedding rate held down by the clock the chip keeps under MFMA load on real data (MI355X_MICROARCH.md, DVFS
+give-back)?  Same launches, same kernels: random weights + random pixels against all-zero weights (every activation and
+every MFMA operand zero).  A large gap = the plateau every launch shape lands on is the chip's power / clock limit."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import a_link_amd  # noqa
+from a_link_amd import weights as W
+from a_link_amd.backbone import IRBackbone
+
+
+def rate(params, x, reps=12):
+    bb = IRBackbone(params, max_batch=292, streams=4)
+    out = torch.empty((x.shape[0], 512), device="cuda")
+    for _ in range(3):
+        bb.embed_device(x, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        bb.embed_device(x, out)
+    torch.cuda.synchronize()
+    return reps * x.shape[0] / (time.perf_counter() - t0)
+
+
+def main():
+    p = W.synthetic_ir_params(W.R100_UNITS, seed=1)
+    x = torch.randint(0, 256, (1168, 112, 112, 3), dtype=torch.uint8).float().cuda()
+    print("random weights, random pixels: %.0f embeddings/s" % rate(p, x))
+    pz = {k: (np.zeros_like(v) if k.endswith("_weight") else v) for k, v in p.items()}
+    print("zero conv / FC weights (all-zero MFMA operands on one side, constant activations): %.0f embeddings/s" % rate(pz, x))
+    pzz = {k: (np.zeros_like(v) if (k.endswith("_weight") or k.endswith("_beta") or k.endswith("_bias") or k.endswith("_moving_mean")) else v)
+           for k, v in p.items()}
+    print("zero weights and zero biases (every activation exactly zero): %.0f embeddings/s" % rate(pzz, torch.zeros_like(x)))
+    print("random again: %.0f embeddings/s" % rate(p, x))
+
+
+if __name__ == "__main__":
+    main()
