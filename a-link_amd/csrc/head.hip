@@ -49,6 +49,7 @@ struct alink_head {
     int qmode = 0;
     __bf16* d_pq = nullptr;
     float* d_pqf = nullptr;
+    __bf16* d_wt = nullptr;      // bf16 mode, predict on the bf16 matrix cores: W1^T [h1][D] then W2^T [h2][h1] (re-derived with the packed copies)
     bool pq_dirty = true, pqf_dirty = true;
     // train/eval scratch for up to `cap` rows
     int cap = 4096;
@@ -279,6 +280,172 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const HeadFwd p) {
             *o = pr;
         }
     }
+}
+
+
+// ------------------------------- bf16 compute mode: pair scoring on the bf16 matrix cores ------------------------------
+// The predict path of the bf16 compute mode for the head the reference builds (h1 = 512, h2 = 64, 2-way softmax, D a
+// multiple of 512: code/siamese.py:27-32): same arithmetic as head_fwd_kernel with p.q (operands rounded to bf16,
+// exact products, f32 sums) on v_mfma_f32_16x16x32_bf16 instead of the f32-input instruction (16x the rate), so that
+// pool-scale scoring (1.6 M pairs per GPU and pass in configs[2], 60 M in the DFW score matrix) is bound by the
+// gather of the embedding rows, not by the multiply.
+//   workgroup = 64 pairs, 4 waves; |l - r| of the current 512-deep K chunk as bf16 in LDS ([pair][k], 16-B pieces
+//   XOR-swizzled by the pair so that every ds_read_b128 lane group hits 16 distinct bank slots); layer 1: wave w owns
+//   output channels 128 w .. 128 w + 127 (8 MFMA tiles) x 64 pairs (4 tiles) = 32 accumulators, weight fragments
+//   straight from global (W1^T [h1][D] bf16, L2-resident, next K-step's fragments in flight); a1 = relu(z1 + b1) as bf16
+//   back into the same LDS image; layer 2: wave w owns pair tile w x 64 channels; layer 3 + softmax on the VALU.
+typedef __attribute__((ext_vector_type(8))) __bf16 hbf16x8;
+struct HeadFwdQ {
+    const float *L, *R;
+    const int32_t *li, *ri;
+    long long P;
+    const __bf16 *w1t, *w2t;        // [512][D], [64][512]
+    const float *b1, *b2, *w3, *b3;  // w3: the bf16 values widened to f32, [64][2]
+    float* probs;
+    int D, accumulate;
+    float final_div;
+};
+constexpr int QP = 64;                 // pairs per workgroup
+__device__ __forceinline__ int q_lds_off(int pair, int k) {      // byte offset of element (pair, k) of the [64][512] bf16 image
+    return pair * 1024 + ((((k >> 3) ^ (pair & 15)) << 4) | ((k & 7) << 1));
+}
+__global__ __launch_bounds__(256, 2) void head_fwd_bf16_kernel(const HeadFwdQ p) {
+    extern __shared__ __attribute__((aligned(16))) char qs[];    // 64 KB image + row indices
+    long long* const s_lrow = (long long*)(qs + 65536);
+    long long* const s_rrow = s_lrow + QP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, kb = lane >> 4;
+    const long long p0 = (long long)blockIdx.x * QP;
+    const int D = p.D;
+    if (tid < QP) {
+        long long pp = p0 + tid;
+        if (pp >= p.P) pp = p.P - 1;
+        s_lrow[tid] = p.li ? (long long)p.li[pp] : pp;
+        s_rrow[tid] = p.ri ? (long long)p.ri[pp] : pp;
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[c][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // weight fragment of MFMA tile c at K-step ks: rows (channels) 128 wave + 16 c + ln, k = 32 ks + 8 kb .. + 7
+    const __bf16* w1row = p.w1t + (size_t)(wave * 128 + ln) * D + kb * 8;
+    for (int k0 = 0; k0 < D; k0 += 512) {
+        __syncthreads();                                           // row indices ready / previous chunk's reads done
+        // gather: 64 pairs x 64 pieces of 8 k; thread -> (pair = i >> 6, piece = i & 63), i = tid + 256 j
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int i = tid + 256 * j, pair = i >> 6, piece = i & 63;
+            const float* lp = p.L + s_lrow[pair] * D + k0 + piece * 8;
+            const float* rp = p.R + s_rrow[pair] * D + k0 + piece * 8;
+            const f32x4 l0 = *(const f32x4*)lp, l1 = *(const f32x4*)(lp + 4), r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+            hbf16x8 d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d[e] = (__bf16)fabsf(l0[e] - r0[e]); d[4 + e] = (__bf16)fabsf(l1[e] - r1[e]); }
+            *(hbf16x8*)(qs + pair * 1024 + ((piece ^ (pair & 15)) << 4)) = d;
+        }
+        __syncthreads();
+        hbf16x8 wa[8], wb[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wa[c] = *(const hbf16x8*)(w1row + (size_t)c * 16 * D + k0);
+#pragma unroll 1
+        for (int ks = 0; ks < 16; ks += 2) {
+            // two K-steps per trip, fragments of the second in flight under the first's MFMAs and vice versa
+#pragma unroll
+            for (int c = 0; c < 8; ++c) wb[c] = *(const hbf16x8*)(w1row + (size_t)c * 16 * D + k0 + (ks + 1) * 32);
+            {
+                hbf16x8 pf[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pf[u] = *(const hbf16x8*)(qs + (16 * u + ln) * 1024 + ((((ks * 4 + kb)) ^ ln) << 4));
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[c][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c], pf[u], acc[c][u], 0, 0, 0);
+            }
+            if (ks + 2 < 16) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) wa[c] = *(const hbf16x8*)(w1row + (size_t)c * 16 * D + k0 + (ks + 2) * 32);
+            }
+            {
+                hbf16x8 pf[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pf[u] = *(const hbf16x8*)(qs + (16 * u + ln) * 1024 + (((((ks + 1) * 4 + kb)) ^ ln) << 4));
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[c][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[c], pf[u], acc[c][u], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    // a1 = relu(z1 + b1) as bf16 into the image: accumulator element j of tile (c, u) is channel 128 wave + 16 c + 4 kb + j,
+    // pair 16 u + ln -> 4 consecutive channels = one 8-byte store
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = wave * 128 + 16 * c + 4 * kb;
+        const f32x4 bb = *(const f32x4*)(p.b1 + ch);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+            b4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (__bf16)fmaxf(acc[c][u][j] + bb[j], 0.f);
+            *(b4*)(qs + q_lds_off(16 * u + ln, ch)) = o;
+        }
+    }
+    __syncthreads();
+    // layer 2: pair tile `wave`, 4 channel tiles, K = 512
+    f32x4 acc2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const __bf16* w2row = p.w2t + (size_t)ln * 512 + kb * 8;
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+        const hbf16x8 pf = *(const hbf16x8*)(qs + (16 * wave + ln) * 1024 + (((ks * 4 + kb) ^ ln) << 4));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const hbf16x8 wf = *(const hbf16x8*)(w2row + (size_t)c * 16 * 512 + ks * 32);
+            acc2[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf, acc2[c], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                               // every wave is done reading a1: the image's start is free
+    float* const a2 = (float*)qs;                                  // [64 pairs][64 channels] f32 (bf16-valued)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = 16 * c + 4 * kb;
+        const f32x4 bb = *(const f32x4*)(p.b2 + ch);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = qbf(fmaxf(acc2[c][j] + bb[j], 0.f));
+        *(f32x4*)(a2 + (16 * wave + ln) * 64 + ch) = o;
+    }
+    __syncthreads();
+    if (tid < 2 * QP) {
+        const int row = tid >> 1, cls = tid & 1;
+        float z = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) z = fmaf(a2[row * 64 + c], p.w3[c * 2 + cls], z);
+        z += p.b3[cls];
+        const float zo = __shfl_xor(z, 1, 64);
+        const float m = fmaxf(z, zo);
+        const float e = expf(z - m), eo = expf(zo - m);
+        float pr = e / (e + eo);
+        const long long pp = p0 + row;
+        if (pp < p.P) {
+            float* o = p.probs + pp * 2 + cls;
+            if (p.accumulate) pr += *o;
+            if (p.final_div > 0.f) pr = pr / p.final_div;
+            *o = pr;
+        }
+    }
+}
+// wt[c][k] = pq[k][c]: W (in, out) row-major bf16 -> W^T
+__global__ void transpose_bf16_kernel(const __bf16* __restrict__ w, __bf16* __restrict__ wt, int in, int out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)in * out) return;
+    const int c = (int)(i / in), k = (int)(i - (long long)c * in);
+    wt[i] = w[(size_t)k * out + c];
 }
 
 // ------------------------------- small-batch train / eval kernels --------------------------------
@@ -630,10 +797,18 @@ int ensure_packed(alink_head* h, hipStream_t st) {
                        h->d_w1p, h->D, h->h1);
     hipLaunchKernelGGL(pack_kernel, g1((long long)h->h1 * h->h2), dim3(256), 0, st, src + h->oW2,
                        h->d_w2p, h->h1, h->h2);
+    if (h->qmode && h->d_wt) {      // W1^T, W2^T in bf16 for head_fwd_bf16_kernel
+        hipLaunchKernelGGL(transpose_bf16_kernel, g1((long long)h->D * h->h1), dim3(256), 0, st, h->d_pq + h->oW1, h->d_wt,
+                           h->D, h->h1);
+        hipLaunchKernelGGL(transpose_bf16_kernel, g1((long long)h->h1 * h->h2), dim3(256), 0, st, h->d_pq + h->oW2,
+                           h->d_wt + (size_t)h->D * h->h1, h->h1, h->h2);
+    }
     ALINK_HIP(hipGetLastError());
     h->packed_dirty = false;
     return ALINK_OK;
 }
+
+bool g_use_bf16_mfma = true;       // A/B: bf16 mode's predict on the bf16 matrix cores (else the f32-input kernel with rounding)
 
 size_t fwd_lds_bytes(int h1) {
     const size_t a = (size_t)(KC / 8) * ROWP, b = (size_t)(h1 / 8) * ROWP, c = 4 * TP * 64 + TP * 64;
@@ -647,6 +822,17 @@ int launch_fwd(alink_head* h, const float* L, const float* R, const int32_t* li,
                int mat_row0 = 0, int out_col = -1) {
     int rc = ensure_packed(h, st);
     if (rc) return rc;
+    if (h->qmode && g_use_bf16_mfma && h->d_wt && h->h1 == 512 && h->h2 == 64 && h->od == 2 && h->D % 512 == 0 && matN == 0 &&
+        out_col < 0) {
+        HeadFwdQ q{};
+        q.L = L; q.R = R; q.li = li; q.ri = ri; q.P = P;
+        q.w1t = h->d_wt; q.w2t = h->d_wt + (size_t)h->D * h->h1;
+        q.b1 = h->d_params + h->ob1; q.b2 = h->d_params + h->ob2; q.w3 = h->d_pqf + h->oW3; q.b3 = h->d_params + h->ob3;
+        q.probs = probs; q.D = h->D; q.accumulate = accumulate; q.final_div = final_div;
+        hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3((unsigned)((P + QP - 1) / QP)), dim3(256), 65536 + 2 * QP * 8, st, q);
+        ALINK_HIP(hipGetLastError());
+        return ALINK_OK;
+    }
     HeadFwd p{};
     p.L = L; p.R = R; p.li = li; p.ri = ri; p.P = P;
     p.w1p = h->d_w1p; p.b1 = h->d_params + h->ob1; p.w2p = h->d_w2p; p.b2 = h->d_params + h->ob2;
@@ -1306,6 +1492,7 @@ int head_init_attrs() {
     ALINK_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     ALINK_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     ALINK_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    ALINK_HIP(hipFuncSetAttribute((const void*)head_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 2 * QP * 8));
     if (dev >= 0 && dev < 64) g_head_attr_done |= 1ull << dev;
     return ALINK_OK;
 }
@@ -1470,6 +1657,7 @@ static int train_step_launches(alink_head_t* h, const float* dev_L, const float*
 }
 
 void alink_debug_set_tiny_step(int on) { g_use_tiny = on != 0; }
+void alink_debug_set_head_bf16_mfma(int on) { g_use_bf16_mfma = on != 0; }
 
 int alink_head_set_graph(alink_head_t* h, int on) {
     ALINK_REQUIRE(h, ALINK_EINVAL, "NULL head");
@@ -1545,6 +1733,8 @@ int alink_head_set_compute_dtype(alink_head_t* h, int dtype) {
         h->allocs.push_back(h->d_pq);
         ALINK_HIP(hipMalloc((void**)&h->d_pqf, h->nparams * sizeof(float)));
         h->allocs.push_back(h->d_pqf);
+        ALINK_HIP(hipMalloc((void**)&h->d_wt, ((size_t)h->D * h->h1 + (size_t)h->h1 * h->h2) * sizeof(__bf16)));
+        h->allocs.push_back(h->d_wt);
     }
     h->qmode = dtype == ALINK_DT_BF16 ? 1 : 0;
     h->packed_dirty = h->pq_dirty = h->pqf_dirty = true;

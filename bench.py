@@ -334,6 +334,13 @@ def main():
             hd.predict_device(E, E, li, ri, out=po)
         torch.cuda.synchronize()
         line["pair_scores_per_s"] = 3 * (1 << 20) / (time.perf_counter() - t1)
+        hq.predict_device(E, E, li, ri, out=po)          # the same 1M pairs in the bf16 compute mode (bf16 matrix cores)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            hq.predict_device(E, E, li, ri, out=po)
+        torch.cuda.synchronize()
+        line["pair_scores_per_s_bf16"] = 3 * (1 << 20) / (time.perf_counter() - t1)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle (kind "port": our CPU restatement; the reference's MXNet /

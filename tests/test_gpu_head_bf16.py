@@ -150,3 +150,39 @@ def _adadelta_state(head):
         out_d.append(d[o:o + n].reshape(s))
         o += n
     return out_a, out_d
+
+
+@pytest.mark.parametrize("d_in,P", [(512, 1), (512, 63), (512, 5000), (2048, 777)])
+def test_bf16_matrix_core_predict_equals_the_rounding_kernel(gpu, d_in, P):
+    """bf16 mode scores pairs with head_fwd_bf16_kernel (v_mfma_f32_16x16x32_bf16) when the head has the reference's
+    shape; the f32-input kernel with in-flight rounding computes the same thing (bf16 operands, exact products, f32 sums)
+    and stays the fallback for other shapes: the two agree up to summation order / rounding-boundary flips, with and
+    without index gather, alone and inside a committee mean, for pair counts that do not fill a 64-pair workgroup."""
+    from a_link_amd import committee, siamese
+    from oracle import siamese_head as O
+    rs = np.random.RandomState(P)
+    n = 300
+    E = rs.randn(n, d_in).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    li = rs.randint(0, n, P).astype(np.int32)
+    ri = rs.randint(0, n, P).astype(np.int32)
+    nets = [siamese.SiameseNetwork((d_in,), "q%d" % i, 0.1, seed=i, compute_dtype="bf16") for i in range(2)]
+    lib = nets[0].siamese_net.lib
+    outs = {}
+    try:
+        for fast in (1, 0):
+            lib.alink_debug_set_head_bf16_mfma(fast)
+            single = nets[0].siamese_net.predict_device(E, E, li, ri).cpu().numpy()
+            plain = nets[0].predict([E[li], E[ri]])
+            bag = committee.Bagging(nets, []).predict_indexed(E, E, li, ri).cpu().numpy()
+            outs[fast] = (single, plain, bag)
+    finally:
+        lib.alink_debug_set_head_bf16_mfma(1)
+    for a, b in zip(outs[1], outs[0]):
+        assert a.shape == (P, 2) and np.isfinite(a).all()
+        assert np.abs(a - b).max() < 3e-3 and np.mean(np.abs(a - b) > 2e-4) < 0.06
+        np.testing.assert_allclose(a.sum(1), 1.0, atol=1e-5)
+    assert np.array_equal(outs[1][0], outs[1][1])                           # gather by index == materialised pairs
+    o = O.HeadModel(d_in, quant="bf16")
+    o.set_weights(nets[0].siamese_net.get_weights())
+    assert np.abs(outs[1][0] - o.predict([E[li], E[ri]])).max() < 3e-3
