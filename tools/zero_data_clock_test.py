@@ -35,5 +35,30 @@ def main():
     print("random again: %.0f embeddings/s" % rate(p, x))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--dominant" not in sys.argv:
     main()
+
+
+def dominant_launch_us(params, x):
+    """mean duration of the stage-3 3x3 launches of one forward, each launch alone (alink_embed_profile)."""
+    bb = IRBackbone(params, max_batch=292)
+    for _ in range(2):
+        bb.embed_device(x[:292])
+    prof = bb.profile(x[:292])
+    conv = [(ms, f) for k, ms, f in prof if k == 1]
+    groups = {}
+    for ms, f in conv:
+        groups.setdefault(round(f / 1e6), []).append(ms)
+    key = max(groups, key=lambda k: sum(groups[k]))             # the shape with the most time: 14x14, 256 -> 256
+    return 1e3 * float(np.mean(groups[key])), key * 1e6, len(groups[key])
+
+
+if __name__ == "__main__" and "--dominant" in sys.argv:
+    p = W.synthetic_ir_params(W.R100_UNITS, seed=1)
+    x = torch.randint(0, 256, (292, 112, 112, 3), dtype=torch.uint8).float().cuda()
+    us, fl, n = dominant_launch_us(p, x)
+    print("dominant launch on data:  %.1f us x %d launches -> %.0f TFLOP/s = %.1f %% of 2516.6" % (us, n, fl / us / 1e6, 100 * fl / us / 1e6 / 2516.6))
+    pzz = {k: (np.zeros_like(v) if (k.endswith("_weight") or k.endswith("_beta") or k.endswith("_bias") or k.endswith("_moving_mean")) else v)
+           for k, v in p.items()}
+    us, fl, n = dominant_launch_us(pzz, torch.zeros_like(x))
+    print("dominant launch on zeros: %.1f us x %d launches -> %.0f TFLOP/s = %.1f %% of 2516.6" % (us, n, fl / us / 1e6, 100 * fl / us / 1e6 / 2516.6))
