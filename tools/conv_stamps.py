@@ -22,7 +22,7 @@ for name in sys.argv[1:] or ["s2", "s3", "s1"]:
         t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); t0.record()
         _abi.check(lib.alink_conv_nhwc(0, _abi.ptr(x), _abi.ptr(w), _abi.ptr(b), None, _abi.ptr(out), _abi.ptr(out),
-                                       N, H, W, Ci, Co, 3, 1, 1, 1, None))
+                                       N, H, W, Ci, Co, 3, 1, 1, 1, -1, None))
         t1.record(); torch.cuda.synchronize()
     lib.alink_debug_set_stamps(None)
     s = st.cpu().numpy().reshape(-1, 4)
