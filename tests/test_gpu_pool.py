@@ -319,8 +319,8 @@ def test_alink_iteration_selection_at_depth(gpu, capsys, arch, dtype):
     with capsys.disabled():
         print("\n[config 4, %s %s @112 calibrated, P=%d] 1-cos=%.1e max|d ens|=%.2e max|d dis|=%.2e" % (arch, dtype, P, cos, d_ens, d_dis))
     assert cos < 1e-3
-    # f16 meets the 5 % bar at depth; bf16 storage (8 mantissa bits through 24 units: probabilities move by up to 2.5e-2)
-    # leaves up to 10 % of the pairs within their own error of a cut — DESIGN.md §5 has the measured counts
-    _check_alink_iteration(res, P, ens_o, capsys, {"f32": 0.002, "f16": 0.05, "bf16": 0.10}[dtype])
+    # f16 meets the 5 % bar at depth; bf16 storage (8 mantissa bits through 24 / 49 units: probabilities move by up to 3e-2)
+    # leaves 8-9 % of the pairs within their own error of a cut (cap 12 %) — DESIGN.md §5 has the measured counts
+    _check_alink_iteration(res, P, ens_o, capsys, {"f32": 0.002, "f16": 0.05, "bf16": 0.12}[dtype])
     if dtype == "f32":            # the reference's own precision reproduces its query sets
         assert all(set(q) == qs for (q, _, qs, *_rest) in res.values())
