@@ -88,12 +88,16 @@ def dp_batch_slices(n, world):
 DP_SHARD_MIN_ROWS = 2048
 
 
-def dp_train_on_batch(head, x, y, class_weight=None, sample_weight=None, group=None, mode="auto"):
+def dp_train_on_batch(head, x, y, class_weight=None, sample_weight=None, group=None, mode="auto", exchange="gather"):
     """Keras train_on_batch on a DenseHead in a one-process-per-GPU job: x=[L,R], y one-hot — the FULL batch on
     every rank.  mode "replicated": every rank runs the whole step (bit-identical weights, zero communication);
     "sharded": each rank runs its slice with the GLOBAL normaliser, ONE all-reduce carries gradients + metrics,
     every rank applies the same Adadelta update (equal to the single-GPU step up to f32 summation order);
-    "auto": replicated below DP_SHARD_MIN_ROWS rows."""
+    "auto": replicated below DP_SHARD_MIN_ROWS rows.
+    exchange (sharded mode): "gather" = ONE all-gather of every rank's 1.18 MB gradient buffer over the direct xGMI links
+    and a sum in rank order on every rank (one-shot, latency of one hop, the same bits on every rank whatever algorithm
+    the library would pick for a reduction: SURVEY.md §5 — a ring is the wrong shape for a message this small);
+    "allreduce" = torch.distributed.all_reduce (RCCL's own choice)."""
     if mode == "auto":
         mode = "replicated" if len(y) < DP_SHARD_MIN_ROWS else "sharded"
     if mode == "replicated":
@@ -124,7 +128,14 @@ def dp_train_on_batch(head, x, y, class_weight=None, sample_weight=None, group=N
         m[1] *= (hi - lo)                                    # accuracy: local mean -> local sum
     else:
         gm.zero_()
-    dist.all_reduce(gm, group=group)
+    if exchange == "gather" and world > 1:
+        every = torch.empty((world, gm.numel()), dtype=gm.dtype, device=gm.device)
+        dist.all_gather_into_tensor(every, gm, group=group)
+        torch.sum(every, dim=0, out=gm)                      # fixed (rank) order
+    elif exchange in ("gather", "allreduce"):
+        dist.all_reduce(gm, group=group)
+    else:
+        raise ValueError("exchange must be gather or allreduce")
     _abi.check(head.lib.alink_head_apply_update(head.h, st))
     out = m[:2].cpu().numpy()
     return [float(out[0]), float(out[1] / n)]
