@@ -173,6 +173,8 @@ class DenseHead(KerasFitMixin):
         # {loss, accuracy} of a step land in pinned host memory, written by the kernel itself (pinned memory
         # is mapped into the device's address space): the step ends with one stream wait, not a copy
         self._metrics_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        self._metrics_host_ptr = self._metrics_host.data_ptr()
+        self._tdev = torch.device(self.device)
         self._stage = {}          # persistent device tensors the host batches are copied into
 
     def __del__(self):
@@ -342,7 +344,9 @@ class DenseHead(KerasFitMixin):
         """Device float32 tensor holding `a` at an address that stays the same from call to call."""
         torch = self.torch
         if isinstance(a, torch.Tensor):
-            return a.to(self.device, torch.float32).contiguous()          # the caller's own buffer
+            if a.dtype is torch.float32 and a.is_cuda and a.is_contiguous() and a.device == self._tdev:
+                return a                                                  # the caller's own buffer, as it is
+            return a.to(self.device, torch.float32).contiguous()
         arr = np.ascontiguousarray(a, dtype=np.float32)
         buf = self._stage.get((key, arr.shape))
         if buf is None:
@@ -356,10 +360,13 @@ class DenseHead(KerasFitMixin):
         sw = self._sample_weights(y, class_weight, sample_weight)
         swd = self._staged("sw", sw) if sw is not None else None
         n = L.shape[0]
-        _abi.check(self.lib.alink_head_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
-                                                  0.0, 1, _abi.ptr(self._metrics_host), _abi.current_stream(self.device)),
-                   "alink_head_train_step")
-        self.torch.cuda.current_stream(self.device).synchronize()
+        st = self.torch.cuda.current_stream(self._tdev)        # looked up once: launch on it, then wait on it
+        rc = self.lib.alink_head_train_step(self.h, L.data_ptr(), R.data_ptr(), yd.data_ptr(),
+                                            swd.data_ptr() if swd is not None else None, n, 0.0, 1, self._metrics_host_ptr,
+                                            st.cuda_stream)
+        if rc:
+            _abi.check(rc, "alink_head_train_step")
+        st.synchronize()
         return self._metrics_host.tolist()
 
     def input_gradients(self, L, R, y):
