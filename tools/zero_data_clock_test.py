@@ -35,7 +35,30 @@ def main():
     print("random again: %.0f embeddings/s" % rate(p, x))
 
 
-if __name__ == "__main__" and "--dominant" not in sys.argv:
+def soak(mode, seconds=12.0):
+    p = W.synthetic_ir_params(W.R100_UNITS, seed=1)
+    x = torch.randint(0, 256, (1168, 112, 112, 3), dtype=torch.uint8).float().cuda()
+    if mode == "zeros":
+        p = {k: (np.zeros_like(v) if (k.endswith("_weight") or k.endswith("_beta") or k.endswith("_bias") or k.endswith("_moving_mean")) else v)
+             for k, v in p.items()}
+        x = torch.zeros_like(x)
+    bb = IRBackbone(p, max_batch=292, streams=4)
+    out = torch.empty((1168, 512), device="cuda")
+    for _ in range(3):
+        bb.embed_device(x, out)
+    torch.cuda.synchronize()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            bb.embed_device(x, out)
+        torch.cuda.synchronize()
+        n += 20
+    print("%s: %.0f embeddings/s over %.1f s" % (mode, n * 1168 / (time.perf_counter() - t0), time.perf_counter() - t0))
+
+
+if __name__ == "__main__" and "--soak" in sys.argv:
+    soak(sys.argv[sys.argv.index("--soak") + 1])
+elif __name__ == "__main__" and "--dominant" not in sys.argv:
     main()
 
 
