@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libalink_hip.so")
 
-DT_BF16, DT_F16, DT_F32 = 0, 1, 2
+DT_BF16, DT_F16, DT_F32, DT_F16X2 = 0, 1, 2, 3
 LAYOUT_NHWC_F32, LAYOUT_NCHW_F32, LAYOUT_NHWC_U8 = 0, 1, 2
 SCORE_UNCERTAINTY, SCORE_MARGIN, SCORE_ENTROPY, SCORE_DISPARITY = 0, 1, 2, 3
 
@@ -44,6 +44,9 @@ PROTOTYPES = {
     "alink_embed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "alink_backbone_enable_grad": (_i, [_vp]),
     "alink_backbone_set_small_batch_split": (_i, [_vp, _i]),
+    "alink_backbone_calibrate": (_i, [_vp, _vp, _i, _i, _vp, _sz, _i, _vp]),
+    "alink_backbone_range_flag": (_i, [_vp, _i]),
+    "alink_conv_nhwc_x2": (_i, [_vp] * 6 + [_i] * 14 + [_vp]),
     "alink_backbone_grad_workspace_bytes": (_sz, [_vp, _i]),
     "alink_embed_cached": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "alink_embed_input_grad": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),

@@ -13,9 +13,11 @@ from . import weights as W
 
 
 class IRBackbone(object):
+    DTYPES = {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16, "f32": _abi.DT_F32, "f16x2": _abi.DT_F16X2}
+
     def __init__(self, params, image_size=(112, 112), emb=512, dtype="bf16", device=None, max_batch=292,
                  widths=W.WIDTHS, streams=4, shards_per_call=None, bn_eps=2e-5, enable_grad=False,
-                 small_batch_split=False):
+                 small_batch_split=False, lazy_range_check=False):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
@@ -40,12 +42,23 @@ class IRBackbone(object):
         # and selection sets that follow it: DESIGN.md §5) when the network's activations fit its range, else bfloat16
         # (8 significant bits, f32's range: 1 - cos ~3e-4).  The range is probed on three images at build time (uniform
         # noise, all 0, all 255); later inputs that leave it raise AlinkError in embed (never NaN embeddings).
+        #
+        # dtype "f16x2" — SPLIT PRECISION, the mode for selection: every activation and folded weight is an f16 pair
+        # hi + lo (22 significant bits) under a power-of-two scale per tensor, three products on the f16 matrix cores
+        # into f32 accumulators.  The accuracy of the float32 mode (active-learning selection sets identical to the f32
+        # arithmetic: DESIGN.md §5) at about a third of the bf16 rate.  Scales are calibrated on the same three probe
+        # images plus whatever `calibrate()` is given later; they change no bit of any embedding (powers of two), a batch
+        # that leaves the range (32x above the calibration images' largest activation) is re-calibrated and re-run.
         self._shards_fixed = None if shards_per_call is None else int(shards_per_call)
+        self.lazy_range_check = bool(lazy_range_check)
         order = ["f16", "bf16"] if dtype == "auto" else [dtype]
         for dt in order:
-            cfg.dtype = {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16, "f32": _abi.DT_F32}[dt]
+            cfg.dtype = self.DTYPES[dt]
             self.dtype = dt
             self._build(cfg, params, small_batch_split, enable_grad)
+            if dt == "f16x2":
+                self._ws = {}
+                self.calibrate(self._probe_images())
             if dtype != "auto" or dt == "bf16" or self._range_probe_ok():
                 break
             self.lib.alink_backbone_destroy(self.h)
@@ -86,12 +99,32 @@ class IRBackbone(object):
         _abi.check(self.lib.alink_backbone_finalize(self.h), "alink_backbone_finalize")
         self._shards_now = None                       # a new handle: its shard count is not set yet
 
-    def _range_probe_ok(self):
+    def _probe_images(self):
         torch = self.torch
         h, w = self.image_size
         g = torch.Generator(device="cpu").manual_seed(0)
-        x = torch.stack([torch.randint(0, 256, (h, w, 3), generator=g).float(), torch.zeros(h, w, 3),
-                         torch.full((h, w, 3), 255.0)]).to("cuda:%d" % self.device)
+        return torch.stack([torch.randint(0, 256, (h, w, 3), generator=g).float(), torch.zeros(h, w, 3),
+                            torch.full((h, w, 3), 255.0)]).to("cuda:%d" % self.device)
+
+    def calibrate(self, x, merge=False):
+        """dtype 'f16x2': choose the per-tensor power-of-two scales from these images (CUDA tensor or host array in any
+        accepted layout, at most max_batch of them are used).  merge=True only ever lowers a scale."""
+        if self.dtype != "f16x2":
+            raise _abi.AlinkError("only dtype='f16x2' is calibrated")
+        torch = self.torch
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x if x.dtype == np.uint8 else x.astype(np.float32)))
+        x = x[:self.max_batch].to("cuda:%d" % self.device).contiguous()
+        layout = self._layout_of(x, self.image_size)
+        n = x.shape[0]
+        ws, wsb = self._workspace(n)
+        torch.cuda.synchronize(self.device)
+        _abi.check(self.lib.alink_backbone_calibrate(self.h, _abi.ptr(x), layout, n, C.c_void_p(ws), wsb, 1 if merge else 0,
+                                                     _abi.current_stream(self.device)), "alink_backbone_calibrate")
+
+    def _range_probe_ok(self):
+        torch = self.torch
+        x = self._probe_images()
         saved, self.dtype = self.dtype, "probe"       # _checked must not raise here
         self._ws, self._side, self._upload, self.n_streams = {}, None, None, 1
         out = self.embed_device(x)
@@ -134,17 +167,42 @@ class IRBackbone(object):
             return _abi.LAYOUT_NCHW_F32
         raise ValueError("images of shape %s do not match (N,%d,%d,3) / (N,3,%d,%d)" % (tuple(x.shape), h, w, h, w))
 
-    def _checked(self, out):
-        """float16 storage has 5 exponent bits: a network whose activations leave +-65504 (deep nets with
-        synthetic weights do) comes out as NaN.  Fail loudly instead of returning it (bf16 has the range)."""
-        if self.dtype == "f16" and not bool(self.torch.isfinite(out).all()):
+    def range_left(self, reset=True):
+        """True if, since the last reset, some embedding came out non-finite (float16 storage has 5 exponent bits).  The
+        flag is one word of pinned host memory that the last kernel of a forward writes: synchronise first."""
+        return bool(self.lib.alink_backbone_range_flag(self.h, 1 if reset else 0))
+
+    def check_range(self):
+        """Synchronise this device and raise if a float16-storage forward left the range since the last check."""
+        if self.dtype in ("f16", "f16x2"):
+            self.torch.cuda.synchronize(self.device)
+            if self.range_left():
+                raise _abi.AlinkError("activations exceeded the float16 range in this network: build the backbone with "
+                                      "dtype='bf16' (or, for dtype='f16x2', calibrate() on images like these)")
+
+    def _checked(self, out, redo=None):
+        """float16 storage: a network whose activations leave +-65504 (deep nets with synthetic weights do) comes out as
+        NaN.  Fail loudly instead of returning it (bf16 has the range).  The test is a flag the FC-finish kernel raises,
+        read after ONE synchronisation per call — or, with lazy_range_check, only in check_range() and at the start of
+        the next call.  Split precision re-calibrates on the offending batch (scales only go down) and re-runs once."""
+        if self.dtype not in ("f16", "f16x2") or self.lazy_range_check:
+            return out
+        self.torch.cuda.synchronize(self.device)
+        if self.range_left():
+            if self.dtype == "f16x2" and redo is not None:
+                self.calibrate(redo, merge=True)
+                out = self.embed_device(redo, out=out, _retry=False)
+                return out
             raise _abi.AlinkError("activations exceeded the float16 range in this network: build the backbone with dtype='bf16'")
         return out
 
-    def embed_device(self, x, out=None):
+    def embed_device(self, x, out=None, _retry=True):
         """x: CUDA tensor (N,H,W,3) f32|u8 or (N,3,H,W) f32, contiguous.  Returns (N, emb) f32 CUDA."""
         torch = self.torch
         layout = self._layout_of(x, self.image_size)
+        if self.lazy_range_check and self.dtype in ("f16", "f16x2") and self.range_left(reset=False):
+            self.range_left()
+            raise _abi.AlinkError("an earlier forward left the float16 range (lazy_range_check): its embeddings are not finite")
         if not x.is_contiguous():
             x = x.contiguous()
         n = x.shape[0]
@@ -159,7 +217,7 @@ class IRBackbone(object):
                 ws, wsb = self._workspace(m)
                 _abi.check(self.lib.alink_embed(self.h, _abi.ptr(x[i:i + m]), layout, m, _abi.ptr(out[i:i + m]),
                                                 C.c_void_p(ws), wsb, st), "alink_embed")
-            return self._checked(out)
+            return self._checked(out, x if _retry else None)
         if self._side is None:
             self._side = [torch.cuda.Stream(device=x.device) for _ in range(self.n_streams)]
         cur = torch.cuda.current_stream(x.device)
@@ -180,7 +238,7 @@ class IRBackbone(object):
             done = torch.cuda.Event()
             done.record(s)
             cur.wait_event(done)                # results are valid in caller-stream order
-        return self._checked(out)
+        return self._checked(out, x if _retry else None)
 
     # -- input gradient (FGSM / PGD extension) --------------------------------------------------------
     def _grad_workspace(self, n):

@@ -87,6 +87,10 @@ struct ConvParams {
                           // workgroups, same weights, bit-identical sums)
     int stagger;          // linear-tile kernel: the workgroup in the CU's second wave slot starts this many x 1024 cycles late
     int ablate;           // diagnostic timing-only modes of conv3x3_direct (0 = normal)
+    // ALINK_DT_F16X2 only (powers of two, exact): stored value = true value x 2^e, e per tensor.
+    float acc_scale;      // 2^(e_out - e_in - e_w): accumulator -> output units
+    float bias_scale;     // 2^e_out
+    float res_scale;      // 2^(e_out - e_resid)
     void* stamps;         // diagnostic: 4 x u64 s_memtime stamps per workgroup, or nullptr
 };
 
@@ -105,6 +109,8 @@ struct StemParams {
     // (c' = 2 - c when flip: RGB pixels into a BGR-trained network).  IR-ResNet: sub = 127.5, mul = 1/128.
     float sub[3], mul;
     int flip;
+    // ALINK_DT_F16X2: wgt = [64'][hi 32 | lo 32]; the loader stores normalised pixels x 2^8; out = [N][H][W][hi 64 | lo 64]
+    float acc_scale, bias_scale;
 };
 hipError_t launch_stem(int dtype, const StemParams& p, hipStream_t stream);
 
@@ -114,8 +120,11 @@ struct FcFinishParams {
     float*       out;     // [M][E], L2-normalised rows
     float*       norms;   // [M] row norms before normalisation (as divided by: 1 for a zero row), or nullptr
     int S, M, E;
+    float scale;          // the slab sums are multiplied by this before the bias (ALINK_DT_F16X2: 2^-(e_in + e_w); else 1)
+    int*  nonfinite;      // or nullptr: set to 1 when a row comes out non-finite (16-bit range left somewhere upstream)
 };
 hipError_t launch_fc_finish(const FcFinishParams& p, hipStream_t stream);
+hipError_t launch_absmax_f16(const void* x, size_t n_elements, unsigned* out_bits, hipStream_t stream);
 // epilogue of a split-K convolution: p as for the fused launch (out = the real output), slabs [S][M][Cout] f32
 hipError_t launch_conv_split_finish(int dtype, const ConvParams& p, const float* slabs, int S, hipStream_t stream);
 

@@ -61,6 +61,18 @@ uint16_t f32_to_f16_rne(float f) {
 static inline uint16_t cvt(int dtype, float f) {
     return dtype == ALINK_DT_BF16 ? f32_to_bf16_rne(f) : f32_to_f16_rne(f);
 }
+// ALINK_DT_F16X2: x -> f16 pair, hi = RN16(x), lo = RN16(x - hi): |x - hi - lo| <= 2^-22 |x| (while lo stays normal)
+static inline void split16(double x, uint16_t* hi, uint16_t* lo) {
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (double)h);
+    memcpy(hi, &h, 2);
+    memcpy(lo, &l, 2);
+}
+// exponent e with maxabs * 2^e in [1024, 2048): 32x below the f16 overflow threshold, lo = 2^-11 hi still >= 2^-1
+static inline int scale_exp(double maxabs) {
+    if (!(maxabs > 0.0) || !std::isfinite(maxabs)) return 0;
+    return 10 - std::ilogb(maxabs);
+}
 
 hipError_t conv_set_attributes();
 static unsigned long long g_kernels_ready = 0;       // one bit per device (function attributes and the probe are per device)
@@ -94,6 +106,9 @@ struct ConvLayer {
     void* d_wb = nullptr;                   // T [Cin][k*k*Cout], rows permuted for `bvariant`
     int   bvariant = 0;                     // direct variant of the backward convolution (0 = conv_igemm)
     int   role = 0, unit = -1;              // 1 conv1, 2 shortcut, 3 conv2; index of the residual unit
+    // ALINK_DT_F16X2: stored value = true value x 2^e.  e_w is fixed at finalize (folded weights), e_out by
+    // alink_backbone_calibrate (the largest output the calibration images produce lands in [1024, 2048))
+    int   e_w = 0, e_out = 0;
 };
 
 }  // namespace alink
@@ -121,6 +136,12 @@ struct alink_backbone {
     bool grad = false;
     bool split_small = false;   // alink_backbone_set_small_batch_split
     F32Net* f32 = nullptr;      // cfg.dtype == ALINK_DT_F32: the float32 precision mode (backbone_f32.hip) runs every call
+    // ALINK_DT_F16X2 (split precision)
+    bool calibrated = false;
+    int  stem_e_w = 0, stem_e_out = 0, fc_e_w = 0;
+    unsigned* d_absmax = nullptr;           // calibration scratch: bits of the largest |value| of a tensor
+    int* h_flag = nullptr;                  // pinned, device-visible: set by fc_finish when an embedding is not finite
+    int* d_flag = nullptr;                  // the same word as the device addresses it
     void*  d_fc_wb = nullptr;                                  // T [C*Hf*Wf][emb]: FC transposed (rows permuted)
     float* d_stem_wf = nullptr;                                // f32 [64][27] folded stem weights
     float* d_zero_bias = nullptr;                              // zeros, >= 9 * max width floats
@@ -143,6 +164,7 @@ struct alink_backbone {
             if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
         }
         if (ev_start) (void)hipEventDestroy(ev_start);
+        if (h_flag) (void)hipHostFree(h_flag);
     }
 };
 
@@ -186,10 +208,22 @@ int upload(alink_backbone* bb, const std::vector<V>& h, void** d) {
 int build_conv(alink_backbone* bb, ConvLayer& L, const std::vector<float>& w, const BN* pre,
                const BN& post, const std::vector<float>* prelu) {
     const int O = L.Cout, I = L.Cin, k = L.ksz, K = k * k * I, dt = bb->cfg.dtype;
-    L.variant = direct_variant(L.ksz, L.stride, L.pad, L.Hin, L.Win, L.Cin, L.Cout);
+    const bool x2 = dt == ALINK_DT_F16X2;
+    // split precision: the linear-tile kernel where it applies, the implicit-GEMM kernel everywhere else
+    L.variant = x2 ? linear_variant(L.ksz, L.stride, L.pad, L.Hin, L.Win, L.Cin, L.Cout)
+                   : direct_variant(L.ksz, L.stride, L.pad, L.Hin, L.Win, L.Cin, L.Cout);
     const int cpl = L.variant ? direct_variant_cpl(L.variant) : 16;
-    std::vector<uint16_t> wq((size_t)O * K);
+    std::vector<uint16_t> wq((size_t)O * K * (x2 ? 2 : 1));
     std::vector<double> tapb((size_t)k * k * O, 0.0);          // [tap][co] shift contribution
+    if (x2) {
+        double mx = 0.0;
+        for (int co = 0; co < O; ++co)
+            for (int ci = 0; ci < I; ++ci)
+                for (int t = 0; t < k * k; ++t)
+                    mx = std::max(mx, std::fabs(post.a[co] * (double)w[((size_t)co * I + ci) * k * k + t] * (pre ? pre->a[ci] : 1.0)));
+        L.e_w = scale_exp(mx);
+    }
+    const double wscale = std::ldexp(1.0, L.e_w);
     for (int co = 0; co < O; ++co) {
         const int row = permuted_row(co, cpl);
         for (int ky = 0; ky < k; ++ky)
@@ -200,6 +234,16 @@ int build_conv(alink_backbone* bb, ConvLayer& L, const std::vector<float>& w, co
                     const double ai = pre ? pre->a[ci] : 1.0;
                     // K order: conv_igemm walks tap-major [tap][ci]; conv3x3_direct walks 64-channel
                     // chunks outermost [ci/64][tap][ci%64]
+                    if (x2) {
+                        // rows of 2K: linear kernel [chunk][hi | lo][tap][64], implicit GEMM [tap][chunk][hi 64 | lo 64]
+                        const int tap = ky * k + kx, cc = ci >> 6;
+                        const size_t khi = L.variant ? (((size_t)cc * 2) * 9 + tap) * 64 + (ci & 63)
+                                                     : (((size_t)tap * (I >> 6) + cc) * 2) * 64 + (ci & 63);
+                        const size_t klo = khi + (L.variant ? 9 * 64 : 64);
+                        split16(post.a[co] * wv * ai * wscale, &wq[(size_t)row * 2 * K + khi], &wq[(size_t)row * 2 * K + klo]);
+                        if (pre) tb += wv * pre->b[ci];
+                        continue;
+                    }
                     const size_t kidx = L.variant ? ((size_t)(ci >> 6) * 9 + (ky * 3 + kx)) * 64 + (ci & 63)
                                                   : (size_t)(ky * k + kx) * I + ci;
                     wq[(size_t)row * K + kidx] = cvt(dt, (float)(post.a[co] * wv * ai));
@@ -292,7 +336,10 @@ alink_backbone_t* alink_backbone_create(const alink_ir_cfg* cfg) {
         set_error("input size %dx%d must be a multiple of 16 (four stride-2 stages)", cfg->height, cfg->width);
         return nullptr;
     }
-    if (cfg->dtype != ALINK_DT_BF16 && cfg->dtype != ALINK_DT_F16 && cfg->dtype != ALINK_DT_F32) { set_error("bad dtype"); return nullptr; }
+    if (cfg->dtype != ALINK_DT_BF16 && cfg->dtype != ALINK_DT_F16 && cfg->dtype != ALINK_DT_F32 && cfg->dtype != ALINK_DT_F16X2) {
+        set_error("bad dtype");
+        return nullptr;
+    }
     alink_backbone* bb = new alink_backbone();
     bb->device = current_device();
     bb->cfg = *cfg;
@@ -390,6 +437,16 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
         return ALINK_OK;
     }
 
+    const bool x2 = dt == ALINK_DT_F16X2;
+    if (x2) {
+        ALINK_REQUIRE(!bb->grad && !bb->split_small, ALINK_ESTATE, "the split-precision mode has no gradient pass and no small-batch split");
+        ALINK_HIP(hipMalloc((void**)&bb->d_absmax, 256));
+        bb->allocs.push_back(bb->d_absmax);
+    }
+    ALINK_HIP(hipHostMalloc((void**)&bb->h_flag, 64, hipHostMallocMapped));
+    *bb->h_flag = 0;
+    ALINK_HIP(hipHostGetDevicePointer((void**)&bb->d_flag, bb->h_flag, 0));
+
     // zero page
     ALINK_HIP(hipMalloc(&bb->d_zero, 4096));
     bb->allocs.push_back(bb->d_zero);
@@ -400,14 +457,23 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
     {
         const auto& cw = bb->raw.at("conv0_weight");
         const BN bn0 = get_bn(bb, "bn0", false);
-        std::vector<uint16_t> wq((size_t)64 * 32, cvt(dt, 0.f));
+        std::vector<uint16_t> wq((size_t)64 * 32 * (x2 ? 2 : 1), x2 ? (uint16_t)0 : cvt(dt, 0.f));
+        if (x2) {
+            double mx = 0.0;
+            for (int co = 0; co < 64; ++co)
+                for (int i = 0; i < 27; ++i) mx = std::max(mx, std::fabs(bn0.a[co] * (double)cw[(size_t)co * 27 + i]));
+            bb->stem_e_w = scale_exp(mx);
+        }
         for (int co = 0; co < 64; ++co) {
             const int row = perm64_row_of_channel(co);
             for (int c = 0; c < 3; ++c)
                 for (int ky = 0; ky < 3; ++ky)
-                    for (int kx = 0; kx < 3; ++kx)
-                        wq[(size_t)row * 32 + ky * 9 + kx * 3 + c] =
-                            cvt(dt, (float)(bn0.a[co] * (double)cw[(((size_t)co * 3 + c) * 3 + ky) * 3 + kx]));
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const double v = bn0.a[co] * (double)cw[(((size_t)co * 3 + c) * 3 + ky) * 3 + kx];
+                        const int kk = ky * 9 + kx * 3 + c;
+                        if (x2) split16(std::ldexp(v, bb->stem_e_w), &wq[(size_t)row * 64 + kk], &wq[(size_t)row * 64 + 32 + kk]);
+                        else    wq[(size_t)row * 32 + kk] = cvt(dt, (float)v);
+                    }
         }
         std::vector<float> bias(64);
         for (int co = 0; co < 64; ++co) bias[co] = (float)bn0.b[co];
@@ -495,15 +561,29 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
         const auto& fw = bb->raw.at("pre_fc1_weight");
         const auto& fb = bb->raw.at("pre_fc1_bias");
         const BN bnl = get_bn(bb, "bn1", false), bfc = get_bn(bb, "fc1", true);
-        std::vector<uint16_t> wq((size_t)E * K);
+        std::vector<uint16_t> wq((size_t)E * K * (x2 ? 2 : 1));
         std::vector<float> bias(E);
+        if (x2) {
+            double mx = 0.0;
+            for (int o = 0; o < E; ++o)
+                for (int ch = 0; ch < C; ++ch)
+                    for (int pos = 0; pos < HW; ++pos)
+                        mx = std::max(mx, std::fabs(bfc.a[o] * (double)fw[(size_t)o * K + (size_t)ch * HW + pos] * bnl.a[ch]));
+            bb->fc_e_w = scale_exp(mx);
+        }
         for (int o = 0; o < E; ++o) {
             const int row = (o & ~63) + perm64_row_of_channel(o & 63);
             double b = (double)fb[o];
             for (int ch = 0; ch < C; ++ch)
                 for (int pos = 0; pos < HW; ++pos) {
                     const double wv = (double)fw[(size_t)o * K + (size_t)ch * HW + pos];
-                    wq[(size_t)row * K + (size_t)pos * C + ch] = cvt(dt, (float)(bfc.a[o] * wv * bnl.a[ch]));
+                    const size_t kk = (size_t)pos * C + ch;
+                    if (x2) {
+                        const size_t khi = (kk >> 6) * 128 + (kk & 63);
+                        split16(std::ldexp(bfc.a[o] * wv * bnl.a[ch], bb->fc_e_w), &wq[(size_t)row * 2 * K + khi], &wq[(size_t)row * 2 * K + khi + 64]);
+                    } else {
+                        wq[(size_t)row * K + kk] = cvt(dt, (float)(bfc.a[o] * wv * bnl.a[ch]));
+                    }
                     b += wv * bnl.b[ch];
                 }
             bias[o] = (float)(bfc.a[o] * b + bfc.b[o]);
@@ -528,7 +608,7 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
         int S = nk / 14;                         // ~14 K-steps per split
         if (S < 1) S = 1;
         if (S > 64) S = 64;
-        bb->fc_kps = (nk + S - 1) / S;
+        bb->fc_kps = (nk + S - 1) / S;                  // real K-steps per split (split precision walks 3 per real step)
         bb->fc_splitk = (nk + bb->fc_kps - 1) / bb->fc_kps;
         bb->Hf = H;
         bb->Wf = W;
@@ -559,13 +639,15 @@ constexpr size_t SPLIT_SLAB_BYTES = (size_t)8 << 20;
 // workspace layout: [big0][big1][small2][small3][small4][fc slabs][conv split-K slabs (small N only)]
 static void ws_layout(const alink_backbone* bb, int N, size_t off[7], size_t* total) {
     const alink_ir_cfg& c = bb->cfg;
-    const size_t big = (size_t)N * c.height * c.width * c.widths[0] * 2;
+    const size_t esz = c.dtype == ALINK_DT_F16X2 ? 4 : 2;          // split precision: an f16 pair per value
+    // big buffers: the stem output (widths[0]) and the first unit's conv1 output (widths[1]) at input resolution
+    const size_t big = (size_t)N * c.height * c.width * std::max(c.widths[0], c.widths[1]) * esz;
     // small buffers hold shortcut and unit outputs (conv1 outputs always go to big buffer 1)
     size_t small = 0;
     int H = c.height, W = c.width;
     for (int s = 0; s < 4; ++s) {
         const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-        small = std::max(small, (size_t)N * Ho * Wo * c.widths[s + 1] * 2);
+        small = std::max(small, (size_t)N * Ho * Wo * c.widths[s + 1] * esz);
         H = Ho;
         W = Wo;
     }
@@ -667,9 +749,11 @@ extern "C" void alink_debug_set_profile_reps(int n) { g_prof_reps = n < 1 ? 1 : 
 extern "C" void alink_debug_set_ablate(int a) { g_ablate = a; }
 extern "C" void alink_debug_set_stamps(void* p) { g_stamps = p; }
 
+// calib (ALINK_DT_F16X2 only): 0 = a normal forward; 1 = choose every tensor's scale exponent from this batch; 2 = the
+// same, never above the exponents already held (re-calibration after a batch left the range).  Synchronous when != 0.
 static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int N, float* dev_out,
                       void* ws, size_t ws_bytes, hipStream_t stream, float* ms, double* flops, int* kind,
-                      int* n_launches, const GradLayout* cache = nullptr) {
+                      int* n_launches, const GradLayout* cache = nullptr, int calib = 0) {
     ALINK_REQUIRE(bb && dev_in && dev_out && ws, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(bb->finalized, ALINK_ESTATE, "alink_embed before alink_backbone_finalize");
     ALINK_REQUIRE(N > 0, ALINK_EINVAL, "n_images must be positive");
@@ -705,16 +789,57 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
     int rc;
     if ((rc = mark())) return rc;
 
+    const bool x2 = cfg.dtype == ALINK_DT_F16X2;
+    ALINK_REQUIRE(!calib || x2, ALINK_ESTATE, "only the split-precision mode is calibrated");
+    ALINK_REQUIRE(!x2 || calib || bb->calibrated, ALINK_ESTATE, "split-precision backbone: alink_backbone_calibrate has not run");
+    int bexp[5] = {0, 0, 0, 0, 0};        // split precision: scale exponent of the tensor each workspace buffer holds
+    // calibration: run `launch(e)` with the output exponent e until the largest |output| lies in [1024, 2048) (f16 pairs:
+    // 32x below overflow, lo halves normal); a power-of-two scale changes no bit of the result, only where it sits
+    auto settle = [&](int* e_io, const void* out, size_t n_elems, auto&& launch) -> int {
+        int e = *e_io;
+        for (int attempt = 0; attempt < 24; ++attempt) {
+            const int rcl = launch(e);
+            if (rcl) return rcl;
+            if (!calib) break;
+            unsigned bits = 0;
+            ALINK_HIP(hipMemsetAsync(bb->d_absmax, 0, 4, stream));
+            ALINK_HIP(launch_absmax_f16(out, n_elems, bb->d_absmax, stream));
+            ALINK_HIP(hipMemcpyAsync(&bits, bb->d_absmax, 4, hipMemcpyDeviceToHost, stream));
+            ALINK_HIP(hipStreamSynchronize(stream));
+            float m;
+            memcpy(&m, &bits, 4);
+            if (bits >= 0x7f800000u) { e -= 8; continue; }                 // left the range: lower the scale and redo
+            if (m == 0.f) break;
+            int want = e + (10 - std::ilogb(m));
+            if (calib == 2 && bb->calibrated) want = std::min(want, *e_io);
+            if (want == e) break;
+            e = want;
+        }
+        *e_io = e;
+        return ALINK_OK;
+    };
+
     StemParams sp{};
     sp.in = dev_in; sp.wgt = bb->d_stem_w; sp.bias = bb->d_stem_bias; sp.alpha = bb->d_stem_alpha;
     sp.out = buf(0); sp.N = N; sp.H = cfg.height; sp.W = cfg.width; sp.C0 = 64; sp.layout = layout;
     sp.sub[0] = sp.sub[1] = sp.sub[2] = 127.5f; sp.mul = 0.0078125f; sp.flip = 0;
-    for (int r = 0; r < reps; ++r) ALINK_HIP(launch_stem(cfg.dtype, sp, stream));
+    if (x2) {
+        rc = settle(&bb->stem_e_out, buf(0), (size_t)N * cfg.height * cfg.width * 128, [&](int e) -> int {
+            sp.acc_scale = std::ldexp(1.f, e - 8 - bb->stem_e_w);          // the loader stores normalised pixels x 2^8
+            sp.bias_scale = std::ldexp(1.f, e);
+            for (int r = 0; r < reps; ++r) ALINK_HIP(launch_stem(cfg.dtype, sp, stream));
+            return ALINK_OK;
+        });
+        if (rc) return rc;
+        bexp[0] = bb->stem_e_out;
+    } else {
+        for (int r = 0; r < reps; ++r) ALINK_HIP(launch_stem(cfg.dtype, sp, stream));
+    }
     note(2.0 * N * cfg.height * cfg.width * 64.0 * 27.0, 0);
     if ((rc = mark())) return rc;
 
     int last_out = 0;
-    for (const ConvLayer& L : bb->convs) {
+    for (ConvLayer& L : bb->convs) {
         ConvParams p{};
         p.in = buf(L.in_buf); p.wgt = L.d_w; p.bias = L.d_bias; p.alpha = L.d_alpha;
         p.resid = L.resid_buf >= 0 ? buf(L.resid_buf) : nullptr;
@@ -737,6 +862,21 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
             p.fine = nwg128 <= g_fine_max ? 1 : 0;
         }
         const int S = plan_split(bb, L, N);
+        if (x2) {
+            p.ksteps_per_split *= 3;
+            rc = settle(&L.e_out, p.out, (size_t)p.M * L.Cout * 2, [&](int e) -> int {
+                p.acc_scale = std::ldexp(1.f, e - bexp[L.in_buf] - L.e_w);
+                p.bias_scale = std::ldexp(1.f, e);
+                p.res_scale = L.resid_buf >= 0 ? std::ldexp(1.f, e - bexp[L.resid_buf]) : 1.f;
+                for (int r = 0; r < reps; ++r) {
+                    if (L.variant) ALINK_HIP(launch_conv3x3_direct(L.variant, cfg.dtype, p, stream));
+                    else           ALINK_HIP(launch_conv_igemm(cfg.dtype, p, stream));
+                }
+                return ALINK_OK;
+            });
+            if (rc) return rc;
+            bexp[L.out_buf] = L.e_out;
+        } else
         for (int r = 0; r < reps; ++r) {
             ConvParams q = p;
             if (S > 1) {
@@ -758,7 +898,7 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         p.out = buf(5); p.zero = bb->d_zero;
         p.N = N; p.H = 1; p.W = 1; p.Cin = bb->fc_K; p.Cout = cfg.emb; p.Ho = 1; p.Wo = 1;
         p.stride = 1; p.ksz = 1; p.pad = 0; p.M = N; p.border_cls = 0;
-        p.splitk = bb->fc_splitk; p.ksteps_per_split = bb->fc_kps;
+        p.splitk = bb->fc_splitk; p.ksteps_per_split = bb->fc_kps * (x2 ? 3 : 1);
         ALINK_REQUIRE(p.splitk > 1, ALINK_EINVAL, "FC split-K must be > 1 (K=%d)", bb->fc_K);
         for (int r = 0; r < reps; ++r) ALINK_HIP(launch_conv_igemm(cfg.dtype, p, stream));
         note(conv_flops(p), 2);
@@ -767,6 +907,8 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         f.slabs = (const float*)buf(5); f.bias = bb->d_fc_bias; f.out = dev_out;
         f.norms = cache ? (float*)(base + cache->norms) : nullptr;
         f.S = bb->fc_splitk; f.M = N; f.E = cfg.emb;
+        f.scale = x2 ? std::ldexp(1.f, -(bexp[last_out] + bb->fc_e_w)) : 1.f;
+        f.nonfinite = bb->d_flag;       // 16-bit storage: an activation beyond the range ends as a non-finite embedding
         for (int r = 0; r < reps; ++r) ALINK_HIP(launch_fc_finish(f, stream));
         note(0.0, 3);
         if ((rc = mark())) return rc;
@@ -781,6 +923,11 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         }
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
         *n_launches = nl;
+    }
+    if (calib) {
+        ALINK_HIP(hipStreamSynchronize(stream));
+        ALINK_REQUIRE(*bb->h_flag == 0, ALINK_EINVAL, "calibration batch produced non-finite embeddings");
+        bb->calibrated = true;
     }
     return ALINK_OK;
 }
@@ -831,6 +978,31 @@ int alink_embed_profile(alink_backbone_t* bb, const void* dev_in, int layout, in
     DeviceGuard dg(bb->device);
     return embed_impl(bb, dev_in, layout, n_images, dev_out, dev_workspace, workspace_bytes,
                       (hipStream_t)stream, ms, flops, kind, n_launches);
+}
+
+int alink_backbone_calibrate(alink_backbone_t* bb, const void* dev_in, int layout, int n_images, void* dev_workspace,
+                             size_t workspace_bytes, int merge, void* stream) {
+    ALINK_REQUIRE(bb && bb->finalized, ALINK_ESTATE, "alink_backbone_calibrate before alink_backbone_finalize");
+    ALINK_REQUIRE(bb->cfg.dtype == ALINK_DT_F16X2, ALINK_ESTATE, "only the split-precision mode (ALINK_DT_F16X2) is calibrated");
+    ALINK_REQUIRE(dev_in && dev_workspace && n_images > 0, ALINK_EINVAL, "bad argument");
+    DeviceGuard dg(bb->device);
+    hipStream_t st = (hipStream_t)stream;
+    ALINK_HIP(hipStreamSynchronize(st));
+    *bb->h_flag = 0;
+    float* scratch = nullptr;           // the embeddings of the calibration batch are not wanted
+    ALINK_HIP(hipMalloc((void**)&scratch, (size_t)n_images * bb->cfg.emb * sizeof(float)));
+    const int rc = embed_impl(bb, dev_in, layout, n_images, scratch, dev_workspace, workspace_bytes, st, nullptr, nullptr,
+                              nullptr, nullptr, nullptr, merge ? 2 : 1);
+    (void)hipFree(scratch);
+    return rc;
+}
+
+int alink_backbone_range_flag(alink_backbone_t* bb, int reset) {
+    ALINK_REQUIRE(bb && bb->finalized, ALINK_ESTATE, "alink_backbone_range_flag before alink_backbone_finalize");
+    if (!bb->h_flag) return 0;          // float32 mode: nothing to leave
+    const int v = *(volatile int*)bb->h_flag != 0 ? 1 : 0;
+    if (reset) *(volatile int*)bb->h_flag = 0;
+    return v;
 }
 
 // ---- input gradient (FGSM / PGD extension) ------------------------------------------------------------
@@ -991,6 +1163,100 @@ int alink_conv_nhwc(int dtype, const void* dev_in, const void* dev_w, const floa
     (void)hipFree(d_zero);
     if (e != hipSuccess) return hip_fail(e, "launch_conv_igemm", __FILE__, __LINE__);
     if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize", __FILE__, __LINE__);
+    return ALINK_OK;
+}
+
+
+// Split-precision twin of alink_conv_nhwc (unit tests): float32 tensors in natural layouts on the device, converted
+// to / from the f16-pair layouts on the HOST (synchronous, test use only).  Stored value = true value x 2^e.
+int alink_conv_nhwc_x2(const float* dev_in, const float* dev_w, const float* dev_bias, const float* dev_alpha,
+                       const float* dev_resid, float* dev_out, int N, int H, int W, int Cin, int Cout, int ksz, int stride,
+                       int pad, int border_cls, int fine, int e_in, int e_w, int e_out, int e_res, void* stream) {
+    ALINK_REQUIRE(dev_in && dev_w && dev_bias && dev_out, ALINK_EINVAL, "NULL argument");
+    DeviceGuard dg(device_of_pointer(dev_in));
+    ALINK_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, ALINK_EINVAL, "Cin/Cout must be multiples of 64");
+    ALINK_REQUIRE(ksz == 1 || ksz == 3, ALINK_EINVAL, "ksz must be 1 or 3");
+    ALINK_REQUIRE(!border_cls || (ksz == 3 && stride == 1 && pad == 1), ALINK_EINVAL,
+                  "border classes need a 3x3 stride-1 pad-1 convolution");
+    int rc = init_kernels();
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ALINK_HIP(hipStreamSynchronize(st));
+    const int K = ksz * ksz * Cin, Ho = conv_out(H, ksz, stride, pad), Wo = conv_out(W, ksz, stride, pad);
+    const size_t Min = (size_t)N * H * W, M = (size_t)N * Ho * Wo;
+    const int variant = linear_variant(ksz, stride, pad, H, W, Cin, Cout);
+    const int cpl = variant ? direct_variant_cpl(variant) : 16;
+    auto pack_act = [&](const float* dev, size_t rows, int C, int e, std::vector<uint16_t>& q) -> int {
+        std::vector<float> h(rows * C);
+        ALINK_HIP(hipMemcpy(h.data(), dev, h.size() * 4, hipMemcpyDeviceToHost));
+        q.assign(rows * C * 2, 0);
+        for (size_t m = 0; m < rows; ++m)
+            for (int c = 0; c < C; ++c) {
+                const size_t at = m * 2 * C + (size_t)(c >> 6) * 128 + (c & 63);
+                split16(std::ldexp((double)h[m * C + c], e), &q[at], &q[at + 64]);
+            }
+        return ALINK_OK;
+    };
+    std::vector<uint16_t> qin, qres, qw((size_t)Cout * K * 2);
+    if ((rc = pack_act(dev_in, Min, Cin, e_in, qin))) return rc;
+    if (dev_resid && (rc = pack_act(dev_resid, M, Cout, e_res, qres))) return rc;
+    {
+        std::vector<float> h((size_t)Cout * K);
+        ALINK_HIP(hipMemcpy(h.data(), dev_w, h.size() * 4, hipMemcpyDeviceToHost));
+        for (int co = 0; co < Cout; ++co) {
+            const size_t r = (size_t)permuted_row(co, cpl) * 2 * K;
+            for (int tap = 0; tap < ksz * ksz; ++tap)
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const int cc = ci >> 6;
+                    const size_t khi = variant ? (((size_t)cc * 2) * 9 + tap) * 64 + (ci & 63)
+                                               : (((size_t)tap * (Cin >> 6) + cc) * 2) * 64 + (ci & 63);
+                    split16(std::ldexp((double)h[(size_t)co * K + (size_t)tap * Cin + ci], e_w), &qw[r + khi],
+                            &qw[r + khi + (variant ? 9 * 64 : 64)]);
+                }
+        }
+    }
+    void *d_in = nullptr, *d_res = nullptr, *d_w = nullptr, *d_out = nullptr, *d_zero = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_in); (void)hipFree(d_res); (void)hipFree(d_w); (void)hipFree(d_out); (void)hipFree(d_zero); };
+#define X2_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return hip_fail(e__, #call, __FILE__, __LINE__); } } while (0)
+    X2_TRY(hipMalloc(&d_in, qin.size() * 2));
+    X2_TRY(hipMalloc(&d_w, qw.size() * 2));
+    X2_TRY(hipMalloc(&d_out, M * Cout * 4));
+    X2_TRY(hipMalloc(&d_zero, 4096));
+    X2_TRY(hipMemcpy(d_in, qin.data(), qin.size() * 2, hipMemcpyHostToDevice));
+    X2_TRY(hipMemcpy(d_w, qw.data(), qw.size() * 2, hipMemcpyHostToDevice));
+    X2_TRY(hipMemset(d_zero, 0, 4096));
+    if (dev_resid) {
+        X2_TRY(hipMalloc(&d_res, qres.size() * 2));
+        X2_TRY(hipMemcpy(d_res, qres.data(), qres.size() * 2, hipMemcpyHostToDevice));
+    }
+    ConvParams p{};
+    p.in = d_in; p.wgt = d_w; p.bias = dev_bias; p.alpha = dev_alpha; p.resid = d_res; p.out = d_out;
+    p.zero = d_zero; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Ho = Ho; p.Wo = Wo;
+    p.stride = stride; p.ksz = ksz; p.pad = pad; p.M = (int)M; p.border_cls = border_cls;
+    p.splitk = 1; p.ksteps_per_split = 3 * ksz * ksz * (Cin / 64);
+    p.acc_scale = std::ldexp(1.f, e_out - e_in - e_w);
+    p.bias_scale = std::ldexp(1.f, e_out);
+    p.res_scale = std::ldexp(1.f, e_out - e_res);
+    if (variant == 11 || variant == 12 || variant == 14) {
+        const long long nwg128 = (((long long)p.M + 223) / 224) * (Cout / 128);
+        p.fine = fine < 0 ? (nwg128 <= g_fine_max ? 1 : 0) : (fine ? 1 : 0);
+    }
+    X2_TRY(variant ? launch_conv3x3_direct(variant, ALINK_DT_F16X2, p, st) : launch_conv_igemm(ALINK_DT_F16X2, p, st));
+    X2_TRY(hipStreamSynchronize(st));
+    std::vector<uint16_t> qo(M * Cout * 2);
+    X2_TRY(hipMemcpy(qo.data(), d_out, qo.size() * 2, hipMemcpyDeviceToHost));
+    std::vector<float> ho(M * Cout);
+    for (size_t m = 0; m < M; ++m)
+        for (int c = 0; c < Cout; ++c) {
+            const size_t at = m * 2 * Cout + (size_t)(c >> 6) * 128 + (c & 63);
+            _Float16 hh, ll;
+            memcpy(&hh, &qo[at], 2);
+            memcpy(&ll, &qo[at + 64], 2);
+            ho[m * Cout + c] = (float)std::ldexp((double)hh + (double)ll, -e_out);
+        }
+    X2_TRY(hipMemcpy(dev_out, ho.data(), ho.size() * 4, hipMemcpyHostToDevice));
+#undef X2_TRY
+    cleanup();
     return ALINK_OK;
 }
 

@@ -284,7 +284,7 @@ int f32net_embed(const F32Net* n, const void* dev_in, int layout, int N, float* 
         ALINK_HIP(launch_gemm32(g, gws, st));
         FcFinishParams f{};
         f.slabs = (const float*)(base + WL.fc); f.bias = n->d_fc_bias; f.out = dev_out; f.norms = nullptr;
-        f.S = 1; f.M = N; f.E = n->emb;
+        f.S = 1; f.M = N; f.E = n->emb; f.scale = 1.f;
         ALINK_HIP(launch_fc_finish(f, st));
     }
     ALINK_HIP(hipGetLastError());

@@ -423,6 +423,7 @@ hipError_t direct_set_attributes() {
 
 hipError_t launch_conv3x3_direct(int variant, int dtype, const ConvParams& p, hipStream_t st) {
     if (variant >= 11) return launch_conv3x3_linear(variant, dtype, p, st);
+    if (dtype != ALINK_DT_BF16 && dtype != ALINK_DT_F16) return hipErrorInvalidValue;   // no split-precision form of these
     if (p.ksz != 3 || p.stride != 1 || p.pad != 1 || p.splitk != 1) return hipErrorInvalidValue;
     if ((long long)p.N * p.H * p.W * p.Cin >= (1ll << 31)) return hipErrorInvalidValue;
 #define L(V) (dtype == ALINK_DT_BF16 ? V::launch<__bf16>(p, st) : V::launch<_Float16>(p, st))

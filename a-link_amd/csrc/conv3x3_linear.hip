@@ -85,7 +85,13 @@ struct Lin {
 // EPI: the epilogue a launch needs, fixed at compile time for the two forms the forward pass uses — 1: bias + PReLU
 // (a unit's conv1), 2: bias + residual (conv2) — so that neither carries the other's loads, selects and branches;
 // 0: every mode by run-time flags (PReLU', post-ReLU, split partial sums, both at once).
-template <typename T, int W, int TCW, int EPI>
+//
+// SP (T = _Float16 only): the split-precision mode ALINK_DT_F16X2 — every value an f16 pair hi + lo.  Activations are
+// [pixel][2 Cin], each 64-channel chunk stored as [hi 64 | lo 64]; weights [Cout][chunk][hi: 9 taps x 64 | lo: 9 taps x 64].
+// A chunk is walked three times — X = hi against W_hi, X = hi against W_lo, X = lo against W_hi — into the same f32
+// accumulators (27 K-steps per chunk instead of 9, two input refills instead of one); the dropped lo x W_lo term is 2^-22
+// of the sum.  Power-of-two scales per tensor (ConvParams::acc_scale, bias_scale, res_scale) keep hi in range and lo normal.
+template <typename T, int W, int TCW, int EPI, bool SP>
 __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams p) {
     typedef typename Vec8<T>::type vec8;
     typedef Lin<W, TCW> G;
@@ -117,10 +123,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     // split mode (small batches: too few workgroups to fill the chip): blockIdx.y owns ncc / splitk of the
     // 64-channel input chunks and leaves its f32 partial sums in slab blockIdx.y (conv_split_finish_kernel
     // adds the slabs in order and applies the epilogue)
+    constexpr int NPH = SP ? 3 : 1;
+    const int CinP = SP ? 2 * Cin : Cin;                               // pixel pitch of the input tensor in elements
     const int ncc_all = Cin >> 6;
     const int ncc = ncc_all / p.splitk, cc_first = (int)blockIdx.y * ncc;
-    const int nk = ncc * 9;
-    const int K = 9 * Cin;
+    const int nk = ncc * 9 * NPH;
+    const int K = 9 * CinP;                                            // weight row pitch
     const long long totpix = (long long)p.N * H * W;
 
     const int ntn = p.Cout / BN;
@@ -139,24 +147,31 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     const int xpos0 = tid >> 3;
     const int xc16 = (tid & 7) ^ ((tid >> 4) & 7);
     const long long xgp0 = gp0 - W - 1 + xpos0;                        // pixel of slot 0
-    auto stage_x = [&](int cc) {
+    auto stage_x = [&](int cc, int part = 0) {     // part (SP): 0 = the chunk's hi half, 1 = its lo half
 #pragma unroll
         for (int i = 0; i < XSLOTS; ++i) {
             const long long gp = xgp0 + 32 * i;
             const bool ok = xpos0 + 32 * i < G::XPIX && gp >= 0 && gp < totpix;
-            const T* src = ok ? gin + ((size_t)gp * Cin + cc * 64 + xc16 * 8) : gz + (lane & 7) * 8;
+            const T* src = ok ? gin + ((size_t)gp * CinP + (SP ? 2 * cc + part : cc) * 64 + xc16 * 8) : gz + (lane & 7) * 8;
             dma16(src, smem + (NT * i + wave * 64) * 16);
         }
     };
     // ---- W staging (K-step order [cout][chunk][tap][64], as conv3x3_direct): slot s = tid + 256 i -> row
     // (tid >> 3) + 32 i, piece tid & 7, again with an i-independent swizzle term ------------------------------------
     const unsigned woff0 = (unsigned)((tid >> 3) * K + (((tid & 7) ^ ((tid >> 4) & 7)) * 8));
-    const T* wstep = gw + (size_t)n0 * K + (size_t)cc_first * 9 * 64;   // advanced by 64 elements per K-step (uniform)
+    const T* wstep = gw + (size_t)n0 * K + (size_t)cc_first * (SP ? 18 : 9) * 64;   // advanced by 64 elements per K-step (uniform)
+    int wr = 0;       // SP: position of the K-step being staged inside its chunk's 27 (hi taps, lo taps, hi taps again)
     auto stage_w = [&](int bufoff) {
 #pragma unroll
         for (int i = 0; i < WSLOTS; ++i)
             dma16(wstep + (woff0 + (unsigned)(32 * i * K)), smem + G::WOFF + bufoff + (NT * i + wave * 64) * 16);
-        wstep += 64;
+        if (SP) {
+            // blocks of the chunk: 0..8 hi, 9..17 lo; the walk is 0..17, back to 0..8, then on to the next chunk (18)
+            wstep += wr == 17 ? -17 * 64 : (wr == 26 ? 10 * 64 : 64);
+            wr = wr == 26 ? 0 : wr + 1;
+        } else {
+            wstep += 64;
+        }
     };
 
     // The first input span and the first weight tile are requested NOW: the per-lane border bits (integer divisions),
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     const int ncls = p.border_cls ? 9 : 1;
     float* const ebias = (float*)(smem + G::WOFF + 2 * WBYTES);
     float* const ealpha = ebias + 9 * BN;
-    for (int i = tid; i < ncls * BN; i += NT) ebias[i] = p.bias[(i / BN) * p.Cout + n0 + (i % BN)];
+    for (int i = tid; i < ncls * BN; i += NT) ebias[i] = p.bias[(i / BN) * p.Cout + n0 + (i % BN)] * (SP ? p.bias_scale : 1.f);
     if (p.alpha)
         for (int i = tid; i < BN; i += NT) ealpha[i] = p.alpha[n0 + i];
     wait_dma_then_barrier();
@@ -208,11 +223,13 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
 
     int wtog = 0;
     for (int cc = 0; cc < ncc; ++cc) {
+#pragma unroll 1
+      for (int ph = 0; ph < NPH; ++ph) {
         auto step = [&](auto tapc) {
             constexpr int tap = decltype(tapc)::a;
             constexpr int ky = tap / 3, kx = tap % 3;
             constexpr unsigned tapbits = (ky == 0 ? 1u : 0u) | (ky == 2 ? 2u : 0u) | (kx == 0 ? 4u : 0u) | (kx == 2 ? 8u : 0u);
-            const int t = cc * 9 + tap;
+            const int t = (cc * NPH + ph) * 9 + tap;
             if (t + 1 < nk) stage_w(wtog ^ WBYTES);
             // A lane whose pixel lies on the border this tap crosses must read zeros: its border bits, shifted
             // up to 2^18 and beyond, are ADDED to its operand address, which then lies outside the workgroup's
@@ -248,14 +265,18 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
         step(IC<0>{}); step(IC<1>{}); step(IC<2>{});
         step(IC<3>{}); step(IC<4>{}); step(IC<5>{});
         step(IC<6>{}); step(IC<7>{}); step(IC<8>{});
-        if (cc + 1 < ncc) {
+        // SP: the hi half serves phases 0 and 1, the lo half phase 2
+        const bool next_chunk = ph == NPH - 1;
+        if (next_chunk ? cc + 1 < ncc : ph == 1) {
             // single X buffer: every wave is past its last read of this chunk; refill and wait — the
             // co-resident workgroup keeps the matrix cores busy meanwhile
             const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-            stage_x(cc_first + cc + 1);
+            if (next_chunk) stage_x(cc_first + cc + 1, 0);
+            else            stage_x(cc_first + cc, 1);
             wait_dma_then_barrier();
             if (stamps) refill_cycles += __builtin_amdgcn_s_memtime() - t0;
         }
+      }
     }
     if (stamps && tid == 0) {
         stamps[(size_t)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
@@ -268,7 +289,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     const int wbase = wco * (16 * TCW);
     auto chan_t = [&](int t) { return wbase + (TCW == 4 ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) : 8 * q + 4 * t); };
     auto chan_h = [&](int h) { return wbase + (TCW == 4 ? 32 * h + 8 * q : 8 * q); };
-    if (EPI == 0 && p.splitk > 1) {
+    if (!SP && EPI == 0 && p.splitk > 1) {
         float* slab = (float*)p.out + (size_t)blockIdx.y * (size_t)totpix * p.Cout;
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
@@ -276,6 +297,78 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
             if (gp < totpix) {
 #pragma unroll
                 for (int t = 0; t < TCW; ++t) *(f32x4*)(slab + (size_t)gp * p.Cout + n0 + chan_t(t)) = acc[t][u];
+            }
+        }
+        return;
+    }
+    if constexpr (SP) {
+        // split-precision epilogue: out = [pixel][2 Cout], the lane's 8-channel runs at chunk * 128 + (channel & 63), lo
+        // half 64 elements on.  The finished value replaces the accumulator; the residual's hi and lo halves are added
+        // in two passes (one batch of loads each: the same registers as the 16-bit kernel's single pass).
+        size_t off[TPW];
+        bool ok[TPW];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const long long gp = gp0 + 16 * (wpx * TPW + u) + dl;
+            ok[u] = gp < totpix;
+            off[u] = (size_t)(ok[u] ? gp : 0) * (2 * p.Cout);
+            const unsigned b4 = (border >> (4 * u)) & 15u;
+            const int rc = (b4 & 1u) ? 0 : ((b4 & 2u) ? 2 : 1);
+            const int ccl = (b4 & 4u) ? 0 : ((b4 & 8u) ? 2 : 1);
+            const int cls = p.border_cls ? rc * 3 + ccl : 0;
+#pragma unroll
+            for (int t = 0; t < TCW; ++t) {
+                const f32x4 b = *(const f32x4*)(ebias + cls * BN + chan_t(t));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][u][j] = fmaf(acc[t][u][j], p.acc_scale, b[j]);
+            }
+        }
+        if (p.alpha) {
+#pragma unroll
+            for (int t = 0; t < TCW; ++t) {
+                const f32x4 a4 = *(const f32x4*)(ealpha + chan_t(t));
+#pragma unroll
+                for (int u = 0; u < TPW; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t][u][j] = acc[t][u][j] > 0.f ? acc[t][u][j] : acc[t][u][j] * a4[j];
+            }
+        }
+        int so[CPL / 8];
+#pragma unroll
+        for (int h = 0; h < CPL / 8; ++h) so[h] = ((n0 + chan_h(h)) >> 6) * 128 + ((n0 + chan_h(h)) & 63);
+        if (p.resid) {
+            const T* r = (const T*)p.resid;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                vec8 res[TPW][CPL / 8];
+#pragma unroll
+                for (int u = 0; u < TPW; ++u)
+#pragma unroll
+                    for (int h = 0; h < CPL / 8; ++h) res[u][h] = *(const vec8*)(r + off[u] + so[h] + 64 * part);
+#pragma unroll
+                for (int u = 0; u < TPW; ++u)
+#pragma unroll
+                    for (int h = 0; h < CPL / 8; ++h)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            acc[2 * h + (i >> 2)][u][i & 3] = fmaf((float)res[u][h][i], p.res_scale, acc[2 * h + (i >> 2)][u][i & 3]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            if (!ok[u]) continue;
+#pragma unroll
+            for (int h = 0; h < CPL / 8; ++h) {
+                vec8 o8, l8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v = acc[2 * h + (i >> 2)][u][i & 3];
+                    if (p.post_relu) v = fmaxf(v, 0.f);
+                    o8[i] = (T)v;
+                    l8[i] = (T)(v - (float)o8[i]);
+                }
+                *(vec8*)((T*)p.out + off[u] + so[h]) = o8;
+                *(vec8*)((T*)p.out + off[u] + so[h] + 64) = l8;
             }
         }
         return;
@@ -360,7 +453,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
 
 bool g_generic_epilogue = false;      // A/B: every launch on the run-time-flag epilogue (EPI = 0)
 
-template <typename T, int W, int TCW>
+template <typename T, int W, int TCW, bool SP = false>
 hipError_t launch_one(const ConvParams& p, hipStream_t st) {
     typedef Lin<W, TCW> G;
     const long long totpix = (long long)p.N * p.H * W;
@@ -368,22 +461,32 @@ hipError_t launch_one(const ConvParams& p, hipStream_t st) {
     const long long nwg = groups * (p.Cout / G::BN);
     if (nwg <= 0 || nwg >= (1ll << 31)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)nwg, (unsigned)p.splitk);
+    if (SP) {      // one epilogue form: it is a third of the 16-bit kernel's share of the time
+        if (p.splitk != 1 || p.dact) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 0, SP>), grid, dim3(NT), G::lds_bytes(), st, p);
+        return hipGetLastError();
+    }
     const bool plain = p.splitk == 1 && !p.dact && !p.post_relu && !p.stamps && !g_generic_epilogue;
     if (plain && p.alpha && !p.resid)
-        hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 1>), grid, dim3(NT), G::lds_bytes(), st, p);
+        hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 1, false>), grid, dim3(NT), G::lds_bytes(), st, p);
     else if (plain && !p.alpha && p.resid)
-        hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 2>), grid, dim3(NT), G::lds_bytes(), st, p);
+        hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 2, false>), grid, dim3(NT), G::lds_bytes(), st, p);
     else
-        hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 0>), grid, dim3(NT), G::lds_bytes(), st, p);
+        hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 0, false>), grid, dim3(NT), G::lds_bytes(), st, p);
     return hipGetLastError();
 }
 template <typename T, int W, int TCW>
 hipError_t set_attr_one() {
     const int lds = (int)Lin<W, TCW>::lds_bytes();
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<T, W, TCW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<T, W, TCW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<T, W, TCW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<T, W, TCW, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<T, W, TCW, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<T, W, TCW, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     return e;
+}
+template <int W, int TCW>
+hipError_t set_attr_sp() {
+    return hipFuncSetAttribute((const void*)conv3x3_linear_kernel<_Float16, W, TCW, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)Lin<W, TCW>::lds_bytes());
 }
 
 // Which map widths take the linear-tile kernel: bit 0 = 56, bit 1 = 28, bit 2 = 14, bit 3 = 7 (default: all).
@@ -494,14 +597,17 @@ hipError_t linear_set_attributes() {
     if ((e = set_attr_one<T, 7, 2>()) != hipSuccess) return e;
     A(__bf16) A(_Float16)
 #undef A
+#define B(W_, TCW_) if ((e = set_attr_sp<W_, TCW_>()) != hipSuccess) return e;
+    B(14, 4) B(28, 4) B(56, 2) B(7, 4) B(14, 2) B(28, 2) B(7, 2)
+#undef B
     return hipSuccess;
 }
 
 hipError_t launch_conv3x3_linear(int variant, int dtype, const ConvParams& p, hipStream_t st) {
     if (p.ksz != 3 || p.stride != 1 || p.pad != 1 || p.H != p.W) return hipErrorInvalidValue;
     if (p.splitk < 1 || (p.Cin / 64) % p.splitk) return hipErrorInvalidValue;      // whole chunks per split
-    if ((long long)p.N * p.H * p.W * p.Cin >= (1ll << 31)) return hipErrorInvalidValue;
-#define L(W_, TCW_) (dtype == ALINK_DT_BF16 ? launch_one<__bf16, W_, TCW_>(p, st) : launch_one<_Float16, W_, TCW_>(p, st))
+    if ((long long)p.N * p.H * p.W * p.Cin * (dtype == ALINK_DT_F16X2 ? 2 : 1) >= (1ll << 31)) return hipErrorInvalidValue;
+#define L(W_, TCW_) (dtype == ALINK_DT_BF16 ? launch_one<__bf16, W_, TCW_>(p, st) : (dtype == ALINK_DT_F16X2 ? launch_one<_Float16, W_, TCW_, true>(p, st) : launch_one<_Float16, W_, TCW_>(p, st)))
     // p.fine: the 64-channel form of the same kernel (weight rows are packed per 32-channel block, so both
     // forms read the same tensor, and every output is the same sum in the same order)
     if (p.fine) {

@@ -64,7 +64,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-template <typename T, int WP, int WC, bool DMA>
+// SP (T = _Float16 only): the split-precision mode ALINK_DT_F16X2.  Every value is an f16 pair hi + lo (22 significant
+// bits); activations are [pixel][2 Cin] with each 64-channel chunk stored as [hi 64 | lo 64], weights
+// [Cout][tap][chunk][hi 64 | lo 64].  A real K-step becomes three: hi x W_hi, hi x W_lo, lo x W_hi into the same f32
+// accumulators (lo x W_lo, 2^-22 of the sum, is dropped), so the kernel body is the same with a longer K walk.  Tensors
+// carry power-of-two scales (ConvParams::acc_scale ...) that keep hi inside the f16 range and lo out of the subnormals.
+template <typename T, int WP, int WC, bool DMA, bool SP>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
     typedef typename Vec8<T>::type vec8;
     constexpr int BM = WP * 64, BN = WC * 64;
@@ -85,9 +90,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const int split = blockIdx.y;
 
     const int Cin = p.Cin, W = p.W, ksz = p.ksz;
-    const int K = ksz * ksz * Cin;
+    const int CinP = SP ? 2 * Cin : Cin;       // pixel pitch of the input tensor in elements
+    const int K = (SP ? 2 : 1) * ksz * ksz * Cin;   // weight row pitch
     const int cpt = Cin >> 6;                  // 64-channel steps per tap
-    const int nk = ksz * ksz * cpt;
+    const int nk = ksz * ksz * cpt * (SP ? 3 : 1);
     const int kt0 = split * p.ksteps_per_split;
     const int kt1 = min(kt0 + p.ksteps_per_split, nk);
 
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                 const int n = m / HoWo, rem = m - n * HoWo;
                 const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-                off = ((n * p.H + iy0) * W + ix0) * Cin + chunk * 8;
+                off = ((n * p.H + iy0) * W + ix0) * CinP + chunk * 8;
                 for (int ky = 0; ky < ksz; ++ky)
                     for (int kx = 0; kx < ksz; ++kx)
                         if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)W)
@@ -127,12 +133,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     for (int j = 0; j < WJ; ++j) woff[j] = (n0 + (tid >> 3) + 32 * j) * K + chunk * 8;
 
     // K-step cursor (uniform): tap index, channel step inside the tap, tap coordinates
-    int s_tap = kt0 / cpt, s_cc = kt0 - s_tap * cpt;
+    const int r0 = SP ? kt0 / 3 : kt0;
+    int s_ph = SP ? kt0 - 3 * r0 : 0;          // SP: 0 = hi x W_hi, 1 = hi x W_lo, 2 = lo x W_hi
+    int s_tap = r0 / cpt, s_cc = r0 - s_tap * cpt;
     int s_ky = s_tap / ksz, s_kx = s_tap - s_ky * ksz;
 
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * TILE_BYTES;
-        const int tap_off = (s_ky * W + s_kx) * Cin + s_cc * 64;
+        const int tap_off = (s_ky * W + s_kx) * CinP + (SP ? 2 * s_cc + (s_ph == 2 ? 1 : 0) : s_cc) * 64;
+        const int wk_off = SP ? ((s_tap * cpt + s_cc) * 2 + (s_ph == 1 ? 1 : 0)) * 64 : kt * 64;
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
             const bool ok = (pmask[j] >> s_tap) & 1u;
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         char* wbase = base + BM * 128;
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
-            const T* src = gw + (woff[j] + kt * 64);
+            const T* src = gw + (woff[j] + wk_off);
             if constexpr (DMA) {
                 dma16(src, wbase + (wave * 8 + 32 * j) * 128);
             } else {
@@ -154,6 +163,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             }
         }
         // advance the cursor to the next K-step
+        if (SP && ++s_ph < 3) return;
+        s_ph = 0;
         if (++s_cc == cpt) {
             s_cc = 0;
             ++s_tap;
@@ -226,7 +237,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         const int m = m0 + wp * 64 + 16 * u + lr;
         ok[u] = m < p.M;
         const int mc = ok[u] ? m : p.M - 1;
-        off[u] = (size_t)mc * p.Cout + cbase;
+        // SP: pixel pitch 2 Cout, the lane's 16 channels are the hi run of chunk cbase / 64 (lo run: + 64 elements)
+        off[u] = SP ? (size_t)mc * (2 * p.Cout) + (size_t)(cbase >> 6) * 128 + (cbase & 63) : (size_t)mc * p.Cout + cbase;
         cls[u] = 0;
         if (p.border_cls) {
             const int rem = mc % HoWo;
@@ -236,13 +248,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             cls[u] = rc * 3 + cc;
         }
     }
-    vec8 res[4][2];            // the residual, or (backward mode) the stored forward activation
+    vec8 res[4][SP ? 4 : 2];   // the residual, or (backward mode) the stored forward activation; SP: hi, hi, lo, lo
     const T* extra = (const T*)(p.dact ? p.dact : p.resid);
     if (extra) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             res[u][0] = *(const vec8*)(extra + off[u]);
             res[u][1] = *(const vec8*)(extra + off[u] + 8);
+            if (SP) {
+                res[u][2] = *(const vec8*)(extra + off[u] + 64);
+                res[u][3] = *(const vec8*)(extra + off[u] + 72);
+            }
         }
     }
     f32x4 bia[4][4];
@@ -265,8 +281,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * t + j] = acc[t][u][j] + bia[u][t][j];
-        if (p.dact) {
+            for (int j = 0; j < 4; ++j)
+                v[4 * t + j] = SP ? fmaf(acc[t][u][j], p.acc_scale, bia[u][t][j] * p.bias_scale) : acc[t][u][j] + bia[u][t][j];
+        if (!SP && p.dact) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 v[i] *= (float)res[u][0][i] > 0.f ? 1.f : al[i];
@@ -280,8 +297,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             if (p.resid) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    v[i] += (float)res[u][0][i];
-                    v[8 + i] += (float)res[u][1][i];
+                    if (SP) {   // hi + lo is exact in f32 (22 significant bits)
+                        v[i] = fmaf((float)res[u][0][i] + (float)res[u][2][i], p.res_scale, v[i]);
+                        v[8 + i] = fmaf((float)res[u][1][i] + (float)res[u][3][i], p.res_scale, v[8 + i]);
+                    } else {
+                        v[i] += (float)res[u][0][i];
+                        v[8 + i] += (float)res[u][1][i];
+                    }
                 }
             }
         }
@@ -298,24 +320,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             }
             *(vec8*)((T*)p.out + off[u]) = o0;
             *(vec8*)((T*)p.out + off[u] + 8) = o1;
+            if (SP) {
+                vec8 l0, l1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    l0[i] = (T)(v[i] - (float)o0[i]);
+                    l1[i] = (T)(v[8 + i] - (float)o1[i]);
+                }
+                *(vec8*)((T*)p.out + off[u] + 64) = l0;
+                *(vec8*)((T*)p.out + off[u] + 72) = l1;
+            }
         }
     }
 }
 
-template <typename T, int WP, int WC, bool DMA>
+template <typename T, int WP, int WC, bool DMA, bool SP = false>
 hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
     constexpr int BM = WP * 64, BN = WC * 64;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
     const int ntm = (p.M + BM - 1) / BM, ntn = p.Cout / BN;
     dim3 grid(ntm * ntn, p.splitk, 1), block(256, 1, 1);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WP, WC, DMA>), grid, block, lds, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WP, WC, DMA, SP>), grid, block, lds, stream, p);
     return hipGetLastError();
 }
 
-template <typename T, int WP, int WC, bool DMA>
+template <typename T, int WP, int WC, bool DMA, bool SP = false>
 hipError_t set_attr_one() {
     constexpr size_t lds = 2 * (size_t)(WP * 64 + WC * 64) * 128;
-    return hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WP, WC, DMA>,
+    return hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WP, WC, DMA, SP>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
@@ -333,6 +365,8 @@ hipError_t conv_set_attributes() {
     if ((e = set_attr_one<T, WP, WC, false>()) != hipSuccess) return e;
     A(__bf16, 4, 1) A(__bf16, 2, 2) A(_Float16, 4, 1) A(_Float16, 2, 2)
 #undef A
+    if ((e = set_attr_one<_Float16, 4, 1, true, true>()) != hipSuccess) return e;
+    if ((e = set_attr_one<_Float16, 2, 2, true, true>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -344,9 +378,15 @@ hipError_t launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t stream)
     // host-side shape contract of the kernel (checked by callers too; never launch out of contract)
     if (p.Cin % 64 || p.Cout % 64 || p.M <= 0 || p.splitk < 1) return hipErrorInvalidValue;
     if (p.ksz * p.ksz > 32) return hipErrorInvalidValue;  // tap mask is 32 bits
-    if ((long long)p.N * p.H * p.W * p.Cin >= (1ll << 31)) return hipErrorInvalidValue;
-    if ((long long)p.Cout * p.ksz * p.ksz * p.Cin >= (1ll << 31)) return hipErrorInvalidValue;
+    const int two = dtype == ALINK_DT_F16X2 ? 2 : 1;
+    if ((long long)p.N * p.H * p.W * p.Cin * two >= (1ll << 31)) return hipErrorInvalidValue;
+    if ((long long)p.Cout * p.ksz * p.ksz * p.Cin * two >= (1ll << 31)) return hipErrorInvalidValue;
     const bool wide = (p.Cout % 128) == 0;
+    if (dtype == ALINK_DT_F16X2) {
+        // split precision: LDS-DMA staging only; no backward mode; a K split must cut between real K-steps
+        if (p.dact || (p.splitk > 1 && p.ksteps_per_split % 3)) return hipErrorInvalidValue;
+        return wide ? launch_one<_Float16, 2, 2, true, true>(p, stream) : launch_one<_Float16, 4, 1, true, true>(p, stream);
+    }
 #define L(T)                                                                          \
     (wide ? (g_use_dma ? launch_one<T, 2, 2, true>(p, stream)                         \
                        : launch_one<T, 2, 2, false>(p, stream))                       \

@@ -8,6 +8,7 @@
 //           that the reference does on the host with sklearn (code/face_model.py:92).
 #include "alink_common.h"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace alink {
@@ -121,6 +122,109 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
     }
 }
 
+// ALINK_DT_F16X2 form of stem_kernel: normalised pixels x 2^8 as f16 pairs (hi tile, lo tile) in LDS, weights
+// [64'][hi 32 | lo 32], three MFMAs per 16 x 16 tile (lo x hi, hi x lo, hi x hi), output [pixel][hi 64 | lo 64].
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void stem_x2_kernel(const StemParams p) {
+    typedef _Float16 T;
+    typedef f16x8 vec8;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int H = p.H, W = p.W;
+    const int RP = ((W + 2) * 3 + 7) & ~7;
+    T* tile = (T*)smem_raw;
+    T* tile_lo = tile + (STEM_ROWS + 2) * RP;
+    const int n = blockIdx.y, y0 = blockIdx.x * STEM_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const int row_elems = (W + 2) * 3;
+    const int total = (STEM_ROWS + 2) * row_elems;
+    for (int i = tid; i < total; i += 256) {
+        const int r = i / row_elems, e = i - r * row_elems;
+        int ixp, c;
+        if (LAYOUT == ALINK_LAYOUT_NCHW_F32) { c = e / (W + 2); ixp = e - c * (W + 2); }
+        else                                 { ixp = e / 3;     c = e - ixp * 3; }
+        const int iy = y0 - 1 + r, ix = ixp - 1;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            float px;
+            if (LAYOUT == ALINK_LAYOUT_NHWC_F32)
+                px = ((const float*)p.in)[(((size_t)n * H + iy) * W + ix) * 3 + c];
+            else if (LAYOUT == ALINK_LAYOUT_NCHW_F32)
+                px = ((const float*)p.in)[(((size_t)n * 3 + c) * H + iy) * W + ix];
+            else
+                px = (float)((const uint8_t*)p.in)[(((size_t)n * H + iy) * W + ix) * 3 + c];
+            v = (px - p.sub[p.flip ? 2 - c : c]) * p.mul * 256.f;
+        }
+        const T hi = (T)v;
+        const int at = r * RP + ixp * 3 + (p.flip ? 2 - c : c);
+        tile[at] = hi;
+        tile_lo[at] = (T)(v - (float)hi);
+    }
+
+    const int q = lane >> 4, lr = lane & 15;
+    vec8 wh[4], wl[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        wh[t] = *(const vec8*)((const T*)p.wgt + (16 * t + lr) * 64 + 8 * q);
+        wl[t] = *(const vec8*)((const T*)p.wgt + (16 * t + lr) * 64 + 32 + 8 * q);
+    }
+    int koff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * q + j;
+        const int ky = (k * 57) >> 9;
+        koff[j] = (k < 27) ? ky * RP + (k - 9 * ky) : -1;
+    }
+    const int cbase = 16 * q;
+    float bi[16], al[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { bi[i] = p.bias[cbase + i] * p.bias_scale; al[i] = p.alpha[cbase + i]; }
+
+    __syncthreads();
+
+    const int tpr = (W + 15) >> 4;
+    const int ntiles = STEM_ROWS * tpr;
+    for (int tl = wave; tl < ntiles; tl += 4) {
+        const int ry = tl / tpr, xt = tl - ry * tpr;
+        const int y = y0 + ry;
+        const int x = xt * 16 + lr;
+        const int xc = x < W ? x : W - 1;
+        const int b0 = ry * RP + xc * 3;
+        vec8 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ph[j] = koff[j] >= 0 ? tile[b0 + koff[j]] : (T)0.f;
+            pl[j] = koff[j] >= 0 ? tile_lo[b0 + koff[j]] : (T)0.f;
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[t] = mfma16<T>(wh[t], pl, f32x4{0.f, 0.f, 0.f, 0.f});
+            acc[t] = mfma16<T>(wl[t], ph, acc[t]);
+            acc[t] = mfma16<T>(wh[t], ph, acc[t]);
+        }
+        if (y < H && x < W) {
+            vec8 o0, o1, l0, l1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * t + j;
+                    float v = fmaf(acc[t][j], p.acc_scale, bi[i]);
+                    v = v > 0.f ? v : v * al[i];
+                    const T hi = (T)v;
+                    const T lo = (T)(v - (float)hi);
+                    if (i < 8) { o0[i] = hi; l0[i] = lo; } else { o1[i - 8] = hi; l1[i - 8] = lo; }
+                }
+            T* o = (T*)p.out + (((size_t)n * H + y) * W + x) * 128 + cbase;
+            *(vec8*)o = o0;
+            *(vec8*)(o + 8) = o1;
+            *(vec8*)(o + 64) = l0;
+            *(vec8*)(o + 72) = l1;
+        }
+    }
+}
+
 // One wave per embedding row: sum the split-K slabs in slab order (bit-reproducible), add the folded
 // bias, L2-normalise with sklearn.preprocessing.normalize semantics (zero norm -> divide by 1).
 __global__ __launch_bounds__(256) void fc_finish_kernel(const FcFinishParams p) {
@@ -135,13 +239,14 @@ __global__ __launch_bounds__(256) void fc_finish_kernel(const FcFinishParams p) 
         // bias first then slabs would change rounding vs "sum then bias"; keep sum-then-bias
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int z = 0; z < p.S; ++z) a += *(const f32x4*)(p.slabs + ((size_t)z * p.M + m) * E + c0);
-        a += s;
+        a = a * p.scale + s;        // scale: an exact power of two (1 outside the split-precision mode)
         *(f32x4*)(p.out + (size_t)m * E + c0) = a;
         ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     float nrm = sqrtf(ss);
+    if (p.nonfinite && lane == 0 && !(nrm <= 3.4e38f)) *p.nonfinite = 1;     // inf or NaN somewhere in the row
     if (nrm == 0.f) nrm = 1.f;
     if (p.norms && lane == 0) p.norms[m] = nrm;
     for (int c0 = lane * 4; c0 < E; c0 += 256) {
@@ -222,6 +327,18 @@ hipError_t launch_stem(int dtype, const StemParams& p, hipStream_t stream) {
     if ((size_t)(STEM_ROWS + 2) * (((p.W + 2) * 3 + 7) & ~7) * 2 > 60000) return hipErrorInvalidValue;
     if (dtype == ALINK_DT_BF16) return launch_stem_t<__bf16>(p, stream);
     if (dtype == ALINK_DT_F16) return launch_stem_t<_Float16>(p, stream);
+    if (dtype == ALINK_DT_F16X2) {
+        const int RP = ((p.W + 2) * 3 + 7) & ~7;
+        const size_t lds = (size_t)2 * (STEM_ROWS + 2) * RP * 2;
+        dim3 grid((p.H + STEM_ROWS - 1) / STEM_ROWS, p.N, 1), block(256, 1, 1);
+        switch (p.layout) {
+            case ALINK_LAYOUT_NHWC_F32: hipLaunchKernelGGL(stem_x2_kernel<ALINK_LAYOUT_NHWC_F32>, grid, block, lds, stream, p); break;
+            case ALINK_LAYOUT_NCHW_F32: hipLaunchKernelGGL(stem_x2_kernel<ALINK_LAYOUT_NCHW_F32>, grid, block, lds, stream, p); break;
+            case ALINK_LAYOUT_NHWC_U8:  hipLaunchKernelGGL(stem_x2_kernel<ALINK_LAYOUT_NHWC_U8>, grid, block, lds, stream, p); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     return hipErrorInvalidValue;
 }
 
@@ -232,6 +349,35 @@ hipError_t launch_conv_split_finish(int dtype, const ConvParams& p, const float*
     if (dtype == ALINK_DT_BF16) hipLaunchKernelGGL(conv_split_finish_kernel<__bf16>, grid, block, 0, stream, p, slabs, S);
     else if (dtype == ALINK_DT_F16) hipLaunchKernelGGL(conv_split_finish_kernel<_Float16>, grid, block, 0, stream, p, slabs, S);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// calibration of the split-precision mode: bits of max |x| over an f16 tensor (non-negative floats order like their
+// bit patterns; an inf or NaN anywhere comes out as >= 0x7f800000).  *out must be zero before the launch.
+namespace {
+__global__ __launch_bounds__(256) void absmax_f16_kernel(const f16x8* __restrict__ x, size_t n8, unsigned* out) {
+    float m = 0.f;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const f16x8 v = x[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = fabsf((float)v[j]);
+            bad = bad || !(a <= 65504.f);
+            m = fmaxf(m, a);
+        }
+    }
+    unsigned bits = bad ? 0x7fc00000u : __float_as_uint(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o, 64));
+    if ((threadIdx.x & 63) == 0 && bits) atomicMax(out, bits);
+}
+}  // namespace
+hipError_t launch_absmax_f16(const void* x, size_t n, unsigned* out, hipStream_t stream) {
+    if (n % 8 || !x || !out) return hipErrorInvalidValue;
+    const size_t n8 = n / 8;
+    const unsigned grid = (unsigned)std::min<size_t>((n8 + 255) / 256, 2048);
+    hipLaunchKernelGGL(absmax_f16_kernel, dim3(grid), dim3(256), 0, stream, (const f16x8*)x, n8, out);
     return hipGetLastError();
 }
 

@@ -40,6 +40,11 @@ extern "C" {
 #define ALINK_DT_BF16 0
 #define ALINK_DT_F16  1
 #define ALINK_DT_F32  2   /* pair head: alink_head_set_compute_dtype; IR backbone: the float32 precision mode */
+#define ALINK_DT_F16X2 3  /* IR backbone only: split precision — every activation and folded weight is an f16 PAIR   */
+                          /* hi + lo (22 significant bits, power-of-two scales per tensor), three products hi*hi,     */
+                          /* hi*lo, lo*hi on the f16 matrix cores into f32 accumulators: the accuracy of the float32  */
+                          /* mode (selection sets identical to the f32 arithmetic) at ~1/3 of the bf16 rate.          */
+                          /* Needs alink_backbone_calibrate before the first alink_embed.                             */
 
 /* input pixel layouts accepted by alink_embed */
 #define ALINK_LAYOUT_NHWC_F32 0   /* what siamese.ArcFace.process receives (code/siamese.py:232-234) */
@@ -123,6 +128,20 @@ int alink_backbone_enable_grad(alink_backbone_t* bb);
  * embedding would no longer be bit-identical whatever batch it arrives in.  Changes the workspace size:
  * query alink_backbone_workspace_bytes after setting it. */
 int alink_backbone_set_small_batch_split(alink_backbone_t* bb, int on);
+
+/* ALINK_DT_F16X2 (split precision) only.  The mode stores every activation as an f16 pair scaled by a power of two
+ * per tensor, chosen so that the largest value a tensor takes on the calibration images lands in [1024, 2048) —
+ * 32x below the f16 overflow threshold, lo halves far above the subnormals.  A power-of-two scale changes no bit of
+ * any result (binary floating point), so embeddings do not depend on the calibration images: they only have to be
+ * "like" later inputs within that 32x.  Synchronous; runs the n_images (<= what the workspace was sized for) through
+ * the network layer by layer.  merge != 0 keeps every exponent at or below its current value (re-calibration after
+ * alink_backbone_range_flag reported a batch that left the range).  Must run once before the first alink_embed. */
+int alink_backbone_calibrate(alink_backbone_t* bb, const void* dev_in, int layout, int n_images,
+                             void* dev_workspace, size_t workspace_bytes, int merge, void* stream);
+/* 16-bit storage modes (BF16 cannot, F16 and F16X2 can leave their range): 1 if, since the last reset, any embedding
+ * written by alink_embed was non-finite.  The word lives in pinned host memory the last kernel of a forward writes;
+ * the caller must have synchronised the streams it embedded on.  reset != 0 clears it. */
+int alink_backbone_range_flag(alink_backbone_t* bb, int reset);
 size_t alink_backbone_grad_workspace_bytes(const alink_backbone_t* bb, int n_images);
 int alink_embed_cached(alink_backbone_t* bb, const void* dev_in, int layout, int n_images, float* dev_out,
                        void* dev_workspace, size_t workspace_bytes, void* stream);
@@ -140,6 +159,14 @@ int alink_conv_nhwc(int dtype, const void* dev_in, const void* dev_w, const floa
                     const float* dev_alpha, const void* dev_resid, void* dev_out,
                     int N, int H, int W, int Cin, int Cout, int ksz, int stride, int pad,
                     int border_cls, int fine, void* stream);
+
+/* Split-precision twin (ALINK_DT_F16X2 kernels): every tensor float32 in its natural layout on the device — dev_w
+ * (Cout, ksz, ksz, Cin), dev_resid / dev_out (M, Cout) — converted to and from f16 pairs on the host (synchronous,
+ * test use only); e_*: the power-of-two scale exponents the stored tensors carry (stored = true x 2^e). */
+int alink_conv_nhwc_x2(const float* dev_in, const float* dev_w, const float* dev_bias, const float* dev_alpha,
+                       const float* dev_resid, float* dev_out, int N, int H, int W, int Cin, int Cout, int ksz,
+                       int stride, int pad, int border_cls, int fine, int e_in, int e_w, int e_out, int e_res,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * VGGFace2 ResNet-50 feature extractor: siamese.RESNET50 (code/siamese.py:203-216) =

@@ -330,3 +330,47 @@ def test_float32_precision_mode(gpu, capsys):
                                                             for (a, nrm), (c, d) in out.items()))
     for (a, nrm), (c, d) in out.items():
         assert c < 2e-6 and d < (2e-5 if nrm else 2e-4), (a, nrm, c, d)
+
+
+def test_split_precision_mode(gpu, capsys):
+    """IRBackbone(dtype="f16x2"): f16 pairs hi + lo with power-of-two scales per tensor, three products on the f16 matrix
+    cores.  Must sit where the float32 mode sits against the f32 CPU oracle (they differ from it by summation order and,
+    here, 2^-22 operand rounding): max |d| a few 1e-6, 1 - cos at the 1e-7 level — on the survey weights too, whose
+    activations (~1e8) no plain f16 storage holds: the calibrated scales do.  Every layout, batch-invariant bit for bit."""
+    from a_link_amd import _abi, weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import ir_resnet
+    size = (32, 32)
+    params = W.synthetic_ir_params((2, 2, 2, 2), size=size, seed=3)
+    bb = IRBackbone(params, image_size=size, dtype="f16x2", max_batch=8)
+    x = _pixels(5, size, seed=1)
+    ref = ir_resnet.embed(params, x)
+    got = bb.embed(x)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 1e-5 and _cos_dist(got, ref).max() < 1e-6, (np.abs(got - ref).max(), _cos_dist(got, ref).max())
+    assert np.array_equal(got, bb.embed(np.ascontiguousarray(np.transpose(x, (0, 3, 1, 2)))))      # NCHW
+    assert np.array_equal(got, bb.embed(x.astype(np.uint8)))                                         # u8
+    assert np.array_equal(bb.embed(x[2:3])[0], got[2])                                               # batch-invariant
+    x19 = _pixels(19, size, seed=7)
+    assert np.array_equal(bb.embed(x19)[9], bb.embed(x19[9:10])[0])                                  # chunked (max_batch 8)
+    # the scales are powers of two: re-calibrating on other images (here: 8x brighter-than-possible ones) moves no bit
+    bb.calibrate(_pixels(4, size, seed=5) * 8.0)
+    assert np.array_equal(bb.embed(x), got)
+    # noisy / fractional / out-of-range pixels keep the accuracy (the stem splits the normalised pixel too)
+    xn = x + np.random.default_rng(3).normal(0, 40, x.shape).astype(np.float32)
+    gn, rn = bb.embed(xn), ir_resnet.embed(params, xn)
+    assert np.abs(gn - rn).max() < 1e-5, np.abs(gn - rn).max()
+    with pytest.raises(_abi.AlinkError):
+        IRBackbone(params, image_size=size, dtype="f16x2", enable_grad=True)
+    out = {}
+    for arch, normalized in (("r50", False), ("r100", True), ("r100", False)):
+        p = W.synthetic_ir_params(W.ARCH_UNITS[arch], seed=1, normalized=normalized)
+        xi = _pixels(6, (112, 112), seed=2)
+        r = ir_resnet.embed(p, xi, batch=6)
+        g = IRBackbone(p, dtype="f16x2", max_batch=6).embed(xi)
+        out[(arch, normalized)] = (float(_cos_dist(g, r).max()), float(np.abs(g - r).max()))
+    with capsys.disabled():
+        print("\n[f16x2 mode vs f32 oracle @112] " + "; ".join("%s %s: 1-cos %.1e max|d| %.1e" % (a, "normalized" if nrm else "survey", c, d)
+                                                              for (a, nrm), (c, d) in out.items()))
+    for (c, d) in out.values():
+        assert c < 1e-6 and d < 2e-5, out

@@ -105,6 +105,49 @@ def _check_conv(out, ref, dt, what, dma):
     assert (err <= tol).all(), "case %s dt=%s dma=%d: max err %.4g" % (what, dt, dma, float((err - tol).max()))
 
 
+def test_split_precision_conv_matches_f64(gpu):
+    """ALINK_DT_F16X2 forms of the implicit-GEMM and linear-tile kernels (values as f16 pairs hi + lo, three products,
+    f32 accumulation): float32 operands in, float32 out, against a float64 convolution of the SAME float32 operands.
+    Error budget: 2^-22 relative per stored operand (x 2 operands + the dropped lo x lo term) and f32 accumulation —
+    asserted at 4e-6 of the per-output sum of |products| scale (the 16-bit kernels are asserted at 2^-8 / 2^-10).
+    The scale exponents are chosen off-centre on purpose (stored values around 2^6 .. 2^12): a power-of-two scale must
+    not change a single bit, which the second run of each case checks."""
+    lib = gpu.load()
+    g = torch.Generator().manual_seed(4321)
+    worst = 0.0
+    for (N, H, W, Ci, Co, k, s, p, border, use_alpha, use_resid) in CASES[:7] + LINEAR_CASES + [(1, 112, 112, 64, 64, 3, 1, 1, 1, 1, 0)]:
+        x = torch.randn(N, H, W, Ci, generator=g)
+        w = torch.randn(Co, k, k, Ci, generator=g) * (1.0 / np.sqrt(k * k * Ci))
+        ncls = 9 if border else 1
+        bias = torch.randn(ncls, Co, generator=g)
+        alpha = torch.rand(Co, generator=g) * 0.5 if use_alpha else None
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        resid = torch.randn(N, Ho, Wo, Co, generator=g) if use_resid else None
+        ref = _ref(x.double(), w.double(), bias.double(), alpha.double() if use_alpha else None,
+                   resid.double() if use_resid else None, s, p, border)
+        mag = _ref(x.double().abs(), w.double().abs(), bias.double().abs(), None, resid.double().abs() if use_resid else None, s, p, border)
+        xd, wd, bd = x.cuda(), w.cuda(), bias.cuda()
+        ad = alpha.cuda() if use_alpha else None
+        rd = resid.cuda() if use_resid else None
+        is_linear_case = (N, H, W, Ci, Co, k, s, p, border, use_alpha, use_resid) in LINEAR_CASES
+        outs = []
+        for fine in ((0, 1) if is_linear_case else (-1,)):
+            for (e_in, e_w, e_out, e_res) in ((9, 14, 8, 10), (4, 11, 5, 7)):
+                out = torch.full((N, Ho, Wo, Co), float("nan"), dtype=torch.float32, device="cuda")
+                rc = lib.alink_conv_nhwc_x2(gpu.ptr(xd), gpu.ptr(wd), gpu.ptr(bd), gpu.ptr(ad), gpu.ptr(rd), gpu.ptr(out),
+                                            N, H, W, Ci, Co, k, s, p, border, fine, e_in, e_w, e_out, e_res, None)
+                gpu.check(rc, "alink_conv_nhwc_x2")
+                got = out.cpu()
+                assert torch.isfinite(got).all(), (N, H, W, Ci, Co, k, s, p)
+                err = ((got.double() - ref).abs() / mag).max().item()
+                worst = max(worst, err)
+                assert err < 4e-6, ((N, H, W, Ci, Co, k, s, p, border, fine), err)
+                outs.append(got)
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), "scale exponents or the 64-channel form changed a bit: %s" % ((N, H, W, Ci, Co, k, s, p),)
+    print("split-precision conv: worst error / sum|products| = %.2e" % worst)
+
+
 def test_conv_rejects_bad_shapes(gpu):
     lib = gpu.load()
     x = torch.zeros(1, 4, 4, 32, dtype=torch.bfloat16, device="cuda")
