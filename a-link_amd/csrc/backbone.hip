@@ -759,7 +759,7 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
     ALINK_REQUIRE(N > 0, ALINK_EINVAL, "n_images must be positive");
     ALINK_REQUIRE(layout >= 0 && layout <= 2, ALINK_EINVAL, "unknown pixel layout %d", layout);
     const alink_ir_cfg& cfg = bb->cfg;
-    ALINK_REQUIRE((long long)N * cfg.height * cfg.width * 64 < (1ll << 31), ALINK_EINVAL,
+    ALINK_REQUIRE((long long)N * cfg.height * cfg.width * 64 * (cfg.dtype == ALINK_DT_F16X2 ? 2 : 1) < (1ll << 31), ALINK_EINVAL,
                   "batch of %d images exceeds the 2^31-element activation limit; split the batch", N);
     size_t off[7], total;
     ws_layout(bb, N, off, &total);

@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=292, help="images per alink_embed call: 292 x 196 pixels = 511 workgroups of the "
                     "14-wide linear-tile kernel for the chip's 512 slots, 1022 for 1024 at 28 wide (chunks of a step are "
                     "issued round-robin on --streams streams)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"], help="activation / weight storage of the backbone; f32 = the "
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "f16x2"], help="activation / weight storage of the backbone; f32 = the "
                     "reference's own precision on the exact-f32 MFMA GEMM (use --batch 256 --chunk 128 --no-extras)")
     ap.add_argument("--weights", default="survey", choices=["survey", "normalized"], help="survey: the SURVEY §8d draw (BatchNorm "
                     "statistics random: activations grow to ~1e8, bf16 only); normalized: the same draw with BatchNorm statistics "

@@ -353,9 +353,14 @@ def test_split_precision_mode(gpu, capsys):
     assert np.array_equal(bb.embed(x[2:3])[0], got[2])                                               # batch-invariant
     x19 = _pixels(19, size, seed=7)
     assert np.array_equal(bb.embed(x19)[9], bb.embed(x19[9:10])[0])                                  # chunked (max_batch 8)
-    # the scales are powers of two: re-calibrating on other images (here: 8x brighter-than-possible ones) moves no bit
+    # the scales are powers of two: re-calibrating on other images (here: 8x brighter-than-possible ones) moves a result
+    # only through lo halves that reach the f16 subnormals — far below the mode's own error
     bb.calibrate(_pixels(4, size, seed=5) * 8.0)
-    assert np.array_equal(bb.embed(x), got)
+    drift = float(np.abs(bb.embed(x) - got).max())
+    with capsys.disabled():
+        print("\n[f16x2 small net] max|d| vs oracle %.2e, 1-cos %.1e; drift after re-calibration on 8x brighter images %.1e"
+              % (np.abs(got - ref).max(), _cos_dist(got, ref).max(), drift))
+    assert drift < 1e-6
     # noisy / fractional / out-of-range pixels keep the accuracy (the stem splits the normalised pixel too)
     xn = x + np.random.default_rng(3).normal(0, 40, x.shape).astype(np.float32)
     gn, rn = bb.embed(xn), ir_resnet.embed(params, xn)

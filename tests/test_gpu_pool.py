@@ -103,7 +103,7 @@ def test_committee_heads_topk_set_equals_oracle(gpu):
     assert not (wrong ^ want) <= fragile
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f32", "f16x2"])
 def test_config3_committee_of_three_ir50_backbones_over_pool(gpu, capsys, dtype):
     """BASELINE configs[2] / SURVEY §8d C3 at its real depth: THREE IR-50 backbones (seeds 1,2,3, BatchNorm statistics
     calibrated like a trained checkpoint's) at 112x112 embed a 2,048-image pool subsample (64 synthetic identities x 32
@@ -112,8 +112,10 @@ def test_config3_committee_of_three_ir50_backbones_over_pool(gpu, capsys, dtype)
     uncertain — compared with the CPU oracle's result for the same pixels and weights (tests/golden/config3_r50.npz:
     ~6,200 float32 oracle forwards made by tests/golden/make_golden_config3.py).  The reduced-precision backbone moves
     a probability by delta_p (MEASURED here); a pair may change sides of the cut only if its oracle |p - 1/2| is within
-    2 delta_p of the cut's.  Both storage types: bf16 (the benchmarked default, range for any weights) and f16 (8x finer,
-    for checkpoints whose activations stay in range — every calibrated / trained one)."""
+    2 delta_p of the cut's.  Storage types: bf16 (the fastest: SCREENING only — a third of this set turns over), f16 (8x
+    finer, for checkpoints whose activations stay in range), and the two modes that must reproduce the oracle's set
+    EXACTLY: f32 (the reference's own precision, exact-f32 MFMA) and f16x2 (split precision: f16 pairs, three products on
+    the f16 matrix cores — the selection mode, ~15 k IR-100 embeddings/s)."""
     import os
     from a_link_amd import committee, siamese, uncertainty as U
     from a_link_amd.backbone import IRBackbone
@@ -129,6 +131,8 @@ def test_config3_committee_of_three_ir50_backbones_over_pool(gpu, capsys, dtype)
     for m, seed in enumerate((1, 2, 3)):
         params = gen.member_params(seed, gold["bn_stats_%d" % m])
         bb = IRBackbone(params, max_batch=292 if dtype != "f32" else 128, dtype=dtype)
+        if dtype == "f16x2":                  # scales from images of the workload (the build-time probe is uniform noise)
+            bb.calibrate(pool[:64])
         Ep.append(torch.from_numpy(bb.embed(pool)).cuda())              # uint8 pixels, 8 launches of <= 292 on 4 streams
         Eg.append(torch.from_numpy(bb.embed(gallery)).cuda())
         # the fixture is the oracle's: its first 8 pool rows and their member probabilities reproduce from the oracle
@@ -168,13 +172,19 @@ def test_config3_committee_of_three_ir50_backbones_over_pool(gpu, capsys, dtype)
               "maximum error (%.2f %%)" % (dtype, P, k, cos_max, delta_p, float(np.abs(pd - ens_o).mean()), cut, differ, k,
                                            len(fragile), 100.0 * len(fragile) / P, len(uniform), 100.0 * len(uniform) / P))
     assert eps_ent < 1e-6, eps_ent
-    assert delta_p < {"f32": 2e-5, "f16": 5e-3, "bf16": 4e-2}[dtype], delta_p
+    assert delta_p < {"f32": 2e-5, "f16x2": 2e-5, "f16": 5e-3, "bf16": 4e-2}[dtype], delta_p
+    # THE assertion: how many of the 1,024 selected pairs differ from the oracle's.  The exact modes: none.  The caps of
+    # the 16-bit storage types are the measured counts (49 and 389) plus a small margin: a regression shows.
+    if dtype in ("f32", "f16x2"):
+        assert got == want, sorted(got ^ want)
+    assert differ <= {"f32": 0, "f16x2": 0, "f16": 0.05 * k, "bf16": 0.40 * k}[dtype], differ
+    assert np.array_equal(idx.cpu().numpy(), np.lexsort((np.arange(P), -e))[:k])      # exact on the device's own scores
+    # secondary (a necessary condition of any exact top-k on perturbed scores, kept as a consistency check of the
+    # measurement itself): whatever differs sits within its own measured error of the cut
     assert fragile <= uniform
-    assert len(fragile) <= {"f32": 0.002, "f16": 0.05, "bf16": 0.15}[dtype] * P, (len(fragile), delta_p)
+    assert len(fragile) <= {"f32": 0.002, "f16x2": 0.002, "f16": 0.05, "bf16": 0.15}[dtype] * P, (len(fragile), delta_p)
     assert (got ^ want) <= fragile, (len(got ^ want), len(fragile))
     assert len(want - fragile) >= 20 and (want - fragile) <= got
-    assert np.array_equal(idx.cpu().numpy(), np.lexsort((np.arange(P), -e))[:k])      # exact on the device's own scores
-    assert differ <= {"f32": 2, "f16": 0.08 * k, "bf16": 0.5 * k}[dtype], differ       # f32: the reference's precision -> its set
 
 
 _CASES = {}
@@ -282,7 +292,7 @@ def _check_alink_iteration(res, P, ens_o, capsys, frag_cap):
     assert max(sizes) >= 20 and min(sizes) >= 3, sizes
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x2"])
 def test_one_alink_iteration_selection_identical(gpu, capsys, dtype):
     """config 4 shape through the HIP path: 16 persons, unique images embedded once, pairs gathered by index, an
     ensemble of two TRAINED heads on clean embeddings + the disguised-faces head on two noisy copies, then the
@@ -302,9 +312,13 @@ def test_one_alink_iteration_selection_identical(gpu, capsys, dtype):
         print("\n[config 4, (1,1,1,1) net %s @32, P=%d] 1-cos=%.1e max|d ens|=%.2e max|d dis|=%.2e" % (dtype, P, cos, d_ens, d_dis))
     assert d_ens < 0.1 and d_dis < 0.1, (d_ens, d_dis)
     _check_alink_iteration(res, P, ens_o, capsys, 0.05)
+    if dtype == "f16x2":          # the selection mode reproduces the oracle's query sets
+        assert d_ens < 2e-5 and d_dis < 2e-5, (d_ens, d_dis)
+        assert all(set(q) == qs for (q, _, qs, *_rest) in res.values())
 
 
-@pytest.mark.parametrize("arch,dtype", [("r50", "bf16"), ("r50", "f16"), ("r100", "bf16"), ("r100", "f16"), ("r100", "f32")])
+@pytest.mark.parametrize("arch,dtype", [("r50", "bf16"), ("r50", "f16"), ("r50", "f16x2"), ("r100", "bf16"), ("r100", "f16"),
+                                        ("r100", "f32"), ("r100", "f16x2")])
 def test_alink_iteration_selection_at_depth(gpu, capsys, arch, dtype):
     """The same iteration at the headline resolution and a production depth: IR-50 at 112x112 (calibrated
     weights: BatchNorm statistics that match the activations, like a trained checkpoint's).  About 300 float32
@@ -321,6 +335,6 @@ def test_alink_iteration_selection_at_depth(gpu, capsys, arch, dtype):
     assert cos < 1e-3
     # f16 meets the 5 % bar at depth; bf16 storage (8 mantissa bits through 24 / 49 units: probabilities move by up to 3e-2)
     # leaves 8-9 % of the pairs within their own error of a cut (cap 12 %) — DESIGN.md §5 has the measured counts
-    _check_alink_iteration(res, P, ens_o, capsys, {"f32": 0.002, "f16": 0.05, "bf16": 0.12}[dtype])
-    if dtype == "f32":            # the reference's own precision reproduces its query sets
+    _check_alink_iteration(res, P, ens_o, capsys, {"f32": 0.002, "f16x2": 0.002, "f16": 0.05, "bf16": 0.12}[dtype])
+    if dtype in ("f32", "f16x2"):  # the reference's own precision, and the split-precision selection mode, reproduce its query sets
         assert all(set(q) == qs for (q, _, qs, *_rest) in res.values())
