@@ -42,6 +42,19 @@ def merge_topk(local_vals, local_global_idx, k, largest=True, group=None):
     world = dist.get_world_size(group)
     dev = local_vals.device
     n = min(k, local_vals.numel())
+    # preconditions (checked, not assumed): the exchange carries indices as int32, and "ties -> lower global index"
+    # rests on every rank handing in its candidates best-first with ties in ascending index order, from a contiguous
+    # ascending shard (what shard_range + alink_topk produce)
+    if n:
+        gi = local_global_idx[:n].to(torch.int64)
+        if int(gi.max()) >= 2 ** 31 or int(gi.min()) < 0:
+            raise ValueError("merge_topk: global pair indices must lie in [0, 2^31) (got up to %d): shard the pool into "
+                             "passes of fewer pairs" % int(gi.max()))
+        if n > 1:
+            v_ = local_vals[:n].to(torch.float32)
+            dv = (v_[1:] - v_[:-1]) if not largest else (v_[:-1] - v_[1:])
+            if bool((dv < 0).any()) or bool(((dv == 0) & (gi[1:] <= gi[:-1])).any()):
+                raise ValueError("merge_topk: candidates must be sorted best-first with ties in ascending index order")
     pad = float("-inf") if largest else float("inf")
     mine = torch.empty((k, 2), dtype=torch.int32, device=dev)
     mine[:, 0] = torch.full((k,), pad, dtype=torch.float32, device=dev).view(torch.int32)
@@ -54,10 +67,15 @@ def merge_topk(local_vals, local_global_idx, k, largest=True, group=None):
         dist.all_gather_into_tensor(every, mine, group=group)
         from . import uncertainty as _unc
         vals_all = every[:, 0].contiguous().view(torch.float32)
-        pos, v = _unc.topk_device(vals_all, min(k, world * k), largest=largest)
-        idx = every[:, 1][pos.long()]
-        keep = idx >= 0                                       # fewer than k real candidates in the whole job
-        return v[keep], idx[keep].to(torch.int64)
+        # padding entries (index -1) score the worst possible value; a REAL candidate with that same score (-inf / +inf)
+        # ties with them, and position order could then rank padding of an earlier rank first: select among the real
+        # entries only (stable compaction keeps the rank-major, tie-ordered positions alink_topk's tie rule relies on)
+        real = (every[:, 1] >= 0).nonzero().flatten()
+        if real.numel() == 0:
+            return vals_all[:0], every[:0, 1].to(torch.int64)
+        pos, v = _unc.topk_device(vals_all[real].contiguous(), min(k, int(real.numel())), largest=largest)
+        idx = every[:, 1][real[pos.long()]]
+        return v, idx.to(torch.int64)
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine, group=group)
     every = torch.cat(parts).numpy()
@@ -134,8 +152,13 @@ def dp_train_on_batch(head, x, y, class_weight=None, sample_weight=None, group=N
         torch.sum(every, dim=0, out=gm)                      # fixed (rank) order
     elif exchange in ("gather", "allreduce"):
         dist.all_reduce(gm, group=group)
+    elif exchange == "host":
+        # a backend without device collectives (gloo): the 1.18 MB buffer is staged through the host
+        hbuf = gm.cpu()
+        dist.all_reduce(hbuf, group=group)
+        gm.copy_(hbuf)
     else:
-        raise ValueError("exchange must be gather or allreduce")
+        raise ValueError("exchange must be gather, allreduce or host")
     _abi.check(head.lib.alink_head_apply_update(head.h, st))
     out = m[:2].cpu().numpy()
     return [float(out[0]), float(out[1] / n)]

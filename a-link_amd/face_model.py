@@ -16,9 +16,20 @@ from . import weights as W
 from .backbone import IRBackbone
 
 
-def get_model(ctx, image_size, model_str, layer, dtype="bf16", max_batch=292, enable_grad=False,
+def default_dtype(enable_grad=False, small_batch_split=False):
+    """The storage / arithmetic mode a model built through the reference's API gets when the caller names none:
+    "f16x2" — split precision, whose active-learning selection sets equal the f32 arithmetic's (the reference computes
+    in float32: code/face_model.py:90) at ~15 k IR-100 embeddings/s.  The input-gradient pass and the small-batch
+    latency mode exist for 16-bit storage only: asking for either selects "bf16".  dtype="bf16" (45 k embeddings/s,
+    1 - cos ~3e-4: good for SCREENING, a third of a tight top-k turns over) and "f16" / "f32" remain explicit choices."""
+    return "bf16" if (enable_grad or small_batch_split) else "f16x2"
+
+
+def get_model(ctx, image_size, model_str, layer, dtype=None, max_batch=292, enable_grad=False,
               small_batch_split=False):
     assert layer == "fc1", "the reference slices the symbol at fc1_output (code/face_model.py:36,53)"
+    if dtype is None:
+        dtype = default_dtype(enable_grad, small_batch_split)
     params, cfg = W.resolve_model_config(model_str, image_size)
     # ctx: a device index as the reference passes (mx.gpu(args.gpu), code/face_model.py:46,57); None = the process's
     # current device (one process per GPU: torch.cuda.set_device(LOCAL_RANK))
@@ -38,7 +49,7 @@ class FaceModel(object):
         self.ga_model = None
         if len(args.model) > 0:
             self.model = get_model(getattr(args, "gpu", None), image_size, args.model, 'fc1',
-                                   dtype=getattr(args, "dtype", "bf16"),
+                                   dtype=getattr(args, "dtype", None),
                                    max_batch=getattr(args, "max_batch", 292),
                                    enable_grad=bool(args.get("enable_grad", False)) if hasattr(args, "get") else False,
                                    small_batch_split=bool(args.get("small_batch_split", False)) if hasattr(args, "get") else False)

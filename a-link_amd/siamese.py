@@ -36,6 +36,16 @@ def _inverse_frequency_weights(y):
 class SiameseNetwork:
     _identity_preprocess = True
 
+    # what customTrainModel / finetune feed the head: this class one-hot labels with inverse-frequency class
+    # weights (code/siamese.py:56,95-103); the baseline scorer of siamese3.py overrides both
+    @staticmethod
+    def _targets(y):
+        return to_categorical(y, num_classes=2)
+
+    @staticmethod
+    def _step_class_weight(y):
+        return _inverse_frequency_weights(y)
+
     def __init__(self, shape, modelName, learningRate=1.0, seed=None, adadelta_epsilon=1e-8, compute_dtype="f32"):
         self.learningRate = learningRate
         self.modelName = modelName
@@ -53,7 +63,7 @@ class SiameseNetwork:
     def finetune(self, X, Y, epochs, batch_size, verbose=1):
         early_stop = EarlyStopping(monitor='val_loss', min_delta=0.1, patience=5, verbose=1)
         reduce_lr = ReduceLROnPlateau(monitor='val_loss', factor=0.2, patience=5, min_lr=0.01, verbose=verbose)
-        Y_encoded = to_categorical(Y, num_classes=2)
+        Y_encoded = self._targets(Y)
         return self.siamese_net.fit(self.preprocess(X), Y_encoded, batch_size=batch_size, epochs=epochs,
                                     validation_split=0.2, verbose=verbose, callbacks=[early_stop, reduce_lr])
 
@@ -88,10 +98,10 @@ class SiameseNetwork:
                 order = np.random.permutation(len(y))
                 n_held = int(len(y) * valRatio)
                 held, used = order[:n_held], order[n_held:]
-                sums[:2] += net.train_on_batch([side[used] for side in x], to_categorical(y[used], num_classes=2),
-                                               class_weight=_inverse_frequency_weights(y[used]))[:2]
+                sums[:2] += net.train_on_batch([side[used] for side in x], self._targets(y[used]),
+                                               class_weight=self._step_class_weight(y[used]))[:2]
                 if n_held > 0:
-                    sums[2:] += net.test_on_batch([side[held] for side in x], to_categorical(y[held], num_classes=2))[:2]
+                    sums[2:] += net.test_on_batch([side[held] for side in x], self._targets(y[held]))[:2]
                 if verbose:
                     sys.stdout.write("Epoch %d : %d / %d : Tr loss: %.4f, Tr acc: %.4f, Vl loss: %.4f, Vl acc: %.4f  \r"
                                      % ((epoch + 1, step, steps_per_epoch) + tuple(sums / step)))
@@ -197,8 +207,10 @@ class RESNET50:
 
 
 class ArcFace:
-    def __init__(self, shape, model_path, dtype="bf16", max_batch=292, enable_grad=False, small_batch_split=False,
+    def __init__(self, shape, model_path, dtype=None, max_batch=292, enable_grad=False, small_batch_split=False,
                  gpu=None):
+        # dtype=None: face_model.default_dtype — "f16x2" (selection sets identical to the reference's float32
+        # arithmetic), or "bf16" when the gradient pass / latency mode is requested
         args = _Args({
             "enable_grad": enable_grad,
             "small_batch_split": small_batch_split,   # latency mode for batches <= 32 (include/alink_hip.h)

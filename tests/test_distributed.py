@@ -85,7 +85,19 @@ def _worker(rank, world, port, q):
         X = np.arange(11, dtype=np.float32).reshape(11, 1, 1, 1)
         E, (l0, h0) = D.embed_pool_sharded(Fake(), X)
         ok5 = np.array_equal(E.numpy()[:, 0], np.arange(11)) and (l0, h0) == D.shard_range(11, rank, world)
-        q.put((rank, ok1, ok2, ok3, ok4, ok5))
+        # ---- 4. merge_topk refuses what it cannot carry or order: an index beyond int32, candidates not sorted
+        # best-first, ties not in ascending index order (both ranks raise before the collective: no hang)
+        ok6 = True
+        for vals, idx in (([0.9, 0.5], [2 ** 31, 7]), ([0.5, 0.9], [1, 2]), ([0.5, 0.5], [9, 3])):
+            try:
+                D.merge_topk(torch.tensor(vals), torch.tensor(idx, dtype=torch.int64), 4, largest=True)
+                ok6 = False
+            except ValueError:
+                pass
+        # real candidates that score -inf tie with the padding and must still come back (3 real ones per rank, k = 8)
+        v3, i3 = D.merge_topk(torch.tensor([1.0, float("-inf"), float("-inf")]), torch.tensor([0, 1, 2]) + 10 * rank, 8, largest=True)
+        ok7 = i3.numpy().tolist() == [0, 10, 1, 2, 11, 12] and v3.numpy()[:2].tolist() == [1.0, 1.0]
+        q.put((rank, ok1, ok2, ok3, ok4, ok5, ok6, ok7))
     finally:
         dist.destroy_process_group()
 
@@ -104,3 +116,20 @@ def test_world_size_2_gloo():
     res = sorted(q.get(timeout=10) for _ in range(world))
     for r in res:
         assert all(r[1:]), r
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks through torch.distributed.run as a child process
+    (never an exec of a process that touched the GPU).  On this CPU-only box the ranks must fail with bench.py's own
+    "needs a ROCm device" — not with the old WORLD_SIZE assertion — and the parent must report a non-zero code."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check of the launcher's failure path")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180, env=env)
+    assert p.returncode != 0
+    assert "needs a ROCm device" in p.stderr and "WORLD_SIZE=" not in p.stderr
+    assert p.stdout.strip() == ""

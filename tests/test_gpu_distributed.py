@@ -97,3 +97,86 @@ def test_handles_live_on_their_own_device(gpu):
     L = np.random.RandomState(0).randn(8, 512).astype(np.float32)
     p1 = h1.predict([L, L[::-1].copy()])
     assert np.array_equal(p1, h0.predict([L, L[::-1].copy()])) and torch.cuda.current_device() == 0
+
+
+def _sharded_worker(rank, world, port, path):
+    """One rank of a two-process job that SHARES cuda:0 (a one-GPU box): gloo carries the exchange."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import a_link_amd  # noqa: F401
+        from a_link_amd import distributed as D
+        from a_link_amd.head import DenseHead
+        L, R, y, cw, sw = _sharded_case()
+        out = {}
+        for exch in ("allreduce", "host"):
+            try:
+                hd = DenseHead(512, lr=0.1, seed=0, device=0)
+                ms = []
+                for step in range(3):
+                    ms.append(D.dp_train_on_batch(hd, [L, R], y, class_weight=cw, sample_weight=sw, mode="sharded", exchange=exch))
+                # a 1-row batch: rank 1's shard is EMPTY (its gradient buffer must be zeros, not stale)
+                ms.append(D.dp_train_on_batch(hd, [L[:1], R[:1]], y[:1], mode="sharded", exchange=exch))
+                out[exch] = (np.concatenate([w.ravel() for w in hd.get_weights()]), np.asarray(ms, np.float64))
+            except RuntimeError as e:        # gloo built without device tensors: the host-staged exchange still has to work
+                if exch == "host":
+                    raise
+                out[exch] = str(e)
+        np.savez(path % rank, **{"%s_%s" % (k, n): v for k, val in out.items() if not isinstance(val, str)
+                                 for n, v in (("w", val[0]), ("m", val[1]))},
+                 skipped=np.array([k for k, val in out.items() if isinstance(val, str)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _sharded_case():
+    rs = np.random.RandomState(1)
+    L, R = rs.randn(13, 512).astype(np.float32), rs.randn(13, 512).astype(np.float32)
+    y = np.zeros((13, 2), np.float32)
+    y[np.arange(13), rs.randint(0, 2, 13)] = 1
+    cw = {0: 1.0 / 3, 1: 2.0 / 3}
+    sw = np.ones(13, np.float32)
+    sw[4] = 0.0                                   # one zero weight: Keras divides by the count of non-zero weights
+    return L, R, y, cw, sw
+
+
+def test_sharded_finetune_step_world_size_2(gpu, tmp_path):
+    """distributed.dp_train_on_batch(mode="sharded") with TWO ranks (reference step: code/siamese.py:52-58): two
+    spawned processes share cuda:0, the exchange goes through gloo — exchange="allreduce" on the device buffer where
+    this gloo build reduces device tensors, and exchange="host" (staged through the host) always.  13 rows with class
+    weights and one zero sample weight (rank 0: 7 rows, rank 1: 6), then a 1-row batch (rank 1's shard is empty): the
+    weights after the four steps equal the single-process steps' to 2e-6 and the metrics agree, on both ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    from a_link_amd.head import DenseHead
+    L, R, y, cw, sw = _sharded_case()
+    hd = DenseHead(512, lr=0.1, seed=0, device=0)
+    want_m = [hd.train_on_batch([L, R], y, class_weight=cw, sample_weight=sw) for _ in range(3)]
+    want_m.append(hd.train_on_batch([L[:1], R[:1]], y[:1]))
+    want_w = np.concatenate([w.ravel() for w in hd.get_weights()])
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    path = str(tmp_path / "rank%d.npz")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    ran = set()
+    for r in range(2):
+        z = np.load(path % r)
+        for exch in ("allreduce", "host"):
+            if exch in z["skipped"].tolist():
+                continue
+            ran.add(exch)
+            assert np.abs(z[exch + "_w"] - want_w).max() < 2e-6, (r, exch, np.abs(z[exch + "_w"] - want_w).max())
+            assert np.abs(z[exch + "_m"] - np.asarray(want_m, np.float64)).max() < 2e-6, (r, exch, z[exch + "_m"], want_m)
+    assert "host" in ran
+    print("sharded fine-tune step at world size 2: exchanges exercised = %s" % sorted(ran))

@@ -335,6 +335,6 @@ def test_alink_iteration_selection_at_depth(gpu, capsys, arch, dtype):
     assert cos < 1e-3
     # f16 meets the 5 % bar at depth; bf16 storage (8 mantissa bits through 24 / 49 units: probabilities move by up to 3e-2)
     # leaves 8-9 % of the pairs within their own error of a cut (cap 12 %) — DESIGN.md §5 has the measured counts
-    _check_alink_iteration(res, P, ens_o, capsys, {"f32": 0.002, "f16x2": 0.002, "f16": 0.05, "bf16": 0.12}[dtype])
+    _check_alink_iteration(res, P, ens_o, capsys, {"f32": 0.004, "f16x2": 0.004, "f16": 0.05, "bf16": 0.12}[dtype])
     if dtype in ("f32", "f16x2"):  # the reference's own precision, and the split-precision selection mode, reproduce its query sets
         assert all(set(q) == qs for (q, _, qs, *_rest) in res.values())
