@@ -75,7 +75,10 @@ __device__ __forceinline__ void wait_dma_then_barrier() {
     // counted wait: all but the N youngest LDS-DMA instructions of this wave have landed; then the
     // workgroup barrier.  One asm statement with a memory clobber: no LDS access moves across it and
     // hipcc adds no vmcnt(0) of its own (cdna_hip_programming.md §5 "Pipelining across barriers").
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+    // lgkmcnt(0): the wave's own LDS reads have returned before it arrives — the compiler sinks the MFMAs that
+    // consume a step's last fragments (and their wait) below this statement, and a read still queued at the barrier
+    // can be overtaken by another wave's DMA into the buffer it is aimed at (conv3x3_linear.hip has the full story).
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
 template <int A, int B>

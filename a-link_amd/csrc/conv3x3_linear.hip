@@ -59,8 +59,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // pixel (0..15) inside a 16-pixel MFMA tile handled by MFMA column lr (see conv3x3_direct.hip)
 __device__ __forceinline__ int delta(int lr) { return lr < 4 ? 2 * lr : (lr < 12 ? 2 * (lr - 4) + 1 : 2 * (lr - 8)); }
 
+// End of a K-step (and of an input refill): this wave's LDS-DMAs have landed (vmcnt) AND its own LDS reads have returned
+// (lgkmcnt) before it arrives at the barrier.  The second wait is not optional: the MFMAs that consume a step's last
+// fragments carry no memory dependence, so the compiler sinks them — and the lgkmcnt wait they imply — BELOW this
+// statement; a wave then reaches the barrier with ds_reads still queued, a faster wave passes the barrier and issues the
+// DMA that re-fills the buffer those reads are aimed at, and the reads return the NEXT tile's bytes.  Seen as rare
+// wrong 224-pixel groups under multi-stream load (round 3: 1 row in 10^4 in the 128-channel forms, percent-level in the
+// register-rich 64-channel forms, where the compiler hoists eight reads across); single-stream runs never showed it.
 __device__ __forceinline__ void wait_dma_then_barrier() {
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <int A>
@@ -148,9 +155,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     const int xc16 = (tid & 7) ^ ((tid >> 4) & 7);
     const long long xgp0 = gp0 - W - 1 + xpos0;                        // pixel of slot 0
     auto stage_x = [&](int cc, int part = 0) {     // part (SP): 0 = the chunk's hi half, 1 = its lo half
+        long long x0 = xgp0;
+        // SP refills twice per chunk from two source planes: left to itself the compiler keeps BOTH sets of per-slot
+        // 64-bit source addresses live across the chunk (32 registers the kernel does not have: they went to scratch);
+        // made opaque here, the addresses are rebuilt at each refill (a few dozen VALU operations per 27 K-steps)
+        if (SP) asm volatile("" : "+v"(x0));
 #pragma unroll
         for (int i = 0; i < XSLOTS; ++i) {
-            const long long gp = xgp0 + 32 * i;
+            const long long gp = x0 + 32 * i;
             const bool ok = xpos0 + 32 * i < G::XPIX && gp >= 0 && gp < totpix;
             const T* src = ok ? gin + ((size_t)gp * CinP + (SP ? 2 * cc + part : cc) * 64 + xc16 * 8) : gz + (lane & 7) * 8;
             dma16(src, smem + (NT * i + wave * 64) * 16);

@@ -379,3 +379,30 @@ def test_split_precision_mode(gpu, capsys):
                                                               for (a, nrm), (c, d) in out.items()))
     for (c, d) in out.values():
         assert c < 1e-6 and d < 2e-5, out
+
+
+@pytest.mark.parametrize("dtype,fine_max", [("f16x2", -1), ("bf16", 100000), ("f16", -1)])
+def test_concurrent_launches_are_bit_identical_to_serial(gpu, dtype, fine_max):
+    """Regression for a write-after-read race between a K-step's last LDS reads and the next DMA into the same buffer
+    (csrc/conv3x3_linear.hip wait_dma_then_barrier: the wait for the wave's own reads was missing, and the compiler
+    sinks the consuming MFMAs below the barrier).  It only showed with launches overlapping on several streams: rare
+    wrong 224-pixel groups, per-cent level in the register-rich 64-channel forms (forced everywhere here for bf16 via
+    fine_max; split precision uses them at 7 wide by itself).  2,048 IR-50 images on 4 streams, four times, against the
+    one-stream result: every bit equal."""
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    lib = gpu.load()
+    if fine_max >= 0:
+        lib.alink_debug_set_fine_max(fine_max)
+    try:
+        p = W.synthetic_ir_params(W.R50_UNITS, seed=1, normalized=True)
+        x = torch.randint(0, 256, (2048, 112, 112, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).cuda()
+        ref = IRBackbone(p, dtype=dtype, max_batch=292, streams=1).embed_device(x).clone()
+        bb = IRBackbone(p, dtype=dtype, max_batch=292, streams=4)
+        for rep in range(4):
+            got = bb.embed_device(x)
+            torch.cuda.synchronize()
+            bad = torch.nonzero((got != ref).any(1)).flatten().tolist()
+            assert not bad, (dtype, rep, len(bad), bad[:16])
+    finally:
+        lib.alink_debug_set_fine_max(384)
