@@ -366,7 +366,9 @@ def main():
         traffic = None
         try:
             import glob
-            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_hbm_traffic_%s_*.csv" % args.model)))
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_hbm_traffic_%s_%s_b*.csv" % (args.model, args.dtype))))
+            if not pm and args.dtype == "bf16":        # rounds 1-2 named the bf16 summaries without the dtype
+                pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_hbm_traffic_%s_b*.csv" % args.model)))
             if pm:
                 rows = [ln.split(",") for ln in open(pm[-1]).read().splitlines()[1:]]
                 # the dominant instantiation is the 3x3 conv row with the most launches per forward
@@ -376,7 +378,7 @@ def main():
                 nimg = int(re.search(r"_b(\d+)\.csv$", pm[-1]).group(1))       # images per launch of that profile
                 traffic = {"bytes_per_launch": (float(r[3]) + float(r[4])) * 1e6, "fetch_MB": float(r[3]),
                            "write_MB": float(r[4]), "launches_per_forward": float(r[2]), "per_images": nimg,
-                           "algorithmic_bytes_per_launch": nimg * 196 * 256 * 2 * 2.5 + 256 * 2304 * 2,
+                           "algorithmic_bytes_per_launch": (nimg * 196 * 256 * 2 * 2.5 + 256 * 2304 * 2) * (2 if args.dtype == "f16x2" else 1),
                            "note": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) and WRITE_SIZE, separate passes; "
                                    "algorithmic = input + output (+ residual on every second launch) + weights",
                            "source": os.path.basename(pm[-1])}
