@@ -78,6 +78,11 @@ struct ConvParams {
                           // multiplied by PReLU'(z) read off the stored forward activation: 1 if dact > 0 else alpha[c]
     void*        out;     // [M][Cout] T;  split-K: f32 slabs [splitk][M][Cout]
     const void*  zero;    // >= 256 B of zeros (source for padded taps / tail rows)
+    // conv_igemm only: a fused 1x1 projection shortcut (the first unit of a stage: out = conv(in) + conv1x1_stride(in2)).
+    // in2 = [N][H][W][Cin2] (same grid as `in`), sampled at (oy * stride, ox * stride); its weights follow the ksz*ksz*Cin
+    // columns of every weight row (row pitch ksz*ksz*Cin + Cin2); its K-steps run after the last tap.  nullptr = none.
+    const void*  in2;
+    int Cin2;
     int N, H, W, Cin, Cout, Ho, Wo, stride, ksz, pad, M;
     int border_cls;       // bias class chosen by output position (3x3, stride 1, pad 1 only)
     int splitk;           // 1 = fused epilogue; >1 = f32 partial slabs

@@ -109,11 +109,18 @@ struct ConvLayer {
     // ALINK_DT_F16X2: stored value = true value x 2^e.  e_w is fixed at finalize (folded weights), e_out by
     // alink_backbone_calibrate (the largest output the calibration images produce lands in [1024, 2048))
     int   e_w = 0, e_out = 0;
+    // fused projection shortcut (16-bit modes, forward only): the unit's 1x1 stride-2 conv1sc + its BN ride as extra
+    // K-steps of this (conv2) launch, read from workspace buffer in2_buf with Cin2 channels
+    int   Cin2 = 0, in2_buf = -1;
 };
 
 }  // namespace alink
 
 using namespace alink;
+
+// A/B hook: projection shortcuts fused into the conv2 launch (read at alink_backbone_create; default on)
+static bool g_fuse_shortcut = true;
+extern "C" void alink_debug_set_fuse_shortcut(int on) { g_fuse_shortcut = on != 0; }
 
 struct alink_backbone {
     int device = -1;                                           // device of every allocation / stream of this handle
@@ -135,6 +142,7 @@ struct alink_backbone {
     // input-gradient support
     bool grad = false;
     bool split_small = false;   // alink_backbone_set_small_batch_split
+    bool fuse_shortcut = true;  // alink_debug_set_fuse_shortcut (A/B): projection shortcuts inside the conv2 launch
     F32Net* f32 = nullptr;      // cfg.dtype == ALINK_DT_F32: the float32 precision mode (backbone_f32.hip) runs every call
     // ALINK_DT_F16X2 (split precision)
     bool calibrated = false;
@@ -206,14 +214,16 @@ int upload(alink_backbone* bb, const std::vector<V>& h, void** d) {
 
 // Fold + upload one convolution.  w is MXNet (O, I, kh, kw).
 int build_conv(alink_backbone* bb, ConvLayer& L, const std::vector<float>& w, const BN* pre,
-               const BN& post, const std::vector<float>* prelu) {
+               const BN& post, const std::vector<float>* prelu, const std::vector<float>* w_sc = nullptr,
+               const BN* post_sc = nullptr) {
     const int O = L.Cout, I = L.Cin, k = L.ksz, K = k * k * I, dt = bb->cfg.dtype;
+    const int I2 = w_sc ? L.Cin2 : 0, KR = K + I2;             // KR: weight row pitch of the 16-bit forms
     const bool x2 = dt == ALINK_DT_F16X2;
     // split precision: the linear-tile kernel where it applies, the implicit-GEMM kernel everywhere else
     L.variant = x2 ? linear_variant(L.ksz, L.stride, L.pad, L.Hin, L.Win, L.Cin, L.Cout)
                    : direct_variant(L.ksz, L.stride, L.pad, L.Hin, L.Win, L.Cin, L.Cout);
     const int cpl = L.variant ? direct_variant_cpl(L.variant) : 16;
-    std::vector<uint16_t> wq((size_t)O * K * (x2 ? 2 : 1));
+    std::vector<uint16_t> wq(x2 ? (size_t)O * K * 2 : (size_t)O * KR);
     std::vector<double> tapb((size_t)k * k * O, 0.0);          // [tap][co] shift contribution
     if (x2) {
         double mx = 0.0;
@@ -246,16 +256,19 @@ int build_conv(alink_backbone* bb, ConvLayer& L, const std::vector<float>& w, co
                     }
                     const size_t kidx = L.variant ? ((size_t)(ci >> 6) * 9 + (ky * 3 + kx)) * 64 + (ci & 63)
                                                   : (size_t)(ky * k + kx) * I + ci;
-                    wq[(size_t)row * K + kidx] = cvt(dt, (float)(post.a[co] * wv * ai));
+                    wq[(size_t)row * KR + kidx] = cvt(dt, (float)(post.a[co] * wv * ai));
                     if (pre) tb += wv * pre->b[ci];
                 }
                 tapb[(size_t)(ky * k + kx) * O + co] = post.a[co] * tb;
             }
+        // fused shortcut: conv1sc (O, I2, 1, 1) scaled by its own BN, behind the taps of the same row
+        for (int ci = 0; ci < I2; ++ci)
+            wq[(size_t)row * KR + K + ci] = cvt(dt, (float)(post_sc->a[co] * (double)(*w_sc)[(size_t)co * I2 + ci]));
     }
     const int ncls = L.border_cls ? 9 : 1;
     std::vector<float> bias((size_t)ncls * O);
     for (int co = 0; co < O; ++co) {
-        double full = post.b[co];
+        double full = post.b[co] + (I2 ? post_sc->b[co] : 0.0);
         for (int t = 0; t < k * k; ++t) full += tapb[(size_t)t * O + co];
         if (!L.border_cls) { bias[co] = (float)full; continue; }
         for (int rc = 0; rc < 3; ++rc)
@@ -343,6 +356,7 @@ alink_backbone_t* alink_backbone_create(const alink_ir_cfg* cfg) {
     alink_backbone* bb = new alink_backbone();
     bb->device = current_device();
     bb->cfg = *cfg;
+    bb->fuse_shortcut = g_fuse_shortcut;
     if (!(bb->cfg.bn_eps > 0.f)) bb->cfg.bn_eps = 2e-5f;
 
     // expected tensors, MXNet names
@@ -528,7 +542,11 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
             bb->convs.push_back(c1);
 
             int resid = xb;
-            if (u == 0) {
+            // the projection shortcut of a stage's first unit: fused into the conv2 launch (extra K-steps reading x) in the
+            // 16-bit inference modes; a launch of its own where the backward pass needs it as a layer, and in split precision
+            // (whose two products would need one common scale, fixed before calibration knows the tensors' exponents)
+            const bool fuse_sc = u == 0 && !bb->grad && !x2 && bb->fuse_shortcut;
+            if (u == 0 && !fuse_sc) {
                 const BN bsc = get_bn(bb, P + "_sc", false);
                 ConvLayer sc{};
                 sc.name = P + "_conv1sc";
@@ -546,6 +564,12 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
             c2.Hin = H; c2.Win = W; c2.Hout = Ho; c2.Wout = Wo;
             c2.border_cls = false; c2.has_alpha = false;
             c2.in_buf = tb; c2.out_buf = yb; c2.resid_buf = resid; c2.role = 3; c2.unit = bb->n_units;
+            if (fuse_sc) {
+                const BN bsc = get_bn(bb, P + "_sc", false);
+                c2.resid_buf = -1; c2.Cin2 = cin; c2.in2_buf = xb;
+                if ((rc = build_conv(bb, c2, bb->raw.at(P + "_conv2_weight"), nullptr, bn3, nullptr, &bb->raw.at(P + "_conv1sc_weight"), &bsc)))
+                    return rc;
+            } else
             if ((rc = build_conv(bb, c2, bb->raw.at(P + "_conv2_weight"), nullptr, bn3, nullptr))) return rc;
             bb->convs.push_back(c2);
             ++bb->n_units;
@@ -712,7 +736,7 @@ size_t alink_backbone_workspace_bytes(const alink_backbone_t* bb, int n_images) 
 // up to 8 workgroup rows that leave f32 slabs, summed in order by conv_split_finish_kernel, cuts the
 // dependent chain per layer by the same factor.  Only when the fused grid covers at most half the CUs.
 static int plan_split(const alink_backbone* bb, const ConvLayer& L, int N) {
-    if (!bb->split_small || N > SPLIT_MAX_N) return 1;
+    if (!bb->split_small || N > SPLIT_MAX_N || L.Cin2) return 1;     // a fused shortcut is not split over K
     const long long M = (long long)N * L.Hout * L.Wout;
     const int ncc = L.Cin / 64;
     long long nwg;
@@ -739,6 +763,7 @@ int g_fine_max = 384;     // measured (r100, one launch at a time): the 64-chann
 extern "C" void alink_debug_set_fine_max(int n) { g_fine_max = n; }
 int g_ablate = 0;
 int g_stagger = 0;
+
 extern "C" void alink_debug_set_stagger(int n) { g_stagger = n < 0 ? 0 : n; }
 void* g_stamps = nullptr;
 // alink_embed_profile launches every kernel of the chain this many times back to back between its two
@@ -851,7 +876,8 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         p.N = N; p.H = L.Hin; p.W = L.Win; p.Cin = L.Cin; p.Cout = L.Cout; p.Ho = L.Hout; p.Wo = L.Wout;
         p.stride = L.stride; p.ksz = L.ksz; p.pad = L.pad; p.M = N * L.Hout * L.Wout;
         p.border_cls = L.border_cls ? 1 : 0; p.splitk = 1;
-        p.ksteps_per_split = L.ksz * L.ksz * (L.Cin / 64);
+        p.ksteps_per_split = L.ksz * L.ksz * (L.Cin / 64) + L.Cin2 / 64;
+        if (L.Cin2) { p.in2 = buf(L.in2_buf); p.Cin2 = L.Cin2; }
         p.ablate = g_ablate;
         p.stagger = g_stagger;
         // few images (128-channel grid under 3/4 of the chip, g_fine_max): those workgroups cover only part of the chip and

@@ -91,13 +91,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 
     const int Cin = p.Cin, W = p.W, ksz = p.ksz;
     const int CinP = SP ? 2 * Cin : Cin;       // pixel pitch of the input tensor in elements
-    const int K = (SP ? 2 : 1) * ksz * ksz * Cin;   // weight row pitch
+    const int Cin2 = SP ? 0 : p.Cin2;          // fused projection shortcut: extra K-steps from a second input (16-bit forms)
+    const int K = (SP ? 2 : 1) * ksz * ksz * Cin + Cin2;   // weight row pitch
     const int cpt = Cin >> 6;                  // 64-channel steps per tap
-    const int nk = ksz * ksz * cpt * (SP ? 3 : 1);
+    const int cpt2 = Cin2 >> 6;
+    const int ntap = ksz * ksz;
+    const int nk = ntap * cpt * (SP ? 3 : 1) + cpt2;
     const int kt0 = split * p.ksteps_per_split;
     const int kt1 = min(kt0 + p.ksteps_per_split, nk);
 
     const T* __restrict__ gin = (const T*)p.in;
+    const T* __restrict__ gin2 = (const T*)p.in2;
     const T* __restrict__ gw  = (const T*)p.wgt;
     const T* __restrict__ gz  = (const T*)p.zero;
 
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     // swizzle: row r keeps logical chunk c at position c ^ ((r>>1)&7); (r>>1)&7 == (tid>>4)&7 for
     // every j because rows advance by 32.
     const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
-    int      poff[PJ];
+    int      poff[PJ], poff2[PJ];
     unsigned pmask[PJ];
     {
         const int HoWo = p.Ho * p.Wo;
@@ -114,11 +118,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             const int m = m0 + (tid >> 3) + 32 * j;
             unsigned mask = 0;
             int off = 0;
+            poff2[j] = -1;
             if (m < p.M) {
                 const int n = m / HoWo, rem = m - n * HoWo;
                 const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
                 off = ((n * p.H + iy0) * W + ix0) * CinP + chunk * 8;
+                poff2[j] = ((n * p.H + oy * p.stride) * W + ox * p.stride) * Cin2 + chunk * 8;
                 for (int ky = 0; ky < ksz; ++ky)
                     for (int kx = 0; kx < ksz; ++kx)
                         if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)W)
@@ -142,10 +148,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         char* base = smem + buf * TILE_BYTES;
         const int tap_off = (s_ky * W + s_kx) * CinP + (SP ? 2 * s_cc + (s_ph == 2 ? 1 : 0) : s_cc) * 64;
         const int wk_off = SP ? ((s_tap * cpt + s_cc) * 2 + (s_ph == 1 ? 1 : 0)) * 64 : kt * 64;
+        const bool shortcut = !SP && s_tap == ntap;        // (uniform) the K-steps of the fused projection shortcut
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
-            const bool ok = (pmask[j] >> s_tap) & 1u;
-            const T* src = ok ? gin + (poff[j] + tap_off) : gz + (tid & 7) * 8;
+            const bool ok = shortcut ? poff2[j] >= 0 : (pmask[j] >> s_tap) & 1u;
+            const T* src = ok ? (shortcut ? gin2 + (poff2[j] + s_cc * 64) : gin + (poff[j] + tap_off)) : gz + (tid & 7) * 8;
             if constexpr (DMA) {
                 dma16(src, base + (wave * 8 + 32 * j) * 128);
             } else {
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         // advance the cursor to the next K-step
         if (SP && ++s_ph < 3) return;
         s_ph = 0;
-        if (++s_cc == cpt) {
+        if (++s_cc == (shortcut ? cpt2 : cpt)) {
             s_cc = 0;
             ++s_tap;
             if (++s_kx == ksz) { s_kx = 0; ++s_ky; }
@@ -371,12 +378,15 @@ hipError_t conv_set_attributes() {
 }
 
 double conv_flops(const ConvParams& p) {
-    return 2.0 * (double)p.M * (double)p.Cout * (double)(p.ksz * p.ksz * p.Cin);
+    return 2.0 * (double)p.M * (double)p.Cout * (double)(p.ksz * p.ksz * p.Cin + (p.in2 ? p.Cin2 : 0));
 }
 
 hipError_t launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t stream) {
     // host-side shape contract of the kernel (checked by callers too; never launch out of contract)
     if (p.Cin % 64 || p.Cout % 64 || p.M <= 0 || p.splitk < 1) return hipErrorInvalidValue;
+    // fused shortcut: whole 64-channel steps, one fused launch (no K split), 16-bit storage only
+    if (p.in2 ? (p.Cin2 <= 0 || p.Cin2 % 64 || p.splitk != 1 || dtype == ALINK_DT_F16X2) : p.Cin2 != 0) return hipErrorInvalidValue;
+    if ((long long)p.N * p.H * p.W * p.Cin2 >= (1ll << 31)) return hipErrorInvalidValue;
     if (p.ksz * p.ksz > 32) return hipErrorInvalidValue;  // tap mask is 32 bits
     const int two = dtype == ALINK_DT_F16X2 ? 2 : 1;
     if ((long long)p.N * p.H * p.W * p.Cin * two >= (1ll << 31)) return hipErrorInvalidValue;

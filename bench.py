@@ -94,6 +94,7 @@ def main():
                     "library's internal streams (alink_backbone_set_streams)")
     ap.add_argument("--fine-max", type=int, default=-1, help="A/B: largest 128-channel grid that still takes the 64-channel form")
     ap.add_argument("--stagger", type=int, default=-1, help="A/B: start delay (x 1024 cycles) of the second workgroup on a CU in the linear-tile kernel")
+    ap.add_argument("--no-fuse-sc", action="store_true", help="A/B: projection shortcuts as launches of their own instead of extra K-steps of conv2")
     ap.add_argument("--generic-epilogue", action="store_true", help="A/B: linear-tile kernel with the run-time-flag epilogue everywhere")
     ap.add_argument("--config3", action="store_true", help="also time the config-3 leg (3 x IR-50 committee over a pool shard) "
                     "at N = 1; under torch.distributed.run it always runs")
@@ -136,6 +137,9 @@ def main():
     if args.generic_epilogue:
         from a_link_amd import _abi
         _abi.load().alink_debug_set_generic_epilogue(1)
+    if args.no_fuse_sc:
+        from a_link_amd import _abi
+        _abi.load().alink_debug_set_fuse_shortcut(0)
     if args.fine_max >= 0:
         from a_link_amd import _abi
         _abi.load().alink_debug_set_fine_max(args.fine_max)
@@ -344,13 +348,15 @@ def main():
         # shape = same kernel instantiation); the group with the most time.  For r100/r50 that is the
         # 14x14x256->256 stage-3 convolution (conv3x3_linear_kernel; conv3x3_direct_kernel with --linear 0).
         # launch order of the chain: per stage s, unit u: conv1, [shortcut], conv2 (csrc/backbone.hip)
+        n_conv_launches = sum(1 for k, _, _ in profs[0] if k == 1)
+        fused_sc = n_conv_launches == 2 * sum(units)        # projection shortcuts inside the conv2 launch (16-bit modes)
         shape_of = []
         for s_ in range(4):
             for u_ in range(units[s_]):
                 shape_of.append("stage%d %s" % (s_ + 1, "unit1 conv1" if u_ == 0 else "3x3 s1 C->C"))
-                if u_ == 0:
+                if u_ == 0 and not fused_sc:
                     shape_of.append("stage%d unit1 shortcut" % (s_ + 1))
-                shape_of.append("stage%d %s" % (s_ + 1, "unit1 conv2 (stride 2)" if u_ == 0 else "3x3 s1 C->C"))
+                shape_of.append("stage%d %s" % (s_ + 1, ("unit1 conv2 (stride 2%s)" % (" + 1x1 shortcut" if fused_sc else "")) if u_ == 0 else "3x3 s1 C->C"))
         groups = {}
         for run in profs:
             convs = [(ms, f) for k, ms, f in run if k == 1]

@@ -102,10 +102,23 @@ def test_profile_reports_every_launch(gpu):
     prof = bb.profile(x)
     kinds = [k for k, _, _ in prof]
     assert kinds[0] == 0 and kinds[-1] == 3 and kinds[-2] == 2
-    assert kinds.count(1) == sum(units) * 2 + 4
-    total = sum(f for _, _, f in prof)
+    assert kinds.count(1) == sum(units) * 2          # the four projection shortcuts ride inside their unit's conv2 launch
+    total = sum(f for _, _, f in prof)                 # ... and their FLOPs are still counted
     assert abs(total / 4 - ir_resnet.flops_per_image(units, size=32)) < 1e-6 * total
     assert all(ms >= 0 for _, ms, _ in prof)
+    # A/B hook: shortcuts as launches of their own (what the gradient pass and split precision use) — same embeddings
+    # up to the rounding of the shortcut's output to 16 bits, which the fused form skips
+    lib = gpu.load()
+    lib.alink_debug_set_fuse_shortcut(0)
+    try:
+        unfused = IRBackbone(params, image_size=size, max_batch=4)
+    finally:
+        lib.alink_debug_set_fuse_shortcut(1)
+    assert [k for k, _, _ in unfused.profile(x)].count(1) == sum(units) * 2 + 4
+    a, b = bb.embed_device(x).cpu().numpy(), unfused.embed_device(x).cpu().numpy()
+    assert _cos_dist(a, b).max() < 2e-4
+    ref = ir_resnet.embed(params, x.cpu().numpy())
+    assert _cos_dist(a, ref).max() <= _cos_dist(b, ref).max() * 1.5 + 1e-6
 
 
 def test_error_paths(gpu):

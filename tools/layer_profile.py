@@ -19,6 +19,7 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--ablate", type=int, default=0)
 ap.add_argument("--no-direct", action="store_true")
 ap.add_argument("--no-pair", action="store_true")
+ap.add_argument("--no-fuse-sc", action="store_true", help="A/B: projection shortcuts as launches of their own")
 ap.add_argument("--linear", type=int, default=-1, help="linear-tile widths: bit0 56, bit1 28, bit2 14, bit3 7 (default: library default)")
 a = ap.parse_args()
 units = W.ARCH_UNITS[a.model]
@@ -31,6 +32,8 @@ if a.no_pair:
     _lib.alink_debug_set_pair(0)
 if a.linear >= 0:
     _lib.alink_debug_set_linear(a.linear)
+if a.no_fuse_sc:
+    _lib.alink_debug_set_fuse_shortcut(0)
 bb = IRBackbone(W.synthetic_ir_params(units, seed=1), dtype=a.dtype, max_batch=a.batch)
 x = torch.randint(0, 256, (a.batch, 112, 112, 3), dtype=torch.uint8).float().cuda()
 for _ in range(2):
@@ -40,13 +43,14 @@ ms = np.median(np.array([[m for _, m, _ in p] for p in profs]), axis=0)
 kinds = [k for k, _, _ in profs[0]]
 fl = [f for _, _, f in profs[0]]
 # group identical (kind, flops) launches
+fused_sc = sum(1 for k in kinds if k == 1) == 2 * sum(units)     # projection shortcuts inside the conv2 launch
 names = ["stem"]
 for s in range(4):
     for u in range(units[s]):
         names.append("s%du%d_conv1" % (s + 1, u + 1))
-        if u == 0:
+        if u == 0 and not fused_sc:
             names.append("s%du%d_sc" % (s + 1, u + 1))
-        names.append("s%du%d_conv2" % (s + 1, u + 1))
+        names.append("s%du%d_conv2%s" % (s + 1, u + 1, "+sc" if (u == 0 and fused_sc) else ""))
 names += ["fc_splitk", "fc_finish"]
 tot = ms.sum()
 print("total %.3f ms  -> %.0f emb/s ; conv %.3f ms %.1f TF/s" % (
