@@ -163,6 +163,7 @@ hipError_t direct_set_attributes();
 hipError_t launch_conv3x3_direct(int variant, int dtype, const ConvParams& p, hipStream_t st);
 // linear-tile variants (conv3x3_linear.hip), reached through the four functions above as variants 11..13
 int        linear_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout);
+int        linear_variant_x2(int ksz, int stride, int pad, int H, int W, int Cin, int Cout);   // split precision: + the 112-wide layer
 int        linear_variant_cpl(int v);
 hipError_t linear_set_attributes();
 hipError_t linear_check_contract();   // probes the LDS out-of-range read contract; disables the linear kernel if it fails

@@ -220,7 +220,7 @@ int build_conv(alink_backbone* bb, ConvLayer& L, const std::vector<float>& w, co
     const int I2 = w_sc ? L.Cin2 : 0, KR = K + I2;             // KR: weight row pitch of the 16-bit forms
     const bool x2 = dt == ALINK_DT_F16X2;
     // split precision: the linear-tile kernel where it applies, the implicit-GEMM kernel everywhere else
-    L.variant = x2 ? linear_variant(L.ksz, L.stride, L.pad, L.Hin, L.Win, L.Cin, L.Cout)
+    L.variant = x2 ? linear_variant_x2(L.ksz, L.stride, L.pad, L.Hin, L.Win, L.Cin, L.Cout)
                    : direct_variant(L.ksz, L.stride, L.pad, L.Hin, L.Win, L.Cin, L.Cout);
     const int cpl = L.variant ? direct_variant_cpl(L.variant) : 16;
     std::vector<uint16_t> wq(x2 ? (size_t)O * K * 2 : (size_t)O * KR);
@@ -1210,7 +1210,7 @@ int alink_conv_nhwc_x2(const float* dev_in, const float* dev_w, const float* dev
     ALINK_HIP(hipStreamSynchronize(st));
     const int K = ksz * ksz * Cin, Ho = conv_out(H, ksz, stride, pad), Wo = conv_out(W, ksz, stride, pad);
     const size_t Min = (size_t)N * H * W, M = (size_t)N * Ho * Wo;
-    const int variant = linear_variant(ksz, stride, pad, H, W, Cin, Cout);
+    const int variant = linear_variant_x2(ksz, stride, pad, H, W, Cin, Cout);
     const int cpl = variant ? direct_variant_cpl(variant) : 16;
     auto pack_act = [&](const float* dev, size_t rows, int C, int e, std::vector<uint16_t>& q) -> int {
         std::vector<float> h(rows * C);

@@ -82,6 +82,7 @@ struct F32Net {
     std::vector<F32Layer> layers;
     float *d_fc_w = nullptr, *d_fc_bias = nullptr;      // [K][emb] (k = pos * C + ch), folded bias
     int fcK = 0, emb = 0, H = 0, W = 0, last_buf = 0;
+    int wide0 = 64;                                     // max(widths[0], widths[1]): channels of the widest full-resolution tensor
     std::vector<void*> allocs;
     std::string err;
     ~F32Net() {
@@ -127,6 +128,7 @@ F32Net* f32net_build(const std::map<std::string, std::vector<float>>& raw, const
     n->H = H;
     n->W = W;
     n->emb = cfg.emb;
+    n->wide0 = cfg.widths[0] > cfg.widths[1] ? cfg.widths[0] : cfg.widths[1];
     {   // stem: buffer 0 <- conv0(pixels) + bn0 + PReLU; the pixel buffer is id 4
         F32Layer L{};
         L.kind = 0; L.Cin = 3; L.Cout = w[0]; L.ks = 3; L.stride = 1; L.pad = 1; L.Hin = H; L.Win = W; L.Hout = H; L.Wout = W;
@@ -218,7 +220,8 @@ struct WsLayout { size_t buf[5], fc, gemm, total; };
 WsLayout ws_layout(const F32Net* n, int N, const alink_ir_cfg&) {
     WsLayout L;
     size_t o = 0;
-    const size_t big = al256((size_t)N * n->H * n->W * 64 * 4);
+    // the widest full-resolution tensor: the stem output (widths[0]) or the first unit's conv1 output (widths[1])
+    const size_t big = al256((size_t)N * n->H * n->W * (size_t)n->wide0 * 4);
     for (int i = 0; i < 4; ++i) { L.buf[i] = o; o += big; }
     L.buf[4] = o; o += al256((size_t)N * n->H * n->W * 3 * 4);
     L.fc = o; o += al256((size_t)N * n->emb * 4);

@@ -501,11 +501,12 @@ hipError_t set_attr_sp() {
                                (int)Lin<W, TCW>::lds_bytes());
 }
 
-// Which map widths take the linear-tile kernel: bit 0 = 56, bit 1 = 28, bit 2 = 14, bit 3 = 7 (default: all).
+// Which map widths take the linear-tile kernel: bit 0 = 56, bit 1 = 28, bit 2 = 14, bit 3 = 7, bit 4 = 112 (split
+// precision only: the 16-bit modes have the row-aligned 8-wave kernel there, 6 % faster alone) (default: all).
 // Measured on MI355X: a single 256-image launch at 28 or 14 wide has 448 workgroups for 512
 // slots, so alone it takes as long as the row-aligned kernel (12.5 % fewer MFMAs, idle slots instead of
 // time); with launches overlapping on several streams the embedding rate rises by 4.3 %.
-int g_linear_mode = 15;
+int g_linear_mode = 31;
 
 }  // namespace
 
@@ -595,7 +596,18 @@ int linear_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout
     if ((g_linear_mode & 8) && W == 7 && Cout % 128 == 0) return 14;
     return 0;
 }
-int linear_variant_cpl(int v) { return v == 13 ? 8 : 17; }
+// split precision: the same, plus the 112-wide layer (variant 15: 2 rows per workgroup, 64-channel tiles, 80 KB of LDS, two
+// workgroups per CU) — the 16-bit modes take the row-aligned kernel there, split precision would otherwise fall to the
+// implicit GEMM, which stages the hi half of every input tile twice
+int linear_variant_x2(int ksz, int stride, int pad, int H, int W, int Cin, int Cout) {
+    if (const int v = linear_variant(ksz, stride, pad, H, W, Cin, Cout)) return v;
+    if (ksz != 3 || stride != 1 || pad != 1 || H != W || Cin % 64) return 0;
+    const int dev = current_device();
+    if (dev < 0 || dev >= 64 || !g_contract_ok[dev]) return 0;
+    if ((g_linear_mode & 16) && W == 112 && Cout % 64 == 0) return 15;
+    return 0;
+}
+int linear_variant_cpl(int v) { return (v == 13 || v == 15) ? 8 : 17; }
 
 hipError_t linear_set_attributes() {
     hipError_t e;
@@ -610,7 +622,7 @@ hipError_t linear_set_attributes() {
     A(__bf16) A(_Float16)
 #undef A
 #define B(W_, TCW_) if ((e = set_attr_sp<W_, TCW_>()) != hipSuccess) return e;
-    B(14, 4) B(28, 4) B(56, 2) B(7, 4) B(14, 2) B(28, 2) B(7, 2)
+    B(14, 4) B(28, 4) B(56, 2) B(7, 4) B(14, 2) B(28, 2) B(7, 2) B(112, 2)
 #undef B
     return hipSuccess;
 }
@@ -634,6 +646,7 @@ hipError_t launch_conv3x3_linear(int variant, int dtype, const ConvParams& p, hi
         case 12: return p.W == 28 ? L(28, 4) : hipErrorInvalidValue;
         case 13: return p.W == 56 ? L(56, 2) : hipErrorInvalidValue;
         case 14: return p.W == 7 ? L(7, 4) : hipErrorInvalidValue;
+        case 15: return p.W == 112 && dtype == ALINK_DT_F16X2 ? launch_one<_Float16, 112, 2, true>(p, st) : hipErrorInvalidValue;
     }
 #undef L
     return hipErrorInvalidValue;

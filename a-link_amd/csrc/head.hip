@@ -1729,12 +1729,18 @@ int alink_head_set_compute_dtype(alink_head_t* h, int dtype) {
     ALINK_REQUIRE(dtype == ALINK_DT_F32 || dtype == ALINK_DT_BF16, ALINK_EINVAL, "compute dtype must be ALINK_DT_F32 or ALINK_DT_BF16");
     DeviceGuard dg(h->device);
     if (dtype == ALINK_DT_BF16 && !h->d_pq) {
-        ALINK_HIP(hipMalloc((void**)&h->d_pq, h->nparams * sizeof(__bf16)));
-        h->allocs.push_back(h->d_pq);
-        ALINK_HIP(hipMalloc((void**)&h->d_pqf, h->nparams * sizeof(float)));
-        h->allocs.push_back(h->d_pqf);
-        ALINK_HIP(hipMalloc((void**)&h->d_wt, ((size_t)h->D * h->h1 + (size_t)h->h1 * h->h2) * sizeof(__bf16)));
-        h->allocs.push_back(h->d_wt);
+        // all three buffers or none: a half-allocated set must not leave d_pq set (a retry would skip this block and
+        // the bf16 kernels would dereference the missing ones)
+        void *pq = nullptr, *pqf = nullptr, *wt = nullptr;
+        hipError_t e = hipMalloc(&pq, h->nparams * sizeof(__bf16));
+        if (e == hipSuccess) e = hipMalloc(&pqf, h->nparams * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&wt, ((size_t)h->D * h->h1 + (size_t)h->h1 * h->h2) * sizeof(__bf16));
+        if (e != hipSuccess) {
+            (void)hipFree(pq); (void)hipFree(pqf); (void)hipFree(wt);
+            return hip_fail(e, "hipMalloc (bf16 compute mode buffers)", __FILE__, __LINE__);
+        }
+        h->d_pq = (decltype(h->d_pq))pq; h->d_pqf = (decltype(h->d_pqf))pqf; h->d_wt = (decltype(h->d_wt))wt;
+        h->allocs.push_back(pq); h->allocs.push_back(pqf); h->allocs.push_back(wt);
     }
     h->qmode = dtype == ALINK_DT_BF16 ? 1 : 0;
     h->packed_dirty = h->pq_dirty = h->pqf_dirty = true;

@@ -380,6 +380,21 @@ def test_split_precision_mode(gpu, capsys):
     assert np.abs(gn - rn).max() < 1e-5, np.abs(gn - rn).max()
     with pytest.raises(_abi.AlinkError):
         IRBackbone(params, image_size=size, dtype="f16x2", enable_grad=True)
+    # a batch far outside what the scales were calibrated for (pixels x 100: activations ~100x the probe images', beyond
+    # the 32x headroom): the FC-finish kernel raises the range flag, the host re-calibrates on the offending batch
+    # (scales only go down) and re-runs — the caller sees finite, accurate embeddings ...
+    xb = x * 100.0
+    fresh = IRBackbone(params, image_size=size, dtype="f16x2", max_batch=8)
+    gb, rb = fresh.embed(xb), ir_resnet.embed(params, xb)
+    assert np.isfinite(gb).all() and np.abs(gb - rb).max() < 1e-5, np.abs(gb - rb).max()
+    assert np.abs(fresh.embed(x) - ref).max() < 1e-5           # and ordinary images still embed to f32 accuracy afterwards
+    # ... or, with lazy_range_check (bench.py: one check per timed region), an error at check_range(), never silent NaNs
+    lazy = IRBackbone(params, image_size=size, dtype="f16x2", max_batch=8, lazy_range_check=True)
+    lazy.embed_device(torch.from_numpy(xb).cuda())
+    with pytest.raises(_abi.AlinkError):
+        lazy.check_range()
+    lazy.embed_device(torch.from_numpy(x).cuda())
+    lazy.check_range()                                          # the flag was reset by the failed check
     out = {}
     for arch, normalized in (("r50", False), ("r100", True), ("r100", False)):
         p = W.synthetic_ir_params(W.ARCH_UNITS[arch], seed=1, normalized=normalized)

@@ -92,7 +92,7 @@ def test_conv_matches_cpu(gpu, dt, dma, linear):
                 _check_conv(out, ref, dt, (N, H, W, Ci, Co, k, s, p, border, fine), dma)
     finally:
         lib.alink_debug_set_dma(1)
-        lib.alink_debug_set_linear(15)          # library default: linear tiles at every width they support
+        lib.alink_debug_set_linear(31)          # library default: linear tiles at every width they support
 
 
 def _check_conv(out, ref, dt, what, dma):
