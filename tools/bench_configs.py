@@ -32,11 +32,14 @@ def sync_time(fn, reps=1):
     return (time.perf_counter() - t) / reps, r
 
 
+DTYPE = None        # --dtype: None = the API default (face_model.default_dtype: "f16x2", the selection mode)
+
+
 def config3(pool_n, out):
     """The product path bench.py times under torchrun (distributed.committee_pool_topk), at the full per-GPU shard."""
     import torch
     from a_link_amd import distributed as D, siamese
-    members = [siamese.ArcFace((112, 112), "synthetic:r50:%d" % s) for s in (1, 2, 3)]
+    members = [siamese.ArcFace((112, 112), "synthetic:r50:%d" % s, dtype=DTYPE) for s in (1, 2, 3)]
     heads = [siamese.SiameseNetwork((512,), "h%d" % i, 0.1, seed=i) for i in range(3)]
     g = torch.Generator().manual_seed(0)
     pool = torch.randint(0, 256, (pool_n, 112, 112, 3), generator=g, dtype=torch.uint8).cuda()
@@ -65,7 +68,7 @@ def config4(out, noises, student_dtype="f32"):
     import numpy as np
     import torch
     from a_link_amd import alink_loop as AL, committee, noise, pairs, siamese
-    conv = siamese.ArcFace((112, 112), "synthetic:r100")
+    conv = siamese.ArcFace((112, 112), "synthetic:r100", dtype=DTYPE)
     student = siamese.SiameseNetwork((512,), "/tmp/alink_student", 0.1, seed=1, compute_dtype=student_dtype)
     ens = [siamese.SiameseNetwork((512,), "e1", 0.1, seed=2)]
     np.random.seed(0)                                    # the noise objects draw their Philox seeds at construction
@@ -148,9 +151,14 @@ def main():
     ap.add_argument("--attack-pairs", type=int, default=3)
     ap.add_argument("--noises", default="gaussian,saltpepper,poisson,speckle")
     ap.add_argument("--skip", default="")
+    ap.add_argument("--dtype", default=None, help="backbone storage of the feature models (default: the API default, f16x2 = the "
+                    "selection mode; bf16 = the screening mode)")
     a = ap.parse_args()
     import a_link_amd  # noqa: F401
-    out = {}
+    from a_link_amd import face_model
+    global DTYPE
+    DTYPE = a.dtype
+    out = {"backbone_dtype": a.dtype or face_model.default_dtype()}
     if "3" not in a.skip:
         config3(a.pool, out)
     conv = student = None
@@ -162,7 +170,7 @@ def main():
     if "5" not in a.skip:
         if conv is None:
             from a_link_amd import siamese
-            conv = siamese.ArcFace((112, 112), "synthetic:r100")
+            conv = siamese.ArcFace((112, 112), "synthetic:r100", dtype=DTYPE)
             student = siamese.SiameseNetwork((512,), "/tmp/alink_student", 0.1, seed=1)
         config5(out, conv, student, a.attack_pairs)
     if "g" not in a.skip:
