@@ -11,7 +11,10 @@ import torch
 import a_link_amd  # noqa
 from a_link_amd import siamese
 
-fm = siamese.ArcFace((112, 112), "synthetic:r100", small_batch_split="--split" in sys.argv)
+_dt = [a.split("=")[1] for a in sys.argv if a.startswith("--dtype=")]
+fm = siamese.ArcFace((112, 112), "synthetic:r100" + (":1:normalized" if "--normalized" in sys.argv else ""),
+                     small_batch_split="--split" in sys.argv, dtype=_dt[0] if _dt else None)
+print("backbone dtype:", fm.model.model.dtype)
 net = siamese.SiameseNetwork((512,), "m", 0.1, seed=0)
 rng = np.random.RandomState(0)
 
