@@ -260,7 +260,9 @@ def main():
         ydd = torch.from_numpy(yh).cuda()
         for mode, key in (("sharded", "finetune_step_dp_ms"), ("replicated", "finetune_step_replicated_ms")):
             hdp = DenseHead(512, lr=0.1, seed=0, device=local_rank)
-            for _ in range(20):
+            # RCCL's first few hundred all-reduces on a fresh communicator run 3-5x slower than its steady state
+            # (tools/experiments/dp_step_time.py: 0.27-0.42 ms for the first 220 steps, 0.085 ms after): warm up past that
+            for _ in range(400):
                 D.dp_train_on_batch(hdp, [Ld, Rd], ydd, mode=mode)
             torch.cuda.synchronize()
             barrier()
