@@ -112,6 +112,7 @@ struct ConvLayer {
     // fused projection shortcut (16-bit modes, forward only): the unit's 1x1 stride-2 conv1sc + its BN ride as extra
     // K-steps of this (conv2) launch, read from workspace buffer in2_buf with Cin2 channels
     int   Cin2 = 0, in2_buf = -1;
+    int   stage = 0;                        // 0..3
 };
 
 }  // namespace alink
@@ -163,6 +164,7 @@ struct alink_backbone {
     int nsub = 1;   // default off: a per-call join costs more than the de-synchronisation gains
     hipStream_t sub[MAXSUB] = {};
     hipEvent_t ev_start = nullptr, ev_done[MAXSUB] = {};
+    hipEvent_t ev_front[MAXSUB] = {};       // shard i has issued its HBM-bound front (stem + stage 1)
 
     ~alink_backbone() {
         if (f32) f32net_destroy(f32);
@@ -170,6 +172,7 @@ struct alink_backbone {
         for (int i = 0; i < MAXSUB; ++i) {
             if (sub[i]) (void)hipStreamDestroy(sub[i]);
             if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
+            if (ev_front[i]) (void)hipEventDestroy(ev_front[i]);
         }
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (h_flag) (void)hipHostFree(h_flag);
@@ -536,7 +539,7 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
             c1.Cin = cin; c1.Cout = c; c1.ksz = 3; c1.stride = 1; c1.pad = 1;
             c1.Hin = H; c1.Win = W; c1.Hout = H; c1.Wout = W;
             c1.border_cls = true; c1.has_alpha = true;
-            c1.in_buf = xb; c1.out_buf = tb; c1.resid_buf = -1; c1.role = 1; c1.unit = bb->n_units;
+            c1.in_buf = xb; c1.out_buf = tb; c1.resid_buf = -1; c1.role = 1; c1.unit = bb->n_units; c1.stage = s;
             if ((rc = build_conv(bb, c1, bb->raw.at(P + "_conv1_weight"), &bn1, bn2, &bb->raw.at(P + "_relu1_gamma"))))
                 return rc;
             bb->convs.push_back(c1);
@@ -553,7 +556,7 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
                 sc.Cin = cin; sc.Cout = c; sc.ksz = 1; sc.stride = stride; sc.pad = 0;
                 sc.Hin = H; sc.Win = W; sc.Hout = Ho; sc.Wout = Wo;
                 sc.border_cls = false; sc.has_alpha = false;
-                sc.in_buf = xb; sc.out_buf = sb; sc.resid_buf = -1; sc.role = 2; sc.unit = bb->n_units;
+                sc.in_buf = xb; sc.out_buf = sb; sc.resid_buf = -1; sc.role = 2; sc.unit = bb->n_units; sc.stage = s;
                 if ((rc = build_conv(bb, sc, bb->raw.at(P + "_conv1sc_weight"), nullptr, bsc, nullptr))) return rc;
                 bb->convs.push_back(sc);
                 resid = sb;
@@ -563,7 +566,7 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
             c2.Cin = c; c2.Cout = c; c2.ksz = 3; c2.stride = stride; c2.pad = 1;
             c2.Hin = H; c2.Win = W; c2.Hout = Ho; c2.Wout = Wo;
             c2.border_cls = false; c2.has_alpha = false;
-            c2.in_buf = tb; c2.out_buf = yb; c2.resid_buf = resid; c2.role = 3; c2.unit = bb->n_units;
+            c2.in_buf = tb; c2.out_buf = yb; c2.resid_buf = resid; c2.role = 3; c2.unit = bb->n_units; c2.stage = s;
             if (fuse_sc) {
                 const BN bsc = get_bn(bb, P + "_sc", false);
                 c2.resid_buf = -1; c2.Cin2 = cin; c2.in2_buf = xb;
@@ -640,6 +643,7 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
     for (int i = 0; i < alink_backbone::MAXSUB; ++i) {
         ALINK_HIP(hipStreamCreateWithFlags(&bb->sub[i], hipStreamNonBlocking));
         ALINK_HIP(hipEventCreateWithFlags(&bb->ev_done[i], hipEventDisableTiming));
+        ALINK_HIP(hipEventCreateWithFlags(&bb->ev_front[i], hipEventDisableTiming));
     }
     ALINK_HIP(hipEventCreateWithFlags(&bb->ev_start, hipEventDisableTiming));
     bb->raw.clear();
@@ -763,6 +767,8 @@ int g_fine_max = 384;     // measured (r100, one launch at a time): the 64-chann
 extern "C" void alink_debug_set_fine_max(int n) { g_fine_max = n; }
 int g_ablate = 0;
 int g_stagger = 0;
+int g_shard_stagger = 0;
+extern "C" void alink_debug_set_shard_stagger(int on) { g_shard_stagger = on; }
 
 extern "C" void alink_debug_set_stagger(int n) { g_stagger = n < 0 ? 0 : n; }
 void* g_stamps = nullptr;
@@ -778,7 +784,7 @@ extern "C" void alink_debug_set_stamps(void* p) { g_stamps = p; }
 // same, never above the exponents already held (re-calibration after a batch left the range).  Synchronous when != 0.
 static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int N, float* dev_out,
                       void* ws, size_t ws_bytes, hipStream_t stream, float* ms, double* flops, int* kind,
-                      int* n_launches, const GradLayout* cache = nullptr, int calib = 0) {
+                      int* n_launches, const GradLayout* cache = nullptr, int calib = 0, hipEvent_t front_done = nullptr) {
     ALINK_REQUIRE(bb && dev_in && dev_out && ws, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(bb->finalized, ALINK_ESTATE, "alink_embed before alink_backbone_finalize");
     ALINK_REQUIRE(N > 0, ALINK_EINVAL, "n_images must be positive");
@@ -864,7 +870,12 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
     if ((rc = mark())) return rc;
 
     int last_out = 0;
+    bool front_marked = false;
     for (ConvLayer& L : bb->convs) {
+        if (front_done && !front_marked && L.stage >= 1) {       // everything before this launch is the HBM-bound front
+            ALINK_HIP(hipEventRecord(front_done, stream));
+            front_marked = true;
+        }
         ConvParams p{};
         p.in = buf(L.in_buf); p.wgt = L.d_w; p.bias = L.d_bias; p.alpha = L.d_alpha;
         p.resid = L.resid_buf >= 0 ? buf(L.resid_buf) : nullptr;
@@ -983,9 +994,12 @@ int alink_embed(alink_backbone_t* bb, const void* dev_in, int layout, int n_imag
         ALINK_REQUIRE(woff + need <= workspace_bytes, ALINK_ENOMEM, "workspace too small: %zu < %zu", workspace_bytes,
                       woff + need);
         ALINK_HIP(hipStreamWaitEvent(bb->sub[i], bb->ev_start, 0));
+        // staggered shards (g_shard_stagger): shard i starts when shard i - 1 has got through its HBM-bound front (stem +
+        // stage 1), so that one shard's front runs beside the other's MFMA-bound stages instead of beside its front
+        if (g_shard_stagger && i > 0) ALINK_HIP(hipStreamWaitEvent(bb->sub[i], bb->ev_front[i - 1], 0));
         const int rc = embed_impl(bb, (const char*)dev_in + (size_t)n0 * px_bytes, layout, counts[i],
                                   dev_out + (size_t)n0 * bb->cfg.emb, (char*)dev_workspace + woff, need, bb->sub[i],
-                                  nullptr, nullptr, nullptr, nullptr);
+                                  nullptr, nullptr, nullptr, nullptr, nullptr, 0, g_shard_stagger ? bb->ev_front[i] : nullptr);
         if (rc) return rc;
         ALINK_HIP(hipEventRecord(bb->ev_done[i], bb->sub[i]));
         ALINK_HIP(hipStreamWaitEvent(st, bb->ev_done[i], 0));
