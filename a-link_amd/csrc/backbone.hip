@@ -456,7 +456,7 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
 
     const bool x2 = dt == ALINK_DT_F16X2;
     if (x2) {
-        ALINK_REQUIRE(!bb->grad && !bb->split_small, ALINK_ESTATE, "the split-precision mode has no gradient pass and no small-batch split");
+        ALINK_REQUIRE(!bb->grad, ALINK_ESTATE, "the split-precision mode has no gradient pass");
         ALINK_HIP(hipMalloc((void**)&bb->d_absmax, 256));
         bb->allocs.push_back(bb->d_absmax);
     }
@@ -746,7 +746,7 @@ static int plan_split(const alink_backbone* bb, const ConvLayer& L, int N) {
     long long nwg;
     int units, kpu;                              // what a split divides: input chunks of 9 K-steps (linear) or K-steps (igemm)
     if (L.variant >= 11) {
-        const int bn = L.variant == 13 ? 64 : 128;     // (the 64-channel form chosen for small batches doubles nwg: still <= 512)
+        const int bn = (L.variant == 13 || L.variant == 15) ? 64 : 128;     // (the 64-channel form chosen for small batches doubles nwg: still <= 512)
         nwg = ((M + 223) / 224) * (L.Cout / bn);
         units = ncc; kpu = 9;
     } else if (L.variant == 0) {
@@ -906,8 +906,13 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
                 p.bias_scale = std::ldexp(1.f, e);
                 p.res_scale = L.resid_buf >= 0 ? std::ldexp(1.f, e - bexp[L.resid_buf]) : 1.f;
                 for (int r = 0; r < reps; ++r) {
-                    if (L.variant) ALINK_HIP(launch_conv3x3_direct(L.variant, cfg.dtype, p, stream));
-                    else           ALINK_HIP(launch_conv_igemm(cfg.dtype, p, stream));
+                    ConvParams q = p;
+                    if (S > 1) {           // latency mode: K split into f32 slabs of raw accumulators, scales applied by the finish kernel
+                        q.out = buf(6); q.splitk = S; q.ksteps_per_split = p.ksteps_per_split / S;
+                    }
+                    if (L.variant) ALINK_HIP(launch_conv3x3_direct(L.variant, cfg.dtype, q, stream));
+                    else           ALINK_HIP(launch_conv_igemm(cfg.dtype, q, stream));
+                    if (S > 1) ALINK_HIP(launch_conv_split_finish(cfg.dtype, p, (const float*)buf(6), S, stream));
                 }
                 return ALINK_OK;
             });

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     const int wbase = wco * (16 * TCW);
     auto chan_t = [&](int t) { return wbase + (TCW == 4 ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) : 8 * q + 4 * t); };
     auto chan_h = [&](int h) { return wbase + (TCW == 4 ? 32 * h + 8 * q : 8 * q); };
-    if (!SP && EPI == 0 && p.splitk > 1) {
+    if (EPI == 0 && p.splitk > 1) {     // (SP too: the slabs hold raw accumulators, conv_split_finish applies the scales)
         float* slab = (float*)p.out + (size_t)blockIdx.y * (size_t)totpix * p.Cout;
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
@@ -474,7 +474,7 @@ hipError_t launch_one(const ConvParams& p, hipStream_t st) {
     if (nwg <= 0 || nwg >= (1ll << 31)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)nwg, (unsigned)p.splitk);
     if (SP) {      // one epilogue form: it is a third of the 16-bit kernel's share of the time
-        if (p.splitk != 1 || p.dact) return hipErrorInvalidValue;
+        if (p.dact) return hipErrorInvalidValue;
         hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 0, SP>), grid, dim3(NT), G::lds_bytes(), st, p);
         return hipGetLastError();
     }

@@ -303,6 +303,49 @@ __global__ __launch_bounds__(256) void conv_split_finish_kernel(const ConvParams
     *(vec8*)((T*)p.out + off) = o8;
 }
 
+// split precision (ALINK_DT_F16X2): the slabs hold raw accumulators in units 2^(e_in + e_w); out / resid are f16 pairs
+// [pixel][2 Cout] with every 64-channel chunk stored [hi 64 | lo 64]
+__global__ __launch_bounds__(256) void conv_split_finish_x2_kernel(const ConvParams p, const float* __restrict__ slabs, int S) {
+    typedef _Float16 T;
+    const int c8n = p.Cout >> 3;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)p.M * c8n) return;
+    const int m = (int)(i / c8n), c0 = (int)(i % c8n) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int z = 0; z < S; ++z) {
+        const float* sp = slabs + ((size_t)z * p.M + m) * p.Cout + c0;
+        const f32x4 a = *(const f32x4*)sp, b = *(const f32x4*)(sp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += a[j]; v[4 + j] += b[j]; }
+    }
+    int cls = 0;
+    if (p.border_cls) {
+        const int rem = m % (p.Ho * p.Wo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        cls = ((oy == 0) ? 0 : ((oy == p.Ho - 1) ? 2 : 1)) * 3 + ((ox == 0) ? 0 : ((ox == p.Wo - 1) ? 2 : 1));
+    }
+    const size_t off = (size_t)m * (2 * p.Cout) + (size_t)(c0 >> 6) * 128 + (c0 & 63);
+    f16x8 rh, rl;
+    if (p.resid) {
+        rh = *(const f16x8*)((const T*)p.resid + off);
+        rl = *(const f16x8*)((const T*)p.resid + off + 64);
+    }
+    f16x8 oh, ol;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float x = fmaf(v[j], p.acc_scale, p.bias[(size_t)cls * p.Cout + c0 + j] * p.bias_scale);
+        if (p.alpha) x = x > 0.f ? x : x * p.alpha[c0 + j];
+        if (p.resid) x = fmaf((float)rh[j] + (float)rl[j], p.res_scale, x);
+        if (p.post_relu) x = fmaxf(x, 0.f);
+        oh[j] = (T)x;
+        ol[j] = (T)(x - (float)oh[j]);
+    }
+    *(f16x8*)((T*)p.out + off) = oh;
+    *(f16x8*)((T*)p.out + off + 64) = ol;
+}
+
 template <typename T>
 hipError_t launch_stem_t(const StemParams& p, hipStream_t stream) {
     const int RP = ((p.W + 2) * 3 + 7) & ~7;
@@ -348,6 +391,7 @@ hipError_t launch_conv_split_finish(int dtype, const ConvParams& p, const float*
     dim3 grid((unsigned)((tot + 255) / 256), 1, 1), block(256, 1, 1);
     if (dtype == ALINK_DT_BF16) hipLaunchKernelGGL(conv_split_finish_kernel<__bf16>, grid, block, 0, stream, p, slabs, S);
     else if (dtype == ALINK_DT_F16) hipLaunchKernelGGL(conv_split_finish_kernel<_Float16>, grid, block, 0, stream, p, slabs, S);
+    else if (dtype == ALINK_DT_F16X2 && !p.dact) hipLaunchKernelGGL(conv_split_finish_x2_kernel, grid, block, 0, stream, p, slabs, S);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

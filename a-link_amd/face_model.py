@@ -19,10 +19,10 @@ from .backbone import IRBackbone
 def default_dtype(enable_grad=False, small_batch_split=False):
     """The storage / arithmetic mode a model built through the reference's API gets when the caller names none:
     "f16x2" — split precision, whose active-learning selection sets equal the f32 arithmetic's (the reference computes
-    in float32: code/face_model.py:90) at ~15 k IR-100 embeddings/s.  The input-gradient pass and the small-batch
-    latency mode exist for 16-bit storage only: asking for either selects "bf16".  dtype="bf16" (45 k embeddings/s,
-    1 - cos ~3e-4: good for SCREENING, a third of a tight top-k turns over) and "f16" / "f32" remain explicit choices."""
-    return "bf16" if (enable_grad or small_batch_split) else "f16x2"
+    in float32: code/face_model.py:90) at ~16 k IR-100 embeddings/s.  The input-gradient pass exists for 16-bit
+    storage only: asking for it selects "bf16".  dtype="bf16" (44 k embeddings/s, 1 - cos ~3e-4: good for SCREENING, a
+    third of a tight top-k turns over) and "f16" / "f32" remain explicit choices."""
+    return "bf16" if enable_grad else "f16x2"
 
 
 def get_model(ctx, image_size, model_str, layer, dtype=None, max_batch=292, enable_grad=False,

@@ -44,7 +44,8 @@ extern "C" {
                           /* hi + lo (22 significant bits, power-of-two scales per tensor), three products hi*hi,     */
                           /* hi*lo, lo*hi on the f16 matrix cores into f32 accumulators: the accuracy of the float32  */
                           /* mode (selection sets identical to the f32 arithmetic) at ~1/3 of the bf16 rate.          */
-                          /* Needs alink_backbone_calibrate before the first alink_embed.                             */
+                          /* Needs alink_backbone_calibrate before the first alink_embed; embed / profile / the small-    */
+                          /* batch latency mode, no gradient pass.                                                    */
 
 /* input pixel layouts accepted by alink_embed */
 #define ALINK_LAYOUT_NHWC_F32 0   /* what siamese.ArcFace.process receives (code/siamese.py:232-234) */
