@@ -158,6 +158,11 @@ static inline int permuted_row(int co, int cpl) {
 
 // conv3x3_direct.hip
 int        direct_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout);
+int        direct_variant_tiles(int ksz, int stride, int pad, int H, int W, int Cin, int Cout);   // without the rolling-row kernel
+// conv3x3_c64.hip: rolling-row kernel for 64 -> 64 channel layers, weights in registers (variant 21)
+int        c64_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout);
+hipError_t c64_set_attributes();
+hipError_t launch_conv3x3_c64(int variant, int dtype, const ConvParams& p, hipStream_t st);
 int        direct_variant_cpl(int v);
 hipError_t direct_set_attributes();
 hipError_t launch_conv3x3_direct(int variant, int dtype, const ConvParams& p, hipStream_t st);

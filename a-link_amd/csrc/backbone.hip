@@ -297,7 +297,7 @@ int build_conv(alink_backbone* bb, ConvLayer& L, const std::vector<float>& w, co
         // convolution always runs at stride 1 over the layer's INPUT grid (stride-2 layers see a
         // zero-inserted d(output)), with the layer's own padding.
         const int Hb = (L.ksz == 3) ? L.Hin : L.Hout, Wb = (L.ksz == 3) ? L.Win : L.Wout;
-        L.bvariant = direct_variant(L.ksz, 1, L.pad, Hb, Wb, O, I);
+        L.bvariant = direct_variant_tiles(L.ksz, 1, L.pad, Hb, Wb, O, I);
         const int bcpl = L.bvariant ? direct_variant_cpl(L.bvariant) : 16;
         const int KB = k * k * O;
         std::vector<uint16_t> wb((size_t)I * KB);
@@ -745,7 +745,7 @@ static int plan_split(const alink_backbone* bb, const ConvLayer& L, int N) {
     const int ncc = L.Cin / 64;
     long long nwg;
     int units, kpu;                              // what a split divides: input chunks of 9 K-steps (linear) or K-steps (igemm)
-    if (L.variant >= 11) {
+    if (L.variant >= 11 && L.variant <= 15) {
         const int bn = (L.variant == 13 || L.variant == 15) ? 64 : 128;     // (the 64-channel form chosen for small batches doubles nwg: still <= 512)
         nwg = ((M + 223) / 224) * (L.Cout / bn);
         units = ncc; kpu = 9;

@@ -264,7 +264,7 @@ int add_conv(alink_resnet50* r, const std::string& name, int k, int stride, int 
     Op op;
     op.kind = 2;
     op.name = name;
-    op.variant = direct_variant(k, stride, pad, Hin, Win, cin, cout);
+    op.variant = direct_variant_tiles(k, stride, pad, Hin, Win, cin, cout);
     const int cpl = op.variant ? direct_variant_cpl(op.variant) : 16;
     const int K = k * k * cin;
     std::vector<uint16_t> wq((size_t)cout * K);

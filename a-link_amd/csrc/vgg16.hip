@@ -176,7 +176,7 @@ int alink_vgg16_finalize(alink_vgg16_t* r) {
             const int cout = kWidth[b], K = 9 * cin;
             const auto& w = r->raw.at(lname(b, l) + "/kernel");       // (3, 3, cin, cout)
             VOp op; op.kind = 1; op.name = lname(b, l);
-            op.variant = direct_variant(3, 1, 1, H, W, cin, cout);
+            op.variant = direct_variant_tiles(3, 1, 1, H, W, cin, cout);
             const int cpl = op.variant ? direct_variant_cpl(op.variant) : 16;
             std::vector<uint16_t> wq((size_t)cout * K);
             for (int co = 0; co < cout; ++co) {

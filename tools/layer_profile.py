@@ -19,6 +19,7 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--ablate", type=int, default=0)
 ap.add_argument("--no-direct", action="store_true")
 ap.add_argument("--no-pair", action="store_true")
+ap.add_argument("--no-c64", action="store_true", help="A/B: the 112-wide 64->64 layer on the row-aligned tile kernel instead of the rolling-row kernel")
 ap.add_argument("--no-fuse-sc", action="store_true", help="A/B: projection shortcuts as launches of their own")
 ap.add_argument("--linear", type=int, default=-1, help="linear-tile widths: bit0 56, bit1 28, bit2 14, bit3 7 (default: library default)")
 a = ap.parse_args()
@@ -34,6 +35,8 @@ if a.linear >= 0:
     _lib.alink_debug_set_linear(a.linear)
 if a.no_fuse_sc:
     _lib.alink_debug_set_fuse_shortcut(0)
+if a.no_c64:
+    _lib.alink_debug_set_c64(0)
 bb = IRBackbone(W.synthetic_ir_params(units, seed=1), dtype=a.dtype, max_batch=a.batch)
 x = torch.randint(0, 256, (a.batch, 112, 112, 3), dtype=torch.uint8).float().cuda()
 for _ in range(2):
