@@ -301,7 +301,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     const int wbase = wco * (16 * TCW);
     auto chan_t = [&](int t) { return wbase + (TCW == 4 ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) : 8 * q + 4 * t); };
     auto chan_h = [&](int h) { return wbase + (TCW == 4 ? 32 * h + 8 * q : 8 * q); };
-    if (EPI == 0 && p.splitk > 1) {     // (SP too: the slabs hold raw accumulators, conv_split_finish applies the scales)
+    // split-K slabs: a run-time branch of the generic 16-bit epilogue; for split precision a compile-time form of its own
+    // (EPI == 3) — as a run-time branch there it cost the main form 120 spilled registers
+    if (SP ? EPI == 3 : (EPI == 0 && p.splitk > 1)) {     // (the SP slabs hold raw accumulators, conv_split_finish applies the scales)
         float* slab = (float*)p.out + (size_t)blockIdx.y * (size_t)totpix * p.Cout;
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
@@ -475,7 +477,8 @@ hipError_t launch_one(const ConvParams& p, hipStream_t st) {
     const dim3 grid((unsigned)nwg, (unsigned)p.splitk);
     if (SP) {      // one epilogue form: it is a third of the 16-bit kernel's share of the time
         if (p.dact) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 0, SP>), grid, dim3(NT), G::lds_bytes(), st, p);
+        if (p.splitk > 1) hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 3, SP>), grid, dim3(NT), G::lds_bytes(), st, p);
+        else              hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 0, SP>), grid, dim3(NT), G::lds_bytes(), st, p);
         return hipGetLastError();
     }
     const bool plain = p.splitk == 1 && !p.dact && !p.post_relu && !p.stamps && !g_generic_epilogue;
@@ -497,8 +500,12 @@ hipError_t set_attr_one() {
 }
 template <int W, int TCW>
 hipError_t set_attr_sp() {
-    return hipFuncSetAttribute((const void*)conv3x3_linear_kernel<_Float16, W, TCW, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)Lin<W, TCW>::lds_bytes());
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<_Float16, W, TCW, 0, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lin<W, TCW>::lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<_Float16, W, TCW, 3, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lin<W, TCW>::lds_bytes());
+    return e;
 }
 
 // Which map widths take the linear-tile kernel: bit 0 = 56, bit 1 = 28, bit 2 = 14, bit 3 = 7, bit 4 = 112 (split

@@ -53,3 +53,25 @@ def test_product_never_imports_oracle():
             if f.endswith(".py") or f.endswith(".hip") or f.endswith(".h"):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_no_convolution_kernel_spills_to_scratch():
+    """The build keeps hipcc's per-kernel resource report beside every object (a-link_amd/lib/obj/<file>.usage).  No
+    instantiation of the convolution kernels may use scratch: a spill inside a K loop is silent and costly (round 3: a
+    run-time branch added to the split-precision form of conv3x3_linear spilled 120 registers and cost its dominant
+    kernel 8 %)."""
+    obj = os.path.join(ROOT, "a-link_amd", "lib", "obj")
+    seen = 0
+    for name in ("conv3x3_linear", "conv3x3_direct", "conv3x3_c64", "conv_igemm"):
+        path = os.path.join(obj, name + ".usage")
+        assert os.path.exists(path), "build with the Makefile (it writes %s)" % path
+        fn = None
+        for ln in open(path):
+            m = re.search(r"Function Name: (\S+)", ln)
+            if m:
+                fn = m.group(1)
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", ln)
+            if m and fn and "kernel" in fn:
+                seen += 1
+                assert int(m.group(1)) == 0, "%s uses %s bytes of scratch per lane" % (fn, m.group(1))
+    assert seen >= 60, seen
