@@ -60,6 +60,8 @@ PROTOTYPES = {
     "alink_resnet50_finalize": (_i, [_vp]),
     "alink_resnet50_workspace_bytes": (_sz, [_vp, _i]),
     "alink_resnet50_embed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "alink_resnet50_calibrate": (_i, [_vp, _vp, _i, _i, _vp, _sz, _i, _vp]),
+    "alink_resnet50_range_flag": (_i, [_vp, _i]),
     "alink_resnet50_profile": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp, _vp, _vp, C.POINTER(_i)]),
     "alink_resnet50_op_name": (C.c_char_p, [_vp, _i]),
     "alink_vgg16_create": (_vp, [_i, _i, _i]),

@@ -98,9 +98,13 @@ class VGGResNet50(object):
             params = load_keras_h5(weights)
         else:
             params = weights
+        # dtype "f16x2": split precision (f16 pairs, three products on the f16 matrix cores, calibrated power-of-two scales:
+        # a-link_amd/backbone.py) — features to float32 accuracy, what selection through this feature model needs
+        self.dtype = dtype
         with _abi.on_device(device):
             self.h = self.lib.alink_resnet50_create(int(image_size[0]), int(image_size[1]),
-                                                    {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16}[dtype], float(bn_eps))
+                                                    {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16, "f16x2": _abi.DT_F16X2}[dtype],
+                                                    float(bn_eps))
         if not self.h:
             raise _abi.AlinkError("alink_resnet50_create: " + self.lib.alink_last_error().decode())
         name, cnt = C.c_char_p(), C.c_size_t()
@@ -113,6 +117,25 @@ class VGGResNet50(object):
             _abi.check(self.lib.alink_resnet50_load(self.h, name.value, _abi.ptr(a), a.size), "load " + key)
         _abi.check(self.lib.alink_resnet50_finalize(self.h), "alink_resnet50_finalize")
         self._ws = None
+        if dtype == "f16x2":         # scales from three probe images (uniform noise, black, white); a batch that leaves the
+            h, w = self.image_size   # range later is re-calibrated on (scales only go down) and re-run
+            g = torch.Generator(device="cpu").manual_seed(0)
+            probe = torch.stack([torch.randint(0, 256, (h, w, 3), generator=g).float(), torch.zeros(h, w, 3),
+                                 torch.full((h, w, 3), 255.0)])
+            self.calibrate(probe)
+
+    def calibrate(self, x, preprocessed=False, merge=False):
+        """dtype 'f16x2': choose the per-tensor power-of-two scales from these images (at most max_batch are used)."""
+        if self.dtype != "f16x2":
+            raise _abi.AlinkError("only dtype='f16x2' is calibrated")
+        torch = self.torch
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        x = x[:self.max_batch].to("cuda:%d" % self.device).to(torch.float32).contiguous()
+        ws, wsb = self._workspace(x.shape[0])
+        torch.cuda.synchronize(self.device)
+        _abi.check(self.lib.alink_resnet50_calibrate(self.h, _abi.ptr(x), x.shape[0], 1 if preprocessed else 0, C.c_void_p(ws), wsb,
+                                                     1 if merge else 0, _abi.current_stream(self.device)), "alink_resnet50_calibrate")
 
     def __del__(self):
         try:
@@ -130,7 +153,7 @@ class VGGResNet50(object):
         off = (-t.data_ptr()) % 256
         return t.data_ptr() + off, t.numel() - off
 
-    def embed_device(self, x, preprocessed=False, out=None):
+    def embed_device(self, x, preprocessed=False, out=None, _retry=True):
         """x: CUDA (N, H, W, 3) float32 — raw RGB 0..255, or preprocess()'d when preprocessed=True."""
         torch = self.torch
         if x.ndim != 4 or tuple(x.shape[1:]) != self.image_size + (3,):
@@ -145,6 +168,13 @@ class VGGResNet50(object):
             _abi.check(self.lib.alink_resnet50_embed(self.h, _abi.ptr(x[i:i + m]), m, 1 if preprocessed else 0,
                                                      _abi.ptr(out[i:i + m]), C.c_void_p(ws), wsb, _abi.current_stream(self.device)),
                        "alink_resnet50_embed")
+        if self.dtype in ("f16", "f16x2"):       # 16-bit float storage: never hand back non-finite features silently
+            torch.cuda.synchronize(self.device)
+            if self.lib.alink_resnet50_range_flag(self.h, 1):
+                if self.dtype == "f16x2" and _retry:
+                    self.calibrate(x, preprocessed, merge=True)
+                    return self.embed_device(x, preprocessed, out=out, _retry=False)
+                raise _abi.AlinkError("activations exceeded the float16 range in this network: use dtype='bf16' or 'f16x2'")
         return out
 
     def predict(self, X, batch_size=128, verbose=0, preprocessed=True):

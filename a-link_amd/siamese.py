@@ -183,10 +183,13 @@ class RESNET50:
     the keras-vggface weight file (`rcmalli_vggface_tf_notop_resnet50.h5`), a dict, or None for
     synthetic weights (keras-vggface downloads its file; there is no network here)."""
 
-    def __init__(self, shape, weights=None, dtype="bf16", max_batch=128, seed=1):
+    def __init__(self, shape, weights=None, dtype=None, max_batch=128, seed=1):
         from .resnet50 import VGGResNet50
         self.shape = shape + (3,)
-        self.model = VGGResNet50(image_size=tuple(shape), weights=weights, dtype=dtype, max_batch=max_batch, seed=seed)
+        # dtype=None: "f16x2", split precision — features to float32 accuracy, so that the selection the drivers make from
+        # them (code/ALINK.py:67, code/ALINK_MTP.py:84, code/existing_al.py:58) follows the reference's float32 arithmetic;
+        # "bf16" (3x faster, 1 - cos ~1e-4) and "f16" remain explicit choices
+        self.model = VGGResNet50(image_size=tuple(shape), weights=weights, dtype=dtype or "f16x2", max_batch=max_batch, seed=seed)
 
     def preprocess(self, X):
         """utils.preprocess_input(np.copy(X), version=2): RGB -> BGR, subtract the VGGFace2 channel means."""

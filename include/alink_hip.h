@@ -189,6 +189,13 @@ int alink_resnet50_finalize(alink_resnet50_t* r);
 size_t alink_resnet50_workspace_bytes(const alink_resnet50_t* r, int n_images);
 int alink_resnet50_embed(alink_resnet50_t* r, const float* dev_in, int n_images, int preprocessed,
                          float* dev_out, void* dev_workspace, size_t workspace_bytes, void* stream);
+/* dtype = ALINK_DT_F16X2 (split precision: features to float32 accuracy, so that selection through the drivers that use
+ * this feature model — code/ALINK.py:67, code/ALINK_MTP.py:84, code/existing_al.py:58 — follows the reference's float32
+ * arithmetic): as for the IR backbone, alink_resnet50_calibrate once before the first embed (and again with merge != 0 if
+ * alink_resnet50_range_flag reports a batch that left the range: a non-finite feature was written since the last reset). */
+int alink_resnet50_calibrate(alink_resnet50_t* r, const float* dev_in, int n_images, int preprocessed,
+                             void* dev_workspace, size_t workspace_bytes, int merge, void* stream);
+int alink_resnet50_range_flag(alink_resnet50_t* r, int reset);
 /* per-op HIP-event timing of one forward (synchronous): ms[i] / flops[i] for op i, name via op_name */
 int alink_resnet50_profile(alink_resnet50_t* r, const float* dev_in, int n_images, float* dev_out,
                            void* dev_workspace, size_t workspace_bytes, void* stream, float* ms,

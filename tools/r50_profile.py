@@ -10,7 +10,9 @@ import a_link_amd  # noqa: F401,E402
 from a_link_amd.resnet50 import VGGResNet50  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-m = VGGResNet50(max_batch=n)
+dt_ = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+m = VGGResNet50(max_batch=n, dtype=dt_)
+print("dtype", dt_)
 x = torch.randint(0, 256, (n, 224, 224, 3), device="cuda").float()
 for _ in range(3):
     m.embed_device(x)
