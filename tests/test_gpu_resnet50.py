@@ -93,3 +93,94 @@ def test_alink_py_shape_pipeline(net):
     heads = [siamese.SiameseNetwork((2048,), "e%d" % i, 0.1, seed=i) for i in range(2)]
     p = committee.Bagging(heads, []).predict([f[:2], f[2:]])
     assert p.shape == (2, 2) and np.allclose(p.sum(1), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["f16x2", "bf16"])
+def test_alink_py_iteration_selection_through_resnet50_features(gpu, capsys, dtype):
+    """One A-LINK iteration the way code/ALINK.py runs it — VGGFace2 ResNet-50 features (code/ALINK.py:67), an ensemble
+    of two pair heads on 2048-d features plus the disguised-faces head on two noisy copies, the selection rule of
+    code/ALINK.py:170-201 (column 1) and code/ALINK_arc.py:167-198 (column 0) — against the oracle's query sets on the
+    f32 torch-CPU ResNet-50's features of the same pixels.  Heads are trained oracle-side on other identities so that
+    probabilities spread over (0, 1).  Split precision (the default of siamese.RESNET50) must reproduce both query sets;
+    bf16 storage is measured beside it (screening)."""
+    from a_link_amd import committee, pairs, resnet50 as R, selection, siamese
+    from oracle import al_logic as OA
+    from oracle import vgg_resnet50 as O
+    import _synth
+    size = (224, 224)
+    params = R.synthetic_params(3)
+
+    def feats_o(x):
+        f = O.process(params, x)
+        return (f / np.linalg.norm(f, axis=1, keepdims=True)).astype(np.float32)
+
+    from oracle import siamese_head as OH
+
+    class _Head(object):                 # an oracle head with fixed weights (predict / get_weights: what the test needs)
+        def __init__(self, ws):
+            self.ws = ws
+
+        def predict(self, X):
+            return OH.forward(self.ws, X[0], X[1])
+
+        def get_weights(self):
+            return self.ws
+
+    def spread_head(seed, L, R):
+        """glorot head whose last layer is rescaled so that probabilities run from ~0.12 to ~0.88 over these pairs (a
+        fresh head on the features of a random-weight ResNet-50 puts every pair at 0.65 +- 0.01): the selection rule then
+        has cuts inside the data, and the gain (~1e3) makes every probability a sensitive function of the features."""
+        ws = OH.init_weights(2048, seed=seed)
+        _, (d, z1, a1, z2, a2) = OH.forward(ws, L, R, cache=True)
+        t = (a2 @ (ws[4][:, 1] - ws[4][:, 0])).astype(np.float64)
+        lo, hi = np.percentile(t, [1, 99])
+        gain = np.float32(4.0 / max(hi - lo, 1e-12))
+        ws[4] = (ws[4] * gain).astype(np.float32)
+        ws[5] = np.array([0, np.float32(-gain * 0.5 * (lo + hi))], np.float32)
+        return _Head(ws)
+
+    n_plain, n_dig = [2, 1, 2, 2, 1, 2, 2, 2], [2, 3, 2, 1, 2, 2, 3, 2]
+    te = _synth.identities(8, [a + b for a, b in zip(n_plain, n_dig)], size, seed=7, var=40.0)
+    uniq = _synth.unique_rows(te, n_plain)
+    li, ri, y = pairs.createMiniBatchIndices(n_plain, n_dig)
+    rng = np.random.default_rng(5)
+    noises = [uniq + rng.normal(10, np.sqrt(10), uniq.shape).astype(np.float32),
+              uniq + uniq * (rng.normal(0, 1, uniq.shape).astype(np.float32) / 15)]
+    # oracle
+    Eo = feats_o(uniq)
+    m1 = [spread_head(1, Eo[li], Eo[ri]), spread_head(2, Eo[li], Eo[ri])]
+    Eno = [feats_o(nz) for nz in noises]
+    m2 = spread_head(3, Eno[0][li], Eno[0][ri])
+    ens_o = OA.bagging_predict([m.predict([Eo[li], Eo[ri]]) for m in m1])
+    dis_o = [m2.predict([En[li], En[ri]]) for En in Eno]
+    # device
+    fm = siamese.RESNET50(size, weights=params, dtype=dtype, max_batch=32)
+
+    def feats_g(x):
+        f = fm.process(x)
+        return (f / np.linalg.norm(f, axis=1, keepdims=True)).astype(np.float32)
+
+    heads = []
+    for i, om in enumerate(m1 + [m2]):
+        net = siamese.SiameseNetwork((2048,), "r%d" % i, 0.1, seed=i)
+        net.siamese_net.set_weights(om.get_weights())
+        heads.append(net)
+    E = feats_g(uniq)
+    ens = committee.Bagging(heads[:-1], []).predict_indexed(E, E, li, ri).cpu().numpy()
+    dis = [heads[-1].siamese_net.predict_device(En, En, li, ri).cpu().numpy() for En in (feats_g(nz) for nz in noises)]
+    d_ens = float(np.abs(ens - ens_o).max())
+    d_dis = float(max(np.abs(a - b).max() for a, b in zip(dis, dis_o)))
+    pct = np.percentile(ens_o[:, 0], [1, 99])
+    assert pct[0] < 0.3 and pct[1] > 0.7, pct                      # spread, not 0.5 +- 0.02
+    diffs = []
+    for col in (0, 1):
+        q, active, labels = selection.select_queries(ens, dis, y, col=col, disparity_ratio=0.25, eps=0.05)
+        qs, act_o = OA.select_queries(ens_o, dis_o, y, col, 0.25, 0.05)
+        diffs.append((len(qs), len(set(q) ^ qs)))
+        if dtype == "f16x2":
+            assert set(q) == qs and active == act_o, (col, sorted(set(q) ^ qs))
+    with capsys.disabled():
+        print("\n[ALINK.py shape, VGGFace2 ResNet-50 %s @224, P=%d] max|d ens|=%.2e max|d dis|=%.2e  query sets (size, differing): "
+              "column 0 %s, column 1 %s" % (dtype, len(li), d_ens, d_dis, diffs[0], diffs[1]))
+    assert max(d[0] for d in diffs) >= 10
+    assert d_ens < (2e-5 if dtype == "f16x2" else 0.1), d_ens
