@@ -192,27 +192,80 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    auto mma = [&](const char* pb, const char* wb) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? foff1 : foff0;
+            vec8 wf[4], pf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[t] = *(const vec8*)(wb + t * 2048 + fo);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pf[u] = *(const vec8*)(pb + u * 2048 + fo);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[t][u] = mfma16<T>(wf[t], pf[u], acc[t][u]);
+        }
+    };
+    if constexpr (SP) {
+        // Split precision: per REAL K-step (tap, 64-channel chunk) four tiles are staged — X_lo, W_hi, X_hi, W_lo — and
+        // three products taken: X_lo W_hi, X_hi W_hi, X_hi W_lo.  The four LDS tiles have fixed roles (A0 = X_lo, A1 = X_hi,
+        // W0 = W_hi, W1 = W_lo); each phase's prefetch goes into a tile the phase does not read:
+        //   phase a (A0, W0): fetch X_hi -> A1      phase b (A1, W0): fetch W_lo -> W1      phase c (A1, W1): fetch the next
+        //   step's X_lo -> A0 and W_hi -> W0.   (The first form of this kernel staged a pixel tile AND a weight tile for each
+        //   of the three products: six tile loads per real step instead of four.)
+        char* const A0 = smem, * const W0 = smem + BM * 128, * const A1 = smem + TILE_BYTES, * const W1 = smem + TILE_BYTES + BM * 128;
+        auto stage_a = [&](char* dst, int part) {          // the cursor's pixel tile: part 0 = hi half of the chunk, 1 = lo half
+            const int tap_off = (s_ky * W + s_kx) * CinP + (2 * s_cc + part) * 64;
+#pragma unroll
+            for (int j = 0; j < PJ; ++j) {
+                const bool ok = (pmask[j] >> s_tap) & 1u;
+                dma16(ok ? gin + (poff[j] + tap_off) : gz + (tid & 7) * 8, dst + (wave * 8 + 32 * j) * 128);
+            }
+        };
+        auto stage_w = [&](char* dst, int blk) {           // the cursor's weight tile: blk 0 = hi, 1 = lo
+            const int wk_off = ((s_tap * cpt + s_cc) * 2 + blk) * 64;
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) dma16(gw + (woff[j] + wk_off), dst + (wave * 8 + 32 * j) * 128);
+        };
+        auto advance = [&]() {
+            if (++s_cc == cpt) {
+                s_cc = 0;
+                ++s_tap;
+                if (++s_kx == ksz) { s_kx = 0; ++s_ky; }
+            }
+        };
+        const int r1 = kt1 / 3;                            // real steps r0 .. r1 (a K split cuts between real steps)
+        if (r0 < r1) {
+            stage_a(A0, 1);
+            stage_w(W0, 0);
+            __syncthreads();
+            const char* const pa0 = A0 + (wp * 64) * 128, * const pa1 = A1 + (wp * 64) * 128;
+            const char* const pw0 = W0 + (wc * 64) * 128, * const pw1 = W1 + (wc * 64) * 128;
+            for (int r = r0; r < r1; ++r) {
+                stage_a(A1, 0);                            // X_hi of this step
+                mma(pa0, pw0);                             // X_lo W_hi
+                __syncthreads();
+                stage_w(W1, 1);                            // W_lo of this step
+                mma(pa1, pw0);                             // X_hi W_hi
+                __syncthreads();
+                advance();
+                if (r + 1 < r1) {                          // X_lo and W_hi of the next step
+                    stage_a(A0, 1);
+                    stage_w(W0, 0);
+                }
+                mma(pa1, pw1);                             // X_hi W_lo
+                __syncthreads();
+            }
+        }
+    } else
     if (kt0 < kt1) {
         stage(0, kt0);
         __syncthreads();
         for (int kt = kt0; kt < kt1; ++kt) {
             const int cur = (kt - kt0) & 1;
             if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
-            const char* pb = smem + cur * TILE_BYTES + (wp * 64) * 128;
-            const char* wb = smem + cur * TILE_BYTES + (BM + wc * 64) * 128;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int fo = ks ? foff1 : foff0;
-                vec8 wf[4], pf[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) wf[t] = *(const vec8*)(wb + t * 2048 + fo);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) pf[u] = *(const vec8*)(pb + u * 2048 + fo);
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[t][u] = mfma16<T>(wf[t], pf[u], acc[t][u]);
-            }
+            mma(smem + cur * TILE_BYTES + (wp * 64) * 128, smem + cur * TILE_BYTES + (BM + wc * 64) * 128);
             __syncthreads();
         }
     }
