@@ -172,7 +172,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c64_kernel(const ConvParams p) 
 #pragma unroll 1
         for (int k = 0; k < BR / P; ++k) {
             // This pass's rows have landed (all four waves' DMAs) and the last pass is read out.  Vector-memory operations
-            // complete in issue order: behind the DMAs waited for here the wave has issued the 7 DMAs of the next pass
+            // of a wave — loads, stores and LDS-DMA alike — retire from vmcnt in issue order on this part
+            // (MI355X_MICROARCH.md, "s_waitcnt vmcnt(N)"; flat_* excepted, not used here): behind the DMAs waited for here the wave has issued the 7 DMAs of the next pass
             // and (from the second pass on) the 7 output stores of the pass before — those stay in flight.
             // (with a residual, its 7 loads sit between them and count too: they are complete, the count is positional)
             if (k == 0)       wait_all_but_then_barrier<TPWV>();
