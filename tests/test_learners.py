@@ -58,3 +58,17 @@ def test_committee_vote_proba_and_mean():
     assert np.array_equal(com.predict(X), (X[0][:, 0] > 0).astype(int))
     idx, _ = com.query(X, n_instances=3)
     assert set(idx.tolist()) == {3, 4, 5}
+
+
+def test_default_precision_of_the_reference_api_classes():
+    """The reference embeds in float32 (code/face_model.py:90): models built through its API without a dtype get the split
+    precision mode, whose selection sets equal the f32 arithmetic's; the gradient pass exists for 16-bit storage only."""
+    from a_link_amd import _abi, face_model
+    assert face_model.default_dtype() == "f16x2"
+    assert face_model.default_dtype(small_batch_split=True) == "f16x2"
+    assert face_model.default_dtype(enable_grad=True) == "bf16"
+    assert (_abi.DT_BF16, _abi.DT_F16, _abi.DT_F32, _abi.DT_F16X2) == (0, 1, 2, 3)
+    import re, os
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "alink_hip.h")).read()
+    for name, val in (("ALINK_DT_BF16", 0), ("ALINK_DT_F16", 1), ("ALINK_DT_F32", 2), ("ALINK_DT_F16X2", 3)):
+        assert re.search(r"#define\s+%s\s+%d\b" % (name, val), hdr), name
