@@ -8,7 +8,9 @@ import a_link_amd  # noqa
 from a_link_amd import siamese
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4672
-fm = siamese.ArcFace((112, 112), "synthetic:r100")
+dt_ = sys.argv[2] if len(sys.argv) > 2 else None          # None: the API default (f16x2)
+fm = siamese.ArcFace((112, 112), "synthetic:r100", dtype=dt_)
+print("backbone dtype:", fm.model.model.dtype)
 rng = np.random.RandomState(0)
 x8 = rng.randint(0, 256, (n, 112, 112, 3)).astype(np.uint8)
 xf = x8.astype(np.float32)
