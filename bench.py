@@ -75,8 +75,9 @@ def _launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (default 100: ~2.6 s of the headline workload, long enough for "
+                    "a power / utilisation sampler beside the run to see it)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="r100", choices=["r100", "r50", "r34", "r18"])
     ap.add_argument("--batch", type=int, default=1168, help="images per step per GPU")
     ap.add_argument("--chunk", type=int, default=292, help="images per alink_embed call: 292 x 196 pixels = 511 workgroups of the "
@@ -225,7 +226,7 @@ def main():
         if args.select_dtype == "f16x2":
             bs.calibrate(x[:64])
         sel_out = torch.empty((B, 512), dtype=torch.float32, device="cuda")
-        sel_steps = max(2, args.steps // (4 if args.select_dtype == "f16x2" else 10))
+        sel_steps = max(2, args.steps // (4 if args.select_dtype == "f16x2" else 25))
         bs.embed_device(x, sel_out)
         torch.cuda.synchronize()
         barrier()

@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O/prof
 cd $R
-python bench.py --config3 > $O/${P}_bench_r100.json 2> $O/${P}_bench_r100.err
+python bench.py --config3 --steps 100 --warmup 10 > $O/${P}_bench_r100.json 2> $O/${P}_bench_r100.err
 python bench.py --dtype f16x2 --no-cpu-baseline > $O/${P}_bench_r100_f16x2.json 2>/dev/null
 python bench.py --dtype f16x2 --weights normalized --no-cpu-baseline > $O/${P}_bench_r100_f16x2_normalized.json 2>/dev/null
 python bench.py --dtype f16 --weights normalized --no-cpu-baseline --select-dtype none > $O/${P}_bench_r100_f16_normalized.json 2>/dev/null
