@@ -408,6 +408,10 @@ def main():
                             "achieved": dom_achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": dom_achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                             "flops_per_launch": dom_f, "avg_launch_ms": dom_avg,
+                            # split precision issues three MFMA FLOPs per algorithmic FLOP (hi*hi, hi*lo, lo*hi): what the matrix
+                            # pipes actually do, beside the algorithmic fraction above
+                            "mfma_flops_issued_per_algorithmic_flop": 3 if args.dtype == "f16x2" else 1,
+                            "frac_issued": dom_achieved * (3 if args.dtype == "f16x2" else 1) / MFMA_PEAK_TFLOPS,
                             "timing": "HIP events on the launch stream around 4 back-to-back launches of every kernel of "
                                       "the chain, kernels run one at a time (alink_embed_profile); rocprofv3 --kernel-trace of "
                                       "`bench.py --streams 1 --batch %d` gives the same averages (profiles/)" % args.chunk,
