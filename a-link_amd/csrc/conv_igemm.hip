@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             if (p.resid) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    if (SP) {   // hi + lo is exact in f32 (22 significant bits)
+                    if (SP) {   // hi + lo in f32: at most one rounding, 2^-24 relative
                         v[i] = fmaf((float)res[u][0][i] + (float)res[u][2][i], p.res_scale, v[i]);
                         v[8 + i] = fmaf((float)res[u][1][i] + (float)res[u][3][i], p.res_scale, v[8 + i]);
                     } else {

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void stem7_x2_kernel(const Stem7Params p, floa
     }
 }
 
-// max pooling on f16 pairs: the maximum of hi + lo (exact in f32), stored as a pair again; the scale is the input's
+// max pooling on f16 pairs: the maximum of hi + lo (formed in f32: at most one rounding), stored as a pair again; the scale is the input's
 __global__ void maxpool3s2_x2_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, int N, int H, int W, int C,
                                      int Ho, int Wo) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
