@@ -78,10 +78,10 @@ struct C64 {
     static constexpr int XBYTES = RING * PITCH;
     static constexpr size_t lds_bytes() { return (size_t)XBYTES + 10 * 64 * 4; }
     static_assert(224 % W == 0 && W % 16 == 0, "whole 16-pixel tiles per row");
-    static_assert(W % BR == 0 && BR % P == 0 && BR / P >= 2, "bands of whole passes, at least two");
+    static_assert(W % BR == 0 && BR % P == 0 && BR / P >= 4 && (BR / P) % 2 == 0, "bands of an even number (>= 4) of whole passes");
 };
 
-template <typename T, int W>
+template <typename T, int W, int EPI>
 __global__ __launch_bounds__(NT, 1) void conv3x3_c64_kernel(const ConvParams p) {
     typedef typename Vec8<T>::type vec8;
     typedef C64<W> G;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c64_kernel(const ConvParams p) 
             if (slot >= RING) slot -= RING;
             const int px = seg * 8 + (lane >> 3);
             const int piece = (lane & 7) ^ (((px + 1) >> 1) & 7);
-            const bool ok = (unsigned)r < (unsigned)H && p.ablate != 2;   // (diagnostic timing mode 2: every row from the zero page)
+            const bool ok = (unsigned)r < (unsigned)H && (EPI != 0 || p.ablate != 2);   // (diagnostic timing mode 2: every row from the zero page)
             const T* src = ok ? gin + ((size_t)((img_row0 + r) * W + px) * 64 + piece * 8) : gz + (lane & 7) * 8;
             dma16(src, smem + slot * PITCH + (seg * 8 + 1) * 128);
         }
@@ -160,6 +160,83 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c64_kernel(const ConvParams p) 
         for (int i = 0; i < 8; ++i) al[i] = p.alpha[ch * 32 + 8 * q + i];
     }
 
+    // one pass of MFMAs: output rows (first row of the pass) + ph, taps from the ring slots starting at s0
+    auto compute = [&](f32x4 (&acc)[2][TPWV], int s0) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int u = 0; u < TPWV; ++u) acc[ct][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI == 0 && p.ablate == 1) return;     // (diagnostic timing mode 1, generic form only: no operand reads, no MFMAs)
+        int sb[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            int slot = s0 + ph + ky;                                 // row (y + ph) + ky - 1
+            if (slot >= RING) slot -= RING;
+            sb[ky] = slot * PITCH;
+        }
+        vec8 pf[2][TPWV];
+#pragma unroll
+        for (int u = 0; u < TPWV; ++u) pf[0][u] = *(const vec8*)(smem + (sb[0] + loff[0][0]) + 2048 * u);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            if (st + 1 < 18) {
+                const int tn = (st + 1) >> 1, ksn = (st + 1) & 1;
+#pragma unroll
+                for (int u = 0; u < TPWV; ++u)
+                    pf[(st + 1) & 1][u] = *(const vec8*)(smem + (sb[tn / 3] + loff[tn % 3][ksn]) + 2048 * u);
+            }
+            const int tap = st >> 1, ks = st & 1;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int u = 0; u < TPWV; ++u) acc[ct][u] = mfma16<T>(wr[ct][tap][ks], pf[st & 1][u], acc[ct][u]);
+        }
+    };
+    // epilogue of one pass: output row y, pixel x = 16 u + d, channels 32 ch + 8 q .. + 7.  EPI fixes the form at compile
+    // time (1: bias by border class + PReLU, 2: bias + residual, 0: by run-time flags) so that it is straight-line code the
+    // compiler can weave into the NEXT pass's MFMAs (it is issued one pass late, from the previous pass's accumulators:
+    // with one wave per SIMD nothing else would cover its ~2 k cycles of VALU, LDS reads and stores)
+    auto epilogue = [&](const f32x4 (&acc)[2][TPWV], int y, long long img_row0) {
+        const bool has_alpha = EPI == 1 || (EPI == 0 && p.alpha), has_resid = EPI == 2 || (EPI == 0 && p.resid);
+        const bool classes = EPI == 1 || (EPI == 0 && p.border_cls);
+        const int rc = classes ? (y == 0 ? 0 : (y == H - 1 ? 2 : 1)) : 0;
+        const size_t rowoff = (size_t)((img_row0 + y) * W) * 64 + ch * 32 + 8 * q;
+        vec8 res[TPWV];
+        if (has_resid) {
+#pragma unroll
+            for (int u = 0; u < TPWV; ++u) res[u] = *(const vec8*)((const T*)p.resid + rowoff + (size_t)(16 * u + d) * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < TPWV; ++u) {
+            const int x = 16 * u + d;
+            const int cls = classes ? rc * 3 + (x == 0 ? 0 : (x == W - 1 ? 2 : 1)) : 0;
+            const f32x4 b0 = *(const f32x4*)(ebias + cls * 64 + ch * 32 + 8 * q);
+            const f32x4 b1 = *(const f32x4*)(ebias + cls * 64 + ch * 32 + 8 * q + 4);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = acc[0][u][j] + b0[j]; v[4 + j] = acc[1][u][j] + b1[j]; }
+            if (has_alpha) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * al[i];
+            }
+            if (has_resid) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += (float)res[u][i];
+            }
+            vec8 o8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o8[i] = (T)v[i];
+            if (EPI != 0 || p.ablate != 3 || o8[0] == (T)12345.f)   // (diagnostic timing mode 3, generic form only: no output stores)
+                *(vec8*)((T*)p.out + rowoff + (size_t)x * 64) = o8;
+        }
+    };
+    // (A scheduling request that spreads the epilogue evenly over the block — __builtin_amdgcn_sched_group_barrier, two
+    // MFMAs / one LDS read / three VALU instructions repeated — was tried and is slower: 0.373 against 0.307 ms; it breaks up
+    // the operand prefetch the compiler's own order keeps.  Left to itself the compiler weaves the epilogue into the last
+    // fifth of the MFMAs.)
+    constexpr int VMI = TPWV * ((EPI == 1) ? 2 : 3);   // vector-memory operations a wave issues per steady-state iteration
+                                                       // (7 row DMAs + 7 stores [+ 7 residual loads]; EPI 0 counts the loads too)
+
     for (long long band = lid; band < nbands; band += nwg) {
         const int n = (int)(band / bands_per_img);
         const int y0 = (int)(band - (long long)n * bands_per_img) * BR;
@@ -169,90 +246,48 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c64_kernel(const ConvParams p) 
         stage_rows(img_row0, y0 - 1, P + 2, 0);                     // rows y0-1 .. y0+P -> slots 0 .. P+1   (pass 0)
         stage_rows(img_row0, y0 + P + 1, P, P + 2);                 // rows of pass 1
         int s0 = 0;                                                  // slot of row (first output row of the pass) - 1
+        f32x4 accA[2][TPWV], accB[2][TPWV];
+        // ---- pass 0: its rows are everything but the wave's 7 youngest DMAs (those are pass 1's) -----------------------
+        wait_all_but_then_barrier<TPWV>();
+        stage_rows(img_row0, y0 + 2 * P + 1, P, 2 * P + 2);         // rows of pass 2
+        compute(accA, 0);
+        s0 = P;
+        // ---- passes 1 .. NPASS-1, two per trip (accumulator sets alternate); each trip also finishes the pass before ----
+        // Waits: a wave's vector-memory operations retire in issue order (MI355X_MICROARCH.md, "s_waitcnt vmcnt(N)"), so
+        // "all but the N youngest" with N = what ONE iteration issues leaves this iteration's prefetch and stores in flight,
+        // in whatever order the compiler emitted them, and guarantees everything older — the rows of the pass about to
+        // be computed among it.  (Pass 1: iteration 0 issued 7 DMAs only.)
 #pragma unroll 1
-        for (int k = 0; k < BR / P; ++k) {
-            // This pass's rows have landed (all four waves' DMAs) and the last pass is read out.  Vector-memory operations
-            // of a wave — loads, stores and LDS-DMA alike — retire from vmcnt in issue order on this part
-            // (MI355X_MICROARCH.md, "s_waitcnt vmcnt(N)"; flat_* excepted, not used here): behind the DMAs waited for here the wave has issued the 7 DMAs of the next pass
-            // and (from the second pass on) the 7 output stores of the pass before — those stay in flight.
-            // (with a residual, its 7 loads sit between them and count too: they are complete, the count is positional)
-            if (k == 0)       wait_all_but_then_barrier<TPWV>();
-            else if (p.resid) wait_all_but_then_barrier<3 * TPWV>();
-            else              wait_all_but_then_barrier<2 * TPWV>();
+        for (int k = 1; k < BR / P; k += 2) {
+            if (k == 1) wait_all_but_then_barrier<TPWV>();
+            else        wait_all_but_then_barrier<VMI>();
             if (k + 2 < BR / P) {
-                int sn = s0 + 2 * P + 2;                             // the P slots the pass before last was the last to read
+                int sn = s0 + 2 * P + 2;
                 if (sn >= RING) sn -= RING;
                 stage_rows(img_row0, y0 + (k + 2) * P + 1, P, sn);
             }
-            f32x4 acc[2][TPWV];
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int u = 0; u < TPWV; ++u) acc[ct][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.ablate != 1) {           // (diagnostic timing mode 1: no operand reads, no MFMAs)
-                // 18 K-steps (tap-major, two K halves per tap), operand fragments double-buffered in registers: the reads of
-                // step s + 1 are issued before the MFMAs of step s (one wave per SIMD: nobody else covers an LDS wait)
-                int sb[3];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    int slot = s0 + ph + ky;                         // row (y + ph) + ky - 1
-                    if (slot >= RING) slot -= RING;
-                    sb[ky] = slot * PITCH;
-                }
-                vec8 pf[2][TPWV];
-#pragma unroll
-                for (int u = 0; u < TPWV; ++u) pf[0][u] = *(const vec8*)(smem + (sb[0] + loff[0][0]) + 2048 * u);
-#pragma unroll
-                for (int st = 0; st < 18; ++st) {
-                    if (st + 1 < 18) {
-                        constexpr int dummy = 0; (void)dummy;
-                        const int tn = (st + 1) >> 1, ksn = (st + 1) & 1;
-#pragma unroll
-                        for (int u = 0; u < TPWV; ++u)
-                            pf[(st + 1) & 1][u] = *(const vec8*)(smem + (sb[tn / 3] + loff[tn % 3][ksn]) + 2048 * u);
-                    }
-                    const int tap = st >> 1, ks = st & 1;
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                        for (int u = 0; u < TPWV; ++u) acc[ct][u] = mfma16<T>(wr[ct][tap][ks], pf[st & 1][u], acc[ct][u]);
-                }
-            }
-            // ---- epilogue of the pass: output row y, pixel x = 16 u + d, channels 32 ch + 8 q .. + 7 -----------------
-            const int y = y0 + k * P + ph;
-            const int rc = p.border_cls ? (y == 0 ? 0 : (y == H - 1 ? 2 : 1)) : 0;
-            const size_t rowoff = (size_t)((img_row0 + y) * W) * 64 + ch * 32 + 8 * q;
-            vec8 res[TPWV];
-            if (p.resid) {
-#pragma unroll
-                for (int u = 0; u < TPWV; ++u) res[u] = *(const vec8*)((const T*)p.resid + rowoff + (size_t)(16 * u + d) * 64);
-            }
-#pragma unroll
-            for (int u = 0; u < TPWV; ++u) {
-                const int x = 16 * u + d;
-                const int cls = p.border_cls ? rc * 3 + (x == 0 ? 0 : (x == W - 1 ? 2 : 1)) : 0;
-                const f32x4 b0 = *(const f32x4*)(ebias + cls * 64 + ch * 32 + 8 * q);
-                const f32x4 b1 = *(const f32x4*)(ebias + cls * 64 + ch * 32 + 8 * q + 4);
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] = acc[0][u][j] + b0[j]; v[4 + j] = acc[1][u][j] + b1[j]; }
-                if (p.alpha) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * al[i];
-                }
-                if (p.resid) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] += (float)res[u][i];
-                }
-                vec8 o8;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o8[i] = (T)v[i];
-                if (p.ablate != 3 || o8[0] == (T)12345.f)   // (diagnostic timing mode 3: no output stores)
-                    *(vec8*)((T*)p.out + rowoff + (size_t)x * 64) = o8;
-            }
+            compute(accB, s0);
+            epilogue(accA, y0 + (k - 1) * P + ph, img_row0);
             s0 += P;
             if (s0 >= RING) s0 -= RING;
+            if (k + 1 < BR / P) {
+                wait_all_but_then_barrier<VMI>();
+                if (k + 3 < BR / P) {
+                    int sn = s0 + 2 * P + 2;
+                    if (sn >= RING) sn -= RING;
+                    stage_rows(img_row0, y0 + (k + 3) * P + 1, P, sn);
+                }
+                compute(accA, s0);
+                epilogue(accB, y0 + k * P + ph, img_row0);
+                s0 += P;
+                if (s0 >= RING) s0 -= RING;
+            } else {
+                epilogue(accB, y0 + k * P + ph, img_row0);           // (odd number of passes: not instantiated today)
+                goto band_done;
+            }
         }
+        epilogue(accA, y0 + (BR / P - 1) * P + ph, img_row0);       // the last pass (NPASS even: it went to accA)
+    band_done:;
     }
 }
 
@@ -268,13 +303,23 @@ int c64_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout) {
     return W == 112 ? 21 : 0;
 }
 
+template <typename T, int EPI>
+static hipError_t c64_attr() {
+    return hipFuncSetAttribute((const void*)conv3x3_c64_kernel<T, 112, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)C64<112>::lds_bytes());
+}
 hipError_t c64_set_attributes() {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel<__bf16, 112>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)C64<112>::lds_bytes());
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel<_Float16, 112>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)C64<112>::lds_bytes());
-    return e;
+    hipError_t e;
+    if ((e = c64_attr<__bf16, 0>()) != hipSuccess || (e = c64_attr<__bf16, 1>()) != hipSuccess || (e = c64_attr<__bf16, 2>()) != hipSuccess) return e;
+    if ((e = c64_attr<_Float16, 0>()) != hipSuccess || (e = c64_attr<_Float16, 1>()) != hipSuccess || (e = c64_attr<_Float16, 2>()) != hipSuccess) return e;
+    return hipSuccess;
+}
+template <typename T>
+static void c64_launch(const ConvParams& p, unsigned grid, hipStream_t st) {
+    const size_t lds = C64<112>::lds_bytes();
+    if (p.alpha && !p.resid && p.border_cls && !p.ablate)       hipLaunchKernelGGL((conv3x3_c64_kernel<T, 112, 1>), dim3(grid), dim3(NT), lds, st, p);
+    else if (!p.alpha && p.resid && !p.border_cls && !p.ablate) hipLaunchKernelGGL((conv3x3_c64_kernel<T, 112, 2>), dim3(grid), dim3(NT), lds, st, p);
+    else                                                         hipLaunchKernelGGL((conv3x3_c64_kernel<T, 112, 0>), dim3(grid), dim3(NT), lds, st, p);
 }
 
 hipError_t launch_conv3x3_c64(int variant, int dtype, const ConvParams& p, hipStream_t st) {
@@ -285,10 +330,8 @@ hipError_t launch_conv3x3_c64(int variant, int dtype, const ConvParams& p, hipSt
     if (dtype != ALINK_DT_BF16 && dtype != ALINK_DT_F16) return hipErrorInvalidValue;
     const long long nbands = (long long)p.N * (p.H / C64<112>::BR);
     const unsigned grid = (unsigned)(nbands < 256 ? nbands : 256);                                   // one persistent workgroup per CU
-    if (dtype == ALINK_DT_BF16)
-        hipLaunchKernelGGL((conv3x3_c64_kernel<__bf16, 112>), dim3(grid), dim3(NT), C64<112>::lds_bytes(), st, p);
-    else
-        hipLaunchKernelGGL((conv3x3_c64_kernel<_Float16, 112>), dim3(grid), dim3(NT), C64<112>::lds_bytes(), st, p);
+    if (dtype == ALINK_DT_BF16) c64_launch<__bf16>(p, grid, st);
+    else                        c64_launch<_Float16>(p, grid, st);
     return hipGetLastError();
 }
 
