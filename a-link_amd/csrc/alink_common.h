@@ -83,6 +83,7 @@ struct ConvParams {
     // columns of every weight row (row pitch ksz*ksz*Cin + Cin2); its K-steps run after the last tap.  nullptr = none.
     const void*  in2;
     int Cin2;
+    int in2_compact;      // in2 holds only the sampled pixels: [N][Ho][Wo][Cin2] (the fused front kernel writes it that way)
     int N, H, W, Cin, Cout, Ho, Wo, stride, ksz, pad, M;
     int border_cls;       // bias class chosen by output position (3x3, stride 1, pad 1 only)
     int splitk;           // 1 = fused epilogue; >1 = f32 partial slabs
@@ -105,7 +106,7 @@ double     conv_flops(const ConvParams& p);
 
 struct StemParams {
     const void*  in;      // pixels, layout per `layout`
-    const void*  wgt;     // [64'][32] T: k = ky*9 + kx*3 + c (27 real, 5 zero), rows permuted
+    const void*  wgt;     // [64'][64] T: k = ky*16 + kx*3 + c (27 real, 37 zero: two MFMA K steps), rows permuted
     const float* bias;    // [C0]
     const float* alpha;   // [C0]
     void*        out;     // [N][H][W][C0] T
@@ -163,6 +164,11 @@ int        direct_variant_tiles(int ksz, int stride, int pad, int H, int W, int 
 int        c64_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout);
 hipError_t c64_set_attributes();
 hipError_t launch_conv3x3_c64(int variant, int dtype, const ConvParams& p, hipStream_t st);
+// front_c64.hip: stem + the first unit's conv1 in one rolling-row launch (the stem's activation stays in LDS; the quarter
+// of it the unit's projection shortcut samples goes to `xs`, [N][56][56][64])
+bool       front_c64_applies(int dtype, int H, int W, int C0, int Cout);
+hipError_t front_c64_set_attributes();
+hipError_t launch_front_c64(int dtype, const ConvParams& conv1, const StemParams& stem, void* xs, bool slopes_le_1, hipStream_t st);
 int        direct_variant_cpl(int v);
 hipError_t direct_set_attributes();
 hipError_t launch_conv3x3_direct(int variant, int dtype, const ConvParams& p, hipStream_t st);

@@ -143,6 +143,7 @@ struct alink_backbone {
     // input-gradient support
     bool grad = false;
     bool split_small = false;   // alink_backbone_set_small_batch_split
+    bool front_slopes_le_1 = false;   // no PReLU slope of the stem or of stage1_unit1 conv1 exceeds 1 (front_c64.hip: PReLU as a max)
     bool fuse_shortcut = true;  // alink_debug_set_fuse_shortcut (A/B): projection shortcuts inside the conv2 launch
     F32Net* f32 = nullptr;      // cfg.dtype == ALINK_DT_F32: the float32 precision mode (backbone_f32.hip) runs every call
     // ALINK_DT_F16X2 (split precision)
@@ -474,7 +475,10 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
     {
         const auto& cw = bb->raw.at("conv0_weight");
         const BN bn0 = get_bn(bb, "bn0", false);
-        std::vector<uint16_t> wq((size_t)64 * 32 * (x2 ? 2 : 1), x2 ? (uint16_t)0 : cvt(dt, 0.f));
+        // 16-bit modes: K = 64 in two MFMA steps, [ky 0: kx*3+c (9) + 7 zeros | ky 1: the same] [ky 2: the same | 16 zeros] — a
+        // pixel's window of one row is one aligned 32-byte record for the fused front kernel (front_c64.hip), and stem_kernel
+        // walks the same K so that the two agree bit for bit; split precision: K = 27 padded to 32, [hi | lo]
+        std::vector<uint16_t> wq((size_t)64 * 64, x2 ? (uint16_t)0 : cvt(dt, 0.f));
         if (x2) {
             double mx = 0.0;
             for (int co = 0; co < 64; ++co)
@@ -489,7 +493,7 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
                         const double v = bn0.a[co] * (double)cw[(((size_t)co * 3 + c) * 3 + ky) * 3 + kx];
                         const int kk = ky * 9 + kx * 3 + c;
                         if (x2) split16(std::ldexp(v, bb->stem_e_w), &wq[(size_t)row * 64 + kk], &wq[(size_t)row * 64 + 32 + kk]);
-                        else    wq[(size_t)row * 32 + kk] = cvt(dt, (float)v);
+                        else    wq[(size_t)row * 64 + ky * 16 + kx * 3 + c] = cvt(dt, (float)v);
                     }
         }
         std::vector<float> bias(64);
@@ -497,6 +501,10 @@ int alink_backbone_finalize(alink_backbone_t* bb) {
         if ((rc = upload(bb, wq, &bb->d_stem_w))) return rc;
         if ((rc = upload(bb, bias, (void**)&bb->d_stem_bias))) return rc;
         if ((rc = upload(bb, bb->raw.at("relu0_gamma"), (void**)&bb->d_stem_alpha))) return rc;
+        bb->front_slopes_le_1 = true;
+        for (const char* nm : {"relu0_gamma", "stage1_unit1_relu1_gamma"})
+            if (bb->raw.count(nm))
+                for (float a : bb->raw.at(nm)) bb->front_slopes_le_1 = bb->front_slopes_le_1 && a <= 1.f;
         if (bb->grad) {
             std::vector<float> wf((size_t)64 * 27);
             for (int co = 0; co < 64; ++co)
@@ -854,7 +862,17 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
     sp.in = dev_in; sp.wgt = bb->d_stem_w; sp.bias = bb->d_stem_bias; sp.alpha = bb->d_stem_alpha;
     sp.out = buf(0); sp.N = N; sp.H = cfg.height; sp.W = cfg.width; sp.C0 = 64; sp.layout = layout;
     sp.sub[0] = sp.sub[1] = sp.sub[2] = 127.5f; sp.mul = 0.0078125f; sp.flip = 0;
-    if (x2) {
+    // The front in one launch (front_c64.hip): stem and the first unit's conv1, the stem's activation kept in LDS; the
+    // quarter of it that the unit's projection shortcut samples lands in buffer 0 as a compact tensor.  16-bit inference
+    // with the shortcut fused into conv2 only: the gradient pass, split precision and a stand-alone shortcut layer read
+    // the whole stem activation.
+    const bool front = !x2 && !cache && bb->convs.size() >= 2 && bb->convs[0].variant == 21 && bb->convs[0].in_buf == 0 &&
+                       bb->convs[1].Cin2 == 64 && bb->convs[1].in2_buf == 0 &&
+                       front_c64_applies(cfg.dtype, cfg.height, cfg.width, 64, bb->convs[0].Cout) &&
+                       plan_split(bb, bb->convs[0], N) == 1;
+    if (front) {
+        // launched with conv1 below
+    } else if (x2) {
         rc = settle(&bb->stem_e_out, buf(0), (size_t)N * cfg.height * cfg.width * 128, [&](int e) -> int {
             sp.acc_scale = std::ldexp(1.f, e - 8 - bb->stem_e_w);          // the loader stores normalised pixels x 2^8
             sp.bias_scale = std::ldexp(1.f, e);
@@ -866,8 +884,10 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
     } else {
         for (int r = 0; r < reps; ++r) ALINK_HIP(launch_stem(cfg.dtype, sp, stream));
     }
-    note(2.0 * N * cfg.height * cfg.width * 64.0 * 27.0, 0);
-    if ((rc = mark())) return rc;
+    if (!front) {
+        note(2.0 * N * cfg.height * cfg.width * 64.0 * 27.0, 0);
+        if ((rc = mark())) return rc;
+    }
 
     int last_out = 0;
     bool front_marked = false;
@@ -888,7 +908,7 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         p.stride = L.stride; p.ksz = L.ksz; p.pad = L.pad; p.M = N * L.Hout * L.Wout;
         p.border_cls = L.border_cls ? 1 : 0; p.splitk = 1;
         p.ksteps_per_split = L.ksz * L.ksz * (L.Cin / 64) + L.Cin2 / 64;
-        if (L.Cin2) { p.in2 = buf(L.in2_buf); p.Cin2 = L.Cin2; }
+        if (L.Cin2) { p.in2 = buf(L.in2_buf); p.Cin2 = L.Cin2; p.in2_compact = (front && &L == &bb->convs[1]) ? 1 : 0; }
         p.ablate = g_ablate;
         p.stagger = g_stagger;
         // few images (128-channel grid under 3/4 of the chip, g_fine_max): those workgroups cover only part of the chip and
@@ -918,6 +938,13 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
             });
             if (rc) return rc;
             bexp[L.out_buf] = L.e_out;
+        } else if (front && &L == &bb->convs[0]) {
+            p.stamps = g_stamps;
+            for (int r = 0; r < reps; ++r) ALINK_HIP(launch_front_c64(cfg.dtype, p, sp, buf(0), bb->front_slopes_le_1, stream));
+            note(conv_flops(p) + 2.0 * N * cfg.height * cfg.width * 64.0 * 27.0, 1);
+            if ((rc = mark())) return rc;
+            last_out = L.out_buf;
+            continue;
         } else
         for (int r = 0; r < reps; ++r) {
             ConvParams q = p;

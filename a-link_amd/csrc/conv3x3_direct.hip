@@ -430,6 +430,7 @@ hipError_t direct_set_attributes() {
     A(D1) A(D2) A(D3) A(D4) A(D5) A(D6) A(S1) A(S3)
 #undef A
     if ((e = c64_set_attributes()) != hipSuccess) return e;
+    if ((e = front_c64_set_attributes()) != hipSuccess) return e;
     return linear_set_attributes();
 }
 

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                 const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
                 off = ((n * p.H + iy0) * W + ix0) * CinP + chunk * 8;
-                poff2[j] = ((n * p.H + oy * p.stride) * W + ox * p.stride) * Cin2 + chunk * 8;
+                poff2[j] = (p.in2_compact ? m : (n * p.H + oy * p.stride) * W + ox * p.stride) * Cin2 + chunk * 8;
                 for (int ky = 0; ky < ksz; ++ky)
                     for (int kx = 0; kx < ksz; ++kx)
                         if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)W)

@@ -34,7 +34,8 @@ constexpr int STEM_ROWS = 8;   // output rows per workgroup
 // One workgroup = one band of STEM_ROWS output rows of one image.  The (STEM_ROWS+2) input rows are
 // normalised, converted to T and parked in LDS with a zero frame (x = -1, x = W, rows outside the
 // image), so the 3x3x3 patch of a pixel is three runs of 9 consecutive LDS elements.  K = 27 is
-// padded to 32: one MFMA K-step per 16 pixels x 16 channels.  Only C0 = 64 is supported.
+// walked as two MFMA K-steps of 32 (rows 0, 1 with 7 zeros behind each run of 9, then row 2) per 16 pixels x 16
+// channels — the K walk of the fused front kernel (front_c64.hip).  Only C0 = 64 is supported.
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
     typedef typename Vec8<T>::type vec8;
@@ -71,18 +72,23 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
 
     // ---- per-lane constants ----------------------------------------------------------------------
     const int q = lane >> 4, lr = lane & 15;
-    // A fragments (weights): tile t, row lr, k = 8q..8q+7  (rows already perm64-permuted on host)
-    vec8 wf[4];
+    // A fragments (weights): tile t, row lr, K = 64 in two steps of 32, k = 8q..8q+7 of each (rows already perm64-permuted
+    // on host).  K order: [ky 0: kx*3+c (9 values) + 7 zeros | ky 1: the same] then [ky 2: the same | 16 zeros] — the walk of
+    // front_c64_kernel, whose image ring holds a pixel's 9-value window as one aligned record: the two kernels agree bit for bit
+    vec8 wf[4][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) wf[t] = *(const vec8*)((const T*)p.wgt + (16 * t + lr) * 32 + 8 * q);
-    // B fragment gather offsets: k = 8q + j -> (ky = k/9, e = k%9) -> ky*RP + e ; k >= 27 -> zero
-    int koff[8];
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 8 * q + j;
-        const int ky = (k * 57) >> 9;               // k / 9 for k < 32
-        koff[j] = (k < 27) ? ky * RP + (k - 9 * ky) : -1;
-    }
+        for (int st = 0; st < 2; ++st) wf[t][st] = *(const vec8*)((const T*)p.wgt + (16 * t + lr) * 64 + st * 32 + 8 * q);
+    // B fragment gather offsets: step st, k = 8q + j -> ky = 2 st + (q >> 1), e = 8 (q & 1) + j -> ky*RP + e ; e >= 9 or ky > 2 -> zero
+    int koff[2][8];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ky = 2 * st + (q >> 1), e = 8 * (q & 1) + j;
+            koff[st][j] = (ky < 3 && e < 9) ? ky * RP + e : -1;
+        }
     const int cbase = 16 * q;                       // lane's 16 consecutive channels
     float bi[16], al[16];
 #pragma unroll
@@ -98,12 +104,17 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
         const int x = xt * 16 + lr;
         const int xc = x < W ? x : W - 1;           // clamp: keep LDS reads in bounds, skip the store
         const T* base = tile + ry * RP + xc * 3;
-        vec8 pf;
+        vec8 pf[2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = koff[j] >= 0 ? base[koff[j]] : (T)0.f;
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[st][j] = koff[st][j] >= 0 ? base[koff[st][j]] : (T)0.f;
         f32x4 acc[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma16<T>(wf[t], pf, f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int t = 0; t < 4; ++t)       // the folded-BN bias is the accumulator's start value (front_c64_kernel does the same)
+            acc[t] = mfma16<T>(wf[t][0], pf[0], f32x4{bi[4 * t], bi[4 * t + 1], bi[4 * t + 2], bi[4 * t + 3]});
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16<T>(wf[t][1], pf[1], acc[t]);
         if (y < H && x < W) {
             vec8 o0, o1;
 #pragma unroll
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = 4 * t + j;
-                    float v = acc[t][j] + bi[i];
+                    float v = acc[t][j];
                     v = v > 0.f ? v : v * al[i];
                     if (i < 8) o0[i] = (T)v; else o1[i - 8] = (T)v;
                 }

@@ -159,12 +159,12 @@ int alink_vgg16_finalize(alink_vgg16_t* r) {
     ALINK_HIP(hipMalloc((void**)&r->d_zero_alpha, 512 * 4));
     r->allocs.push_back(r->d_zero_alpha);
     ALINK_HIP(hipMemset(r->d_zero_alpha, 0, 512 * 4));
-    {   // conv1_1: [64'][32] T, k = ky*9 + kx*3 + c (Keras kernel (3,3,3,64))
+    {   // conv1_1: [64'][64] T, k = ky*16 + kx*3 + c (StemParams::wgt) from the Keras kernel (3,3,3,64)
         const auto& w = r->raw.at("conv1_1/kernel");
-        std::vector<uint16_t> wq((size_t)64 * 32, cvt16(r->dtype, 0.f));
+        std::vector<uint16_t> wq((size_t)64 * 64, cvt16(r->dtype, 0.f));
         for (int co = 0; co < 64; ++co)
             for (int k = 0; k < 27; ++k)
-                wq[(size_t)perm64_row_of_channel(co) * 32 + k] = cvt16(r->dtype, w[(size_t)k * 64 + co]);
+                wq[(size_t)perm64_row_of_channel(co) * 64 + (k / 9) * 16 + k % 9] = cvt16(r->dtype, w[(size_t)k * 64 + co]);
         if ((rc = upload(r, wq, &r->d_stem_w))) return rc;
         if ((rc = upload(r, r->raw.at("conv1_1/bias"), (void**)&r->d_stem_bias))) return rc;
     }

@@ -121,6 +121,39 @@ def test_profile_reports_every_launch(gpu):
     assert _cos_dist(a, ref).max() <= _cos_dist(b, ref).max() * 1.5 + 1e-6
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_fused_front_is_bit_identical_to_stem_and_conv1_launches(gpu, dtype):
+    """csrc/front_c64.hip: stem + stage1_unit1 conv1 in one rolling-row launch (the stem's activation stays in LDS, the
+    projection shortcut reads a compact quarter-resolution copy) against the two launches it replaces — the same
+    arithmetic in the same order, so the embeddings are equal bit for bit.  Every pixel layout; batches that give a
+    workgroup one band (3 images), runs that cross image boundaries (83 images) and runs of whole images (300)."""
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    units = (1, 1, 1, 1)
+    params = W.synthetic_ir_params(units, seed=5, normalized=True)
+    lib = gpu.load()
+    bb = IRBackbone(params, dtype=dtype, max_batch=300)
+    rng = np.random.default_rng(11)
+    for n in (3, 83, 300):
+        u8 = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
+        for x in (u8, u8.float(), u8.float().permute(0, 3, 1, 2).contiguous()):
+            prof = bb.profile(x)
+            assert prof[0][0] == 1 and [k for k, _, _ in prof].count(0) == 0      # no stem launch: it rides in conv1's
+            fused = bb.embed_device(x).clone()
+            lib.alink_debug_set_fuse_stem(0)
+            try:
+                assert bb.profile(x)[0][0] == 0
+                plain = bb.embed_device(x).clone()
+            finally:
+                lib.alink_debug_set_fuse_stem(1)
+            assert torch.isfinite(fused).all()
+            assert torch.equal(fused, plain), (n, x.dtype, tuple(x.shape), (fused - plain).abs().max().item())
+    # FLOPs of the merged launch = stem + conv1
+    from oracle import ir_resnet
+    total = sum(f for _, _, f in bb.profile(u8))
+    assert abs(total / 300 - ir_resnet.flops_per_image(units, size=112)) < 1e-6 * total
+
+
 def test_error_paths(gpu):
     from a_link_amd import weights as W
     from a_link_amd.backbone import IRBackbone

@@ -20,6 +20,7 @@ ap.add_argument("--ablate", type=int, default=0)
 ap.add_argument("--no-direct", action="store_true")
 ap.add_argument("--no-pair", action="store_true")
 ap.add_argument("--no-c64", action="store_true", help="A/B: the 112-wide 64->64 layer on the row-aligned tile kernel instead of the rolling-row kernel")
+ap.add_argument("--no-fuse-stem", action="store_true", help="A/B: stem and stage1_unit1 conv1 as two launches instead of the fused front kernel")
 ap.add_argument("--no-fuse-sc", action="store_true", help="A/B: projection shortcuts as launches of their own")
 ap.add_argument("--linear", type=int, default=-1, help="linear-tile widths: bit0 56, bit1 28, bit2 14, bit3 7 (default: library default)")
 a = ap.parse_args()
@@ -37,6 +38,8 @@ if a.no_fuse_sc:
     _lib.alink_debug_set_fuse_shortcut(0)
 if a.no_c64:
     _lib.alink_debug_set_c64(0)
+if a.no_fuse_stem:
+    _lib.alink_debug_set_fuse_stem(0)
 bb = IRBackbone(W.synthetic_ir_params(units, seed=1), dtype=a.dtype, max_batch=a.batch)
 x = torch.randint(0, 256, (a.batch, 112, 112, 3), dtype=torch.uint8).float().cuda()
 for _ in range(2):
@@ -47,10 +50,11 @@ kinds = [k for k, _, _ in profs[0]]
 fl = [f for _, _, f in profs[0]]
 # group identical (kind, flops) launches
 fused_sc = sum(1 for k in kinds if k == 1) == 2 * sum(units)     # projection shortcuts inside the conv2 launch
-names = ["stem"]
+fused_front = kinds[0] == 1                                       # stem inside the first conv launch (front_c64.hip)
+names = [] if fused_front else ["stem"]
 for s in range(4):
     for u in range(units[s]):
-        names.append("s%du%d_conv1" % (s + 1, u + 1))
+        names.append("stem+s1u1_conv1" if (fused_front and s == 0 and u == 0) else "s%du%d_conv1" % (s + 1, u + 1))
         if u == 0 and not fused_sc:
             names.append("s%du%d_sc" % (s + 1, u + 1))
         names.append("s%du%d_conv2%s" % (s + 1, u + 1, "+sc" if (u == 0 and fused_sc) else ""))
