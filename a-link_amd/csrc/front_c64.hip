@@ -372,7 +372,7 @@ __global__ __launch_bounds__(NT, 1) void front_c64_kernel(const ConvParams p, co
                 head(k + 1);
                 compute(accA, s0);
                 epilogue(accB, y0 + k * P + ph, img_row0);
-                advance();
+                    advance();
             } else {
                 epilogue(accB, y0 + k * P + ph, img_row0);           // the run's last pass (npass is even)
             }

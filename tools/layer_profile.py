@@ -21,11 +21,14 @@ ap.add_argument("--no-direct", action="store_true")
 ap.add_argument("--no-pair", action="store_true")
 ap.add_argument("--no-c64", action="store_true", help="A/B: the 112-wide 64->64 layer on the row-aligned tile kernel instead of the rolling-row kernel")
 ap.add_argument("--no-fuse-stem", action="store_true", help="A/B: stem and stage1_unit1 conv1 as two launches instead of the fused front kernel")
+ap.add_argument("--lib", default="", help="experiments: load this build of libalink_hip.so instead of the package's")
 ap.add_argument("--no-fuse-sc", action="store_true", help="A/B: projection shortcuts as launches of their own")
 ap.add_argument("--linear", type=int, default=-1, help="linear-tile widths: bit0 56, bit1 28, bit2 14, bit3 7 (default: library default)")
 a = ap.parse_args()
 units = W.ARCH_UNITS[a.model]
 from a_link_amd import _abi
+if a.lib:
+    _abi.LIB_PATH = os.path.abspath(a.lib)
 _lib = _abi.load()
 _lib.alink_debug_set_ablate(a.ablate)
 if a.no_direct:
