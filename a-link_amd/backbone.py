@@ -16,7 +16,7 @@ class IRBackbone(object):
     DTYPES = {"bf16": _abi.DT_BF16, "f16": _abi.DT_F16, "f32": _abi.DT_F32, "f16x2": _abi.DT_F16X2}
 
     def __init__(self, params, image_size=(112, 112), emb=512, dtype="bf16", device=None, max_batch=292,
-                 widths=W.WIDTHS, streams=4, shards_per_call=None, bn_eps=2e-5, enable_grad=False,
+                 widths=W.WIDTHS, streams=2, shards_per_call=None, bn_eps=2e-5, enable_grad=False,
                  small_batch_split=False, lazy_range_check=False):
         import torch
         self.torch = torch
@@ -72,7 +72,9 @@ class IRBackbone(object):
         # Inputs larger than max_batch are cut into max_batch-image chunks issued round-robin on
         # `streams` side streams (each with its own workspace) and joined once at the end: chunks are
         # independent, and de-synchronising them lets the HBM bursts of one chunk's tiles overlap the
-        # matrix-core phases of the others (+8...10 % measured on r100).
+        # matrix-core phases of the others (+8...10 % measured on r100).  Two streams since the front of the network is
+        # one persistent launch that owns every CU while it runs (front_c64.hip): 46.1 k against 44.8 k embeddings/s with
+        # four (rounds 1-2, tile kernels throughout: four).
         self.n_streams = max(1, int(streams))
         self._side = None
         self._upload = None

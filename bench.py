@@ -89,7 +89,7 @@ def main():
                     "statistics random: activations grow to ~1e8, bf16 only); normalized: the same draw with BatchNorm statistics "
                     "matching the activations like a trained checkpoint's (a-link_amd/weights.py) — float16 storage works there")
     ap.add_argument("--input", default="f32", choices=["f32", "u8"], help="pixel type resident in HBM")
-    ap.add_argument("--streams", type=int, default=4, help="streams the chunks of one step are spread over")
+    ap.add_argument("--streams", type=int, default=2, help="streams the chunks of one step are spread over (IRBackbone's default)")
     ap.add_argument("--linear", type=int, default=-1, help="A/B: widths on linear pixel tiles (bit0 56, bit1 28, bit2 14, bit3 7)")
     ap.add_argument("--shards", type=int, default=0, help="A/B: image shards one alink_embed call is split into on the "
                     "library's internal streams (alink_backbone_set_streams)")
