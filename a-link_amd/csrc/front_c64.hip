@@ -13,7 +13,7 @@
 //     writes them into the ring slot in the swizzled layout conv1's operand reads expect;
 //   * the only other reader of the stem's activation, the projection shortcut of the unit (1 x 1, stride 2), gets the
 //     quarter it samples as a compact [N][56][56][64] tensor `xs`, stored from the same registers;
-//   * a workgroup owns a CONTIGUOUS range of 16-row bands and rolls through consecutive bands of one image without
+//   * a workgroup owns a CONTIGUOUS range of 4-row bands and rolls through consecutive bands of one image without
 //     restarting, so the 3-barrier prologue (load, park, two pairs of stem rows) is paid once per image it touches.
 //
 // What is left of the launch's HBM traffic is the pixels (11 MB as u8) and conv1's output.
@@ -57,7 +57,9 @@ constexpr int NT = 256;
 constexpr int W = 112, H = 112;
 constexpr int P = 2;                            // output rows per pass: 14 pixel tiles
 constexpr int RING = 8;                         // row slots of the stem activation (6 are live at any time)
-constexpr int BR = 16;                          // rows per band
+constexpr int BR = 4;                           // rows per band = the unit the rows are dealt to workgroups in (two passes: the pass
+                                                // loop runs in pairs); runs roll through consecutive bands, so a small unit costs nothing
+                                                // and balances: 128 images = 14 bands per workgroup (3.5 with 16-row bands: 4 against 3)
 constexpr int BPI = H / BR;                     // bands per image
 constexpr int PITCH = (W + 2) * 128;            // a slot: zero pixel, W pixels, zero pixel
 constexpr int XBYTES = RING * PITCH;
