@@ -164,6 +164,10 @@ int        direct_variant_tiles(int ksz, int stride, int pad, int H, int W, int 
 int        c64_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout);
 hipError_t c64_set_attributes();
 hipError_t launch_conv3x3_c64(int variant, int dtype, const ConvParams& p, hipStream_t st);
+// conv3x3_s2c64.hip: the direct stride-2 kernel for 112 x 112 x 64 -> 56 x 56 x 64, projection shortcut as extra K-steps (variant 25)
+int        s2c64_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout);
+hipError_t s2c64_set_attributes();
+hipError_t launch_conv3x3_s2c64(int variant, int dtype, const ConvParams& p, hipStream_t st);
 // front_c64.hip: stem + the first unit's conv1 in one rolling-row launch (the stem's activation stays in LDS; the quarter
 // of it the unit's projection shortcut samples goes to `xs`, [N][56][56][64])
 bool       front_c64_applies(int dtype, int H, int W, int C0, int Cout);

@@ -774,6 +774,8 @@ static int plan_split(const alink_backbone* bb, const ConvLayer& L, int N) {
 int g_fine_max = 384;     // measured (r100, one launch at a time): the 64-channel form wins while the 128-channel grid fills < 3/4 of the 512 slots
 extern "C" void alink_debug_set_fine_max(int n) { g_fine_max = n; }
 int g_ablate = 0;
+int g_stop_after = 0;       // diagnostic: alink_embed returns after this many convolution launches (0 = the whole chain)
+extern "C" void alink_debug_set_stop_after(int n) { g_stop_after = n; }
 int g_stagger = 0;
 int g_shard_stagger = 0;
 extern "C" void alink_debug_set_shard_stagger(int on) { g_shard_stagger = on; }
@@ -889,9 +891,10 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         if ((rc = mark())) return rc;
     }
 
-    int last_out = 0;
+    int last_out = 0, n_done = 0;
     bool front_marked = false;
     for (ConvLayer& L : bb->convs) {
+        if (g_stop_after && n_done++ >= g_stop_after) return ALINK_OK;
         if (front_done && !front_marked && L.stage >= 1) {       // everything before this launch is the HBM-bound front
             ALINK_HIP(hipEventRecord(front_done, stream));
             front_marked = true;

@@ -394,12 +394,14 @@ extern "C" void alink_debug_set_direct(int on) { g_use_direct = on != 0; }
 extern "C" void alink_debug_set_pair(int on) { g_use_pair = on != 0; }
 
 // Which direct variant (1..6) serves this convolution, 0 = none (use conv_igemm).
-// forward convolutions of the IR backbone: the rolling-row kernel (conv3x3_c64.hip, variant 21) where it applies, else the
-// tile kernels below.  Callers with other epilogues (backward pass: PReLU'; VGGFace2 / VGG16: post-ReLU) use
+// forward convolutions of the IR backbone: the rolling-row kernels (conv3x3_c64.hip, variant 21; its stride-2 form
+// conv3x3_s2c64.hip, variant 25) where they apply, else the tile kernels below (0 = none: conv_igemm).  Callers with other epilogues (backward pass: PReLU'; VGGFace2 / VGG16: post-ReLU) use
 // direct_variant_tiles.
 int direct_variant(int ksz, int stride, int pad, int H, int W, int Cin, int Cout) {
-    if (g_use_direct)
+    if (g_use_direct) {
         if (const int v = c64_variant(ksz, stride, pad, H, W, Cin, Cout)) return v;
+        if (const int v = s2c64_variant(ksz, stride, pad, H, W, Cin, Cout)) return v;
+    }
     return direct_variant_tiles(ksz, stride, pad, H, W, Cin, Cout);
 }
 int direct_variant_tiles(int ksz, int stride, int pad, int H, int W, int Cin, int Cout) {
@@ -420,7 +422,7 @@ int direct_variant_tiles(int ksz, int stride, int pad, int H, int W, int Cin, in
     return 0;
 }
 // weight-row permutation code of a variant (permuted_row): 17 -> perm64b (TCW = 4), 8 -> perm32 (TCW = 2)
-int direct_variant_cpl(int v) { return v == 21 ? 8 : (v >= 11 ? linear_variant_cpl(v) : ((v == 1 || v == 2 || v == 7 || v == 8) ? 17 : 8)); }
+int direct_variant_cpl(int v) { return (v == 21 || v == 25) ? 8 : (v >= 11 ? linear_variant_cpl(v) : ((v == 1 || v == 2 || v == 7 || v == 8) ? 17 : 8)); }
 
 hipError_t direct_set_attributes() {
     hipError_t e;
@@ -431,11 +433,13 @@ hipError_t direct_set_attributes() {
 #undef A
     if ((e = c64_set_attributes()) != hipSuccess) return e;
     if ((e = front_c64_set_attributes()) != hipSuccess) return e;
+    if ((e = s2c64_set_attributes()) != hipSuccess) return e;
     return linear_set_attributes();
 }
 
 hipError_t launch_conv3x3_direct(int variant, int dtype, const ConvParams& p, hipStream_t st) {
     if (variant == 21) return launch_conv3x3_c64(variant, dtype, p, st);
+    if (variant == 25) return launch_conv3x3_s2c64(variant, dtype, p, st);
     if (variant >= 11) return launch_conv3x3_linear(variant, dtype, p, st);
     if (dtype != ALINK_DT_BF16 && dtype != ALINK_DT_F16) return hipErrorInvalidValue;   // no split-precision form of these
     if (p.ksz != 3 || p.stride != 1 || p.pad != 1 || p.splitk != 1) return hipErrorInvalidValue;

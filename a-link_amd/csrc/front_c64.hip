@@ -131,7 +131,6 @@ __global__ __launch_bounds__(NT, 1) void front_c64_kernel(const ConvParams p, co
 #pragma unroll                                         //  16 registers this kernel does not have)
     for (int i = 0; i < 8; ++i) sbi[i] = s.bias[16 * q + 8 * ch + i];
     const int rec_off = lr * IMPX + (q & 1) * 16;     // the lane's half of the record of pixel x = lr
-    const __amdgpu_buffer_rsrc_t xsr = __builtin_amdgcn_make_buffer_rsrc(xs, 0, (int)((size_t)p.N * (H / 2) * (W / 2) * 64 * sizeof(T)), 0x00020000);
     const int sw_off = (lr + 1) * 128 + (((2 * q + ch) ^ (((lr + 1) >> 1) & 7)) << 4);   // ring slot offset of the lane's 16 B at x = lr
 
     // ---- pixel rows: a pair of rows is 672 values, up to three per thread; value jj of a thread is element e of row r of the
@@ -202,10 +201,13 @@ __global__ __launch_bounds__(NT, 1) void front_c64_kernel(const ConvParams p, co
         const char* const wa = (q < 2 ? rbm : rbz) + rec_off;
         const char* const wb = rbp + rec_off;
         char* const ob = smem + slot * PITCH + sw_off;
-        // (a buffer store: the lanes that do not store carry an offset beyond the buffer and are dropped — no branch)
+        // The quarter-resolution copy is stored by an ordinary predicated store.  (A buffer store whose unwanted lanes carry an
+        // out-of-range offset — no branch in the block — was the first form, and WRONG on this part: with launches overlapping
+        // on four streams a buffer_store_dwordx4 now and then sent what its data registers held ~15 instructions LATER (the
+        // compiler reuses them at once: nothing on gfx9 counts a store's data reads), one pixel quad in ~10^5 images, never on
+        // one stream; global stores in the same place: 0 in 300 repetitions.  profiles/experiments/r03_fused_front.txt.)
         const bool to_xs = inimg && !(R & 1) && R >= own_lo && R < own_hi && !(lr & 1);
-        const unsigned xo = (unsigned)(((n * (H / 2) + (R >> 1)) * (W / 2) + (lr >> 1)) * 64 + 16 * q + 8 * ch) * (unsigned)sizeof(T);
-        const unsigned xoff = xo | (to_xs ? 0u : 0xfffffff0u);
+        T* const xrow = xs + ((size_t)(n * (H / 2) + (R >> 1)) * (W / 2) + (lr >> 1)) * 64 + 16 * q + 8 * ch;
         // in two groups of tiles (4 + 3): the operand reads of a group, its MFMAs, its epilogues — the LDS and MFMA latencies are
         // waited out once per group, not per tile
         const int keep = inimg ? -1 : 0;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(NT, 1) void front_c64_kernel(const ConvParams p, co
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ob4[j] &= keep;
                 *(i32x4*)(ob + 2048 * (x0 + i)) = ob4;
-                __builtin_amdgcn_raw_buffer_store_b128(ob4, xsr, xoff, 8 * (x0 + i) * 64 * (int)sizeof(T), 0);
+                if (to_xs) *(i32x4*)(xrow + (size_t)(8 * (x0 + i)) * 64) = ob4;
             }
         };
         group(IC<0>{}, IC<4>{});

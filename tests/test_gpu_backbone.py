@@ -154,6 +154,57 @@ def test_fused_front_is_bit_identical_to_stem_and_conv1_launches(gpu, dtype):
     assert abs(total / 300 - ir_resnet.flops_per_image(units, size=112)) < 1e-6 * total
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_direct_stride2_kernel_with_fused_shortcut_matches_implicit_gemm(gpu, dtype):
+    """csrc/conv3x3_s2c64.hip: stage1_unit1's stride-2 conv2 with the projection shortcut as two more K-steps, as a
+    rolling-row kernel (input rows de-interleaved into odd / even planes in LDS, weights in registers) against the same
+    launch on the implicit-GEMM kernel: the same products summed in the same K order.  With the fused front kernel (the
+    shortcut reads its compact quarter-resolution copy) and without (it samples the stem's activation at stride 2)."""
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    units = (1, 1, 1, 1)
+    params = W.synthetic_ir_params(units, seed=7, normalized=True)
+    lib = gpu.load()
+    direct = IRBackbone(params, dtype=dtype, max_batch=300)
+    lib.alink_debug_set_s2direct(0)
+    try:
+        igemm = IRBackbone(params, dtype=dtype, max_batch=300)
+    finally:
+        lib.alink_debug_set_s2direct(1)
+    rng = np.random.default_rng(13)
+    for n in (2, 37, 300):
+        x = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
+        for fuse_stem in (1, 0):
+            lib.alink_debug_set_fuse_stem(fuse_stem)
+            try:
+                a, b = direct.embed_device(x).clone(), igemm.embed_device(x).clone()
+            finally:
+                lib.alink_debug_set_fuse_stem(1)
+            assert torch.isfinite(a).all()
+            assert torch.equal(a, b), (n, fuse_stem, (a - b).abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_front_kernels_on_four_streams_equal_one_stream(gpu, dtype):
+    """Regression for a store-data race in the first form of csrc/front_c64.hip (round 3): its quarter-resolution copy went
+    out through buffer stores whose unwanted lanes carried an out-of-range offset; with launches overlapping on four streams a
+    buffer_store_dwordx4 now and then sent what its data registers held some fifteen instructions later (the compiler reuses
+    them at once) — one wrong pixel quad in ~10^5 images, never on one stream, so neither the bit-identity test above nor two
+    full suite runs saw it.  Ordinary predicated global stores since.  A shallow net (the front is a fifth of its work) over
+    2,048 images, 40 times on 4 streams, against the one-stream result: every bit equal."""
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    p = W.synthetic_ir_params((1, 1, 1, 1), seed=1, normalized=True)
+    x = torch.randint(0, 256, (2048, 112, 112, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).cuda()
+    ref = IRBackbone(p, dtype=dtype, max_batch=292, streams=1, shards_per_call=1, lazy_range_check=True).embed_device(x).clone()
+    bb = IRBackbone(p, dtype=dtype, max_batch=292, streams=4, lazy_range_check=True)
+    for rep in range(40):
+        got = bb.embed_device(x)
+        torch.cuda.synchronize()
+        bad = torch.nonzero((got != ref).any(1)).flatten().tolist()
+        assert not bad, (dtype, rep, len(bad), bad[:16])
+
+
 def test_error_paths(gpu):
     from a_link_amd import weights as W
     from a_link_amd.backbone import IRBackbone

@@ -1,10 +1,5 @@
 B="python bench.py --no-cpu-baseline --no-extras --select-dtype none"
 run() { echo -n "$* : "; $B "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.0f' % d['value'])"; }
 R50="--model r50 --batch 256 --chunk 256 --streams 1"
-run $R50
-run $R50 --fine-max 0
-run $R50 --fine-max 200
-run $R50 --fine-max 100000
-run $R50
-run $R50 --fine-max 0
-run $R50 --input u8
+for i in 1 2 3; do run $R50; run $R50 --no-s2direct; done
+for i in 1 2; do run; run --no-s2direct; done

@@ -22,6 +22,7 @@ ap.add_argument("--no-pair", action="store_true")
 ap.add_argument("--no-c64", action="store_true", help="A/B: the 112-wide 64->64 layer on the row-aligned tile kernel instead of the rolling-row kernel")
 ap.add_argument("--no-fuse-stem", action="store_true", help="A/B: stem and stage1_unit1 conv1 as two launches instead of the fused front kernel")
 ap.add_argument("--lib", default="", help="experiments: load this build of libalink_hip.so instead of the package's")
+ap.add_argument("--no-s2direct", action="store_true", help="A/B: stage1_unit1's stride-2 conv2 + shortcut on the implicit-GEMM kernel")
 ap.add_argument("--no-fuse-sc", action="store_true", help="A/B: projection shortcuts as launches of their own")
 ap.add_argument("--linear", type=int, default=-1, help="linear-tile widths: bit0 56, bit1 28, bit2 14, bit3 7 (default: library default)")
 a = ap.parse_args()
@@ -43,6 +44,8 @@ if a.no_c64:
     _lib.alink_debug_set_c64(0)
 if a.no_fuse_stem:
     _lib.alink_debug_set_fuse_stem(0)
+if a.no_s2direct:
+    _lib.alink_debug_set_s2direct(0)
 bb = IRBackbone(W.synthetic_ir_params(units, seed=1), dtype=a.dtype, max_batch=a.batch)
 x = torch.randint(0, 256, (a.batch, 112, 112, 3), dtype=torch.uint8).float().cuda()
 for _ in range(2):

@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 fetch_csv, write_csv, n_forwards = sys.argv[1], sys.argv[2], int(sys.argv[3])
-TAGS = ("conv3x3_linear_kernel", "conv3x3_direct_kernel", "conv3x3_c64_kernel", "front_c64_kernel", "conv_igemm_kernel", "stem_kernel", "stem_x2_kernel",
+TAGS = ("conv3x3_linear_kernel", "conv3x3_direct_kernel", "conv3x3_c64_kernel", "conv3x3_s2c64_kernel", "front_c64_kernel", "conv_igemm_kernel", "stem_kernel", "stem_x2_kernel",
         "fc_finish_kernel")
 
 
