@@ -143,6 +143,7 @@ struct alink_backbone {
     // input-gradient support
     bool grad = false;
     bool split_small = false;   // alink_backbone_set_small_batch_split
+    int  siblings = 1;                // shards of the alink_embed call in progress (they run side by side on internal streams)
     bool front_slopes_le_1 = false;   // no PReLU slope of the stem or of stage1_unit1 conv1 exceeds 1 (front_c64.hip: PReLU as a max)
     bool fuse_shortcut = true;  // alink_debug_set_fuse_shortcut (A/B): projection shortcuts inside the conv2 launch
     F32Net* f32 = nullptr;      // cfg.dtype == ALINK_DT_F32: the float32 precision mode (backbone_f32.hip) runs every call
@@ -771,6 +772,8 @@ static int plan_split(const alink_backbone* bb, const ConvLayer& L, int N) {
     return best;
 }
 
+int g_sibling_aware = 1;
+extern "C" void alink_debug_set_sibling_aware(int on) { g_sibling_aware = on != 0; }
 int g_fine_max = 384;     // measured (r100, one launch at a time): the 64-channel form wins while the 128-channel grid fills < 3/4 of the 512 slots
 extern "C" void alink_debug_set_fine_max(int n) { g_fine_max = n; }
 int g_ablate = 0;
@@ -919,7 +922,11 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         // (bit-identical results: same weights, same summation order per output)
         if (L.variant == 11 || L.variant == 12 || L.variant == 14) {
             const long long nwg128 = (((long long)p.M + 223) / 224) * (L.Cout / 128);
-            p.fine = nwg128 <= g_fine_max ? 1 : 0;
+            // (a shard of an in-call split runs beside its siblings: it is their workgroups together that fill the chip —
+            // measured for the 14- and 28-wide layers: IR-50, one 256-image batch +1.5 %, IR-100 at 292 images +1.7 %; the
+            // 7-wide layers, 72 K-steps per workgroup, do better blind: −1 % otherwise at two 292-image shards)
+            const int sib = (g_sibling_aware && L.variant != 14) ? bb->siblings : 1;
+            p.fine = nwg128 * sib <= g_fine_max ? 1 : 0;
         }
         const int S = plan_split(bb, L, N);
         if (x2) {
@@ -1023,6 +1030,8 @@ int alink_embed(alink_backbone_t* bb, const void* dev_in, int layout, int n_imag
     ALINK_HIP(hipEventRecord(bb->ev_start, st));
     size_t woff = 0;
     int n0 = 0;
+    bb->siblings = S;
+    struct Reset { alink_backbone* b; ~Reset() { b->siblings = 1; } } reset{bb};
     for (int i = 0; i < S; ++i) {
         size_t off[7], need;
         ws_layout(bb, counts[i], off, &need);

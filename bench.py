@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--stagger", type=int, default=-1, help="A/B: start delay (x 1024 cycles) of the second workgroup on a CU in the linear-tile kernel")
     ap.add_argument("--shard-stagger", type=int, default=-1, help="A/B: in-call shards start one after the other's front (stem + stage 1)")
     ap.add_argument("--no-fuse-stem", action="store_true", help="A/B: stem and stage1_unit1 conv1 as two launches instead of the fused front kernel")
+    ap.add_argument("--no-sibling-aware", action="store_true", help="A/B: the 64- / 128-channel form of the linear-tile kernel chosen per shard, blind to the call's other shards")
     ap.add_argument("--no-s2direct", action="store_true", help="A/B: stage1_unit1's stride-2 conv2 + shortcut on the implicit-GEMM kernel instead of the direct stride-2 kernel")
     ap.add_argument("--no-c64", action="store_true", help="A/B: without the rolling-row kernel for the 64 -> 64 channel front layers")
     ap.add_argument("--no-fuse-sc", action="store_true", help="A/B: projection shortcuts as launches of their own instead of extra K-steps of conv2")
@@ -148,6 +149,9 @@ def main():
     if args.no_fuse_stem:
         from a_link_amd import _abi
         _abi.load().alink_debug_set_fuse_stem(0)
+    if args.no_sibling_aware:
+        from a_link_amd import _abi
+        _abi.load().alink_debug_set_sibling_aware(0)
     if args.no_s2direct:
         from a_link_amd import _abi
         _abi.load().alink_debug_set_s2direct(0)
