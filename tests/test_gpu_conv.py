@@ -30,6 +30,7 @@ CASES = [
     (3, 112, 112, 64, 64, 3, 1, 1, 0, 0, 1),    # the same kernel: three images (bands of several images per workgroup), residual
     (37, 112, 112, 64, 64, 3, 1, 1, 1, 1, 1),   # 259 bands for 256 persistent workgroups: some take two; PReLU + residual
     (41, 28, 28, 128, 128, 3, 1, 1, 0, 0, 1),   # stage-2 conv2 over 41 images: 144 groups of 224 pixels, most of them across image boundaries
+    (21, 56, 56, 64, 64, 3, 1, 1, 1, 1, 0),     # stage-1 unit over 21 images: 294 groups of 224 pixels across image boundaries
     (3, 112, 112, 64, 64, 3, 2, 1, 0, 0, 1),    # the direct stride-2 kernel (conv3x3_s2c64.hip), plain form: residual; one output row per pass
     (9, 112, 112, 64, 64, 3, 2, 1, 0, 1, 0),    # the same: 504 output rows for 256 workgroups (runs of 1-2 rows across images), PReLU
     (2, 13, 14, 64, 256, 3, 1, 1, 1, 0, 0),     # D1 with a ragged row count (H not a multiple of R)
