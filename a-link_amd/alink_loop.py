@@ -49,6 +49,10 @@ class Flags(object):
     refine_models = False
     train_disguised_model = False
     blind_strategy = False
+    # not a flag of the reference: embed the noisy pair occurrences (2 P n_noise images per iteration, the bulk of its
+    # work) in the feature model's 16-bit SCREENING mode and re-embed in the exact mode only the pairs whose side of a
+    # cut is uncertain (settle.py) — same query set, same fine-tune data; needs a feature model with `process_screen`
+    screen_settle = True
 
     def __init__(self, **kw):
         for k, v in kw.items():
@@ -80,6 +84,7 @@ class LoopState(object):
         self.finetunes = 0
         self.iterations = 0
         self.history = []
+        self.settle_info = []
 
 
 def _np(x):
@@ -92,8 +97,24 @@ def _concat(old, parts):
     return np.concatenate(([old] if np.asarray(old).shape[0] > 0 else []) + parts)
 
 
+def _rows(a, idx):
+    if hasattr(a, "detach"):
+        import torch
+        return a[torch.as_tensor(np.asarray(idx, np.int64), device=a.device)]
+    return np.asarray(a)[np.asarray(idx, np.int64)]
+
+
+def _set_rows(a, idx, v):
+    if hasattr(a, "detach"):
+        import torch
+        a[torch.as_tensor(np.asarray(idx, np.int64), device=a.device)] = torch.as_tensor(v, device=a.device).to(a.dtype)
+    else:
+        a[np.asarray(idx, np.int64)] = _np(v)
+
+
 def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensembleNoise, student, dataGen,
-                    noisy_for_student, clean_for_student, image_res, col=0, verbose=1, labels_one_hot=False):
+                    noisy_for_student, clean_for_student, image_res, col=0, verbose=1, labels_one_hot=False,
+                    noisy_for_student_screen=None):
     """One pass of the loop body (code/ALINK_arc.py:150-254) over an already-built mini-batch.
 
     batch_x            [left, right] pair images (P, H, W, 3)
@@ -102,6 +123,11 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
     noisy_for_student  f(noisy_images) -> what the student consumes (features for the DFW drivers,
                        the low-res pixels themselves for Multi-PIE)
     clean_for_student  [left, right] clean inputs of the student (features / low-res pixels)
+    noisy_for_student_screen  the same conversion in the feature model's fast 16-bit mode: when given (and
+                       flags.screen_settle), every noisy copy is converted by it first and only the pairs whose side of
+                       a cut of the selection rule is uncertain — plus the pairs that end up selected — are converted
+                       again by `noisy_for_student` (settle.select_queries_settled): query set, oracle count, labels and
+                       the rows that reach the fine-tune set equal the all-exact run's.
     Returns the number of examples added to the pending fine-tune set, or -1 when the reference
     `continue`s (no query survived: code/ALINK_arc.py:203-205 — the stop check is skipped too).
     """
@@ -113,12 +139,29 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
     if labels_one_hot:                      # ALINK_MTP.py:174 passes keras.utils.to_categorical(..., 2)
         m1_labels = helpers.one_hot(m1_labels, 2)
     noisy_data = bag.attackModel(batch_x, image_res, m1_labels)
-    noisy_data = [[noisy_for_student(p) for p in part] for part in noisy_data]
     n_noise = len(ensembleNoise)
-    disguisedPredictions = [_np(student.predict([noisy_data[0][jj], noisy_data[1][jj]])) for jj in range(n_noise)]
-    queryIndices, active, labels = selection.select_queries(
-        ensemblePredictions, disguisedPredictions, batch_y, col=col, disparity_ratio=flags.disparity_ratio,
-        eps=flags.eps, blind_strategy=flags.blind_strategy)
+    if noisy_for_student_screen is not None and getattr(flags, "screen_settle", True):
+        from . import settle
+        pixels = noisy_data
+        noisy_data = [[noisy_for_student_screen(p) for p in part] for part in pixels]
+        noisy_data = [[f.clone() if hasattr(f, "detach") else np.array(f, copy=True) for f in part] for part in noisy_data]
+        screened = [_np(student.predict([noisy_data[0][jj], noisy_data[1][jj]])) for jj in range(n_noise)]
+
+        def settle_fn(jj, idx):
+            sides = [noisy_for_student(_rows(pixels[s][jj], idx)) for s in (0, 1)]
+            for s in (0, 1):
+                _set_rows(noisy_data[s][jj], idx, sides[s])          # the exact rows replace the screened ones
+            return _np(student.predict(sides))
+        queryIndices, active, labels, disguisedPredictions, _, info = settle.select_queries_settled(
+            ensemblePredictions, screened, batch_y, settle_fn, col=col, disparity_ratio=flags.disparity_ratio,
+            eps=flags.eps, blind_strategy=flags.blind_strategy)
+        state.settle_info.append(info)
+    else:
+        noisy_data = [[noisy_for_student(p) for p in part] for part in noisy_data]
+        disguisedPredictions = [_np(student.predict([noisy_data[0][jj], noisy_data[1][jj]])) for jj in range(n_noise)]
+        queryIndices, active, labels = selection.select_queries(
+            ensemblePredictions, disguisedPredictions, batch_y, col=col, disparity_ratio=flags.disparity_ratio,
+            eps=flags.eps, blind_strategy=flags.blind_strategy)
     state.active_count += active
     log("Active Count so far : %d" % state.active_count)
     if len(queryIndices) == 0:
@@ -182,7 +225,8 @@ def run_alink_dfw(flags, conversionModel, bag, ensembleNoise, disguisedFacesMode
         batch_x_features = [feats[li], feats[ri]]
         added = alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensembleNoise,
                                 disguisedFacesModel, dataGen, noisy_for_student=conversionModel.process,
-                                clean_for_student=batch_x_features, image_res=image_res, col=col, verbose=verbose)
+                                clean_for_student=batch_x_features, image_res=image_res, col=col, verbose=verbose,
+                                noisy_for_student_screen=getattr(conversionModel, "process_screen", None))
         if added < 0:
             continue
         if int(flags.active_ratio * state.un_size) <= state.active_count:

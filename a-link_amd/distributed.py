@@ -10,7 +10,8 @@ this is new work shaped by SURVEY.md §8e:
     each rank runs forward/backward on its slice of the batch with the GLOBAL normaliser, the flat gradient
     buffer is all-reduced (sum), every rank applies the same Adadelta update;
   * `committee_pool_topk`: the whole config-3 shape on one rank (shard -> committee of backbones + heads ->
-    uncertainty -> local top-k -> merge).
+    uncertainty -> local top-k -> merge); `committee_pool_topk_settled`: the same result from a 16-bit screening pass
+    plus exact re-embedding of only the images that own a pair near the cut (settle.py).
 All functions work on CPU tensors too (that is how the world-size-2 gloo tests exercise them).
 """
 import numpy as np
@@ -189,6 +190,60 @@ def committee_pool_topk(backbones, heads, pool_shard, gallery, k, shard_offset, 
     if dist.is_available() and dist.is_initialized():
         return merge_topk(vals, gidx, k, largest=True, group=group)
     return vals, gidx
+
+
+def committee_pool_topk_settled(screen_backbones, exact_backbones, heads, pool_shard, gallery, k, shard_offset,
+                                kind="entropy", group=None, settle_selected=True, info=None, **settle_kw):
+    """committee_pool_topk with the SAME result (scores, order and indices equal the all-exact run's bit for bit when
+    settle_selected, the same set otherwise) at close to the screening rate: screen-then-settle (settle.py).
+    `screen_backbones[m]` / `exact_backbones[m]` are member m's backbone in the 16-bit screening mode and in the exact
+    mode ("f16x2" or "f32").  The gallery (replicated, a handful of images) is embedded in the exact mode only; the pool
+    shard in the screening mode; then only the pool images that own a pair whose side of the k-th cut is uncertain —
+    under an error bound measured on the pairs already settled, never assumed — are re-embedded in the exact mode and
+    their pairs re-scored.  One candidate exchange + two small all-reduces per round (2-4 rounds).  `info` (a dict, if
+    given) receives images_settled, rounds, delta, d_max, widened, fraction_re_embedded.  settle_kw: safety, delta0,
+    min_sample, stage_above, max_rounds (settle.settle_topk)."""
+    import torch
+    from . import head as _head
+    from . import settle as _settle
+    from . import uncertainty as _unc
+    n, g = len(pool_shard), len(gallery)
+    dev = heads[0].device
+    as_dev = lambda bb, x: bb.embed_device(x) if hasattr(x, "detach") else torch.as_tensor(bb.embed(x)).to(dev)
+    Eg = [as_dev(bb, gallery) for bb in exact_backbones]
+    Ep = [as_dev(bb, pool_shard) for bb in screen_backbones]
+    li = torch.arange(n, dtype=torch.int32, device=Eg[0].device).repeat_interleave(g)
+    ri = torch.arange(g, dtype=torch.int32, device=Eg[0].device).repeat(n)
+    probs = _head.committee_predict_device(heads, Ep, Eg, li, ri)
+    score_s = _unc.score_device(probs, kind).cpu().numpy()
+    p_s = probs[:, 0].cpu().numpy()
+    del Ep, probs
+
+    def exact_fn(imgs):
+        m = len(imgs)
+        if hasattr(pool_shard, "detach"):
+            x = pool_shard[torch.from_numpy(imgs).to(pool_shard.device)]
+        else:
+            x = pool_shard[imgs]
+        Ex = [as_dev(bb, x) for bb in exact_backbones]
+        lj = torch.arange(m, dtype=torch.int32, device=Eg[0].device).repeat_interleave(g)
+        rj = torch.arange(g, dtype=torch.int32, device=Eg[0].device).repeat(m)
+        pr = _head.committee_predict_device(heads, Ex, Eg, lj, rj)
+        sc = _unc.score_device(pr, kind)
+        pos = (imgs[:, None] * g + np.arange(g)).ravel()
+        return pos, pr[:, 0].cpu().numpy(), sc.cpu().numpy()
+
+    owner = np.repeat(np.arange(n), g)
+    comm = _settle.make_comm(group)
+    if "stage_above" not in settle_kw:
+        settle_kw["stage_above"] = 2 * getattr(exact_backbones[0], "max_batch", 292)
+    vals, gidx, inf = _settle.settle_topk(p_s, score_s, owner, n, exact_fn, k, kind=kind, largest=True, comm=comm,
+                                          base=int(shard_offset) * g, settle_selected=settle_selected, **settle_kw)
+    inf["fraction_re_embedded"] = inf["images_settled"] / float(max(n, 1))
+    if info is not None:
+        info.update(inf)
+    out_dev = Eg[0].device
+    return torch.from_numpy(np.ascontiguousarray(vals)).to(out_dev), torch.from_numpy(np.ascontiguousarray(gidx)).to(out_dev)
 
 
 def embed_pool_sharded(feature_model, X, group=None, gather=True):

@@ -211,7 +211,7 @@ class RESNET50:
 
 class ArcFace:
     def __init__(self, shape, model_path, dtype=None, max_batch=292, enable_grad=False, small_batch_split=False,
-                 gpu=None):
+                 gpu=None, screen_dtype=None):
         # dtype=None: face_model.default_dtype — "f16x2" (selection sets identical to the reference's float32
         # arithmetic), or "bf16" when the gradient pass / latency mode is requested
         args = _Args({
@@ -227,9 +227,28 @@ class ArcFace:
             "max_batch": max_batch,
         })
         self.model = face_model.FaceModel(args)
+        # screen_dtype ("auto" = f16 where the network's activations fit its range, else bf16; "f16"; "bf16"): a second
+        # handle on the same checkpoint in the fast 16-bit mode, for screen-then-settle selection (settle.py): the bulk of
+        # the images goes through `process_screen`, only those near a cut through `process`.  Not in the reference.
+        self.screen = None
+        if screen_dtype:
+            self.screen = face_model.FaceModel(_Args(dict(args, dtype=screen_dtype)))
+            self.process_screen = self._process_screen
+
+    def backbones(self):
+        """(screening IRBackbone or None, exact IRBackbone): what distributed.committee_pool_topk_settled takes"""
+        return (self.screen.model if self.screen is not None else None), self.model.model
 
     def preprocess(self, X):
         return X
+
+    def _process_screen(self, X):
+        X = self.preprocess(X)
+        if isinstance(X, (list, tuple)):
+            X = np.stack(X)
+        if len(X) == 0:
+            return np.zeros((0, 512), dtype=np.float32)
+        return self.screen.get_features(X)
 
     def process(self, X):
         """(N,H,W,3) float RGB 0..255 -> (N,512).  The reference loops get_input/get_feature per

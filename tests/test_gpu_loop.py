@@ -149,3 +149,46 @@ def test_flags_match_reference_defaults():
     assert f.noise == 'gaussian,saltpepper,poisson,perlin,speckle,adversarial' and f.blind_strategy is False
     with pytest.raises(AttributeError):
         AL.Flags(nope=1)
+
+
+@pytest.mark.parametrize("screen", ["bf16", "auto"])
+def test_loop_with_screen_then_settle_equals_all_exact_loop(gpu, capsys, screen, tmp_path):
+    """run_alink_dfw with a feature model that carries a 16-bit screening handle (ArcFace(screen_dtype=...)): the noisy
+    pair occurrences — the bulk of an iteration's embeddings — go through the screening mode and only pairs near a cut
+    (and the selected ones) through the exact mode.  Oracle-query count, every iteration's query list, the number of
+    fine-tunes and the student's weights afterwards must equal the all-exact loop's, bit for bit."""
+    from a_link_amd import alink_loop as AL, pairs, settle
+    X_plain, X_dig = _people(6, 1), _people(6, 2)
+    results = []
+    for use in (True, False):
+        flags = AL.Flags(alink_bs=3, batch_send=6, disparity_ratio=0.6, eps=0.0005, ft_epochs=2, mixture_ratio=2,
+                         out_model=str(tmp_path / "post"), screen_settle=use)
+        from a_link_amd import committee, noise, siamese
+        conv = siamese.ArcFace(SIZE, "synthetic:r18:3", screen_dtype=screen)
+        assert conv.backbones()[0] is not None and conv.backbones()[0].dtype in ("bf16", "f16")
+        student = siamese.SiameseNetwork((512,), "student", 0.1, seed=7)
+        ens = [siamese.SiameseNetwork((512,), "ens%d" % i, 0.1, seed=100 + i) for i in range(2)]
+        nz = [noise.get_relevant_noise(n)(model=student, sess=None, feature_model=conv) for n in ("gaussian", "speckle")]
+        for i, z in enumerate(nz):
+            z._seed, z._calls = 1000 + i, 0
+        bag = committee.Bagging(ens, nz)
+        feats_plain = [conv.process(p) for p in X_plain]
+        gen = pairs.getGenerator(pairs.getNormalGenerator(feats_plain, 8), pairs.getNormalGenerator(feats_plain, 8),
+                                 pairs.getImposterGenerator(feats_plain, feats_plain, 8), 8)
+        np.random.seed(5)
+        sets = []
+        o1, o2 = AL.selection.select_queries, settle.select_queries_settled
+        AL.selection.select_queries = lambda *a, **k: (lambda r: (sets.append(list(r[0])), r)[1])(o1(*a, **k))
+        settle.select_queries_settled = lambda *a, **k: (lambda r: (sets.append(list(r[0])), r)[1])(o2(*a, **k))
+        try:
+            st = AL.run_alink_dfw(flags, conv, bag, nz, student, X_plain, X_dig, gen, SIZE, col=0, verbose=0)
+        finally:
+            AL.selection.select_queries, settle.select_queries_settled = o1, o2
+        results.append((st.active_count, st.un_size, sets, st.finetunes, student.siamese_net.get_weights(), st.settle_info))
+    a, b = results
+    assert len(a[5]) == len(a[2]) >= 2 and not b[5]
+    with capsys.disabled():
+        print("\n[loop, screening %s] (pair, noise) rows settled per iteration: %s" % (screen, ["%.0f %%" % (100 * i["fraction_settled"]) for i in a[5]]))
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[3] == b[3] >= 1
+    for x, y in zip(a[4], b[4]):
+        assert np.array_equal(x, y)

@@ -187,6 +187,58 @@ def test_config3_committee_of_three_ir50_backbones_over_pool(gpu, capsys, dtype)
     assert len(want - fragile) >= 20 and (want - fragile) <= got
 
 
+@pytest.mark.parametrize("screen", ["f16", "bf16"])
+def test_config3_screen_settle_selection_identical(gpu, capsys, screen):
+    """BASELINE configs[2] through SCREEN-THEN-SETTLE (a-link_amd/settle.py, distributed.committee_pool_topk_settled): the
+    pool is embedded in the 16-bit screening mode — alone, that turns over 41 (f16) / 394 (bf16) of the 1,024 selected
+    pairs — and only the pool images that own a pair whose side of the 1,024th cut is uncertain, under an error bound
+    measured on the pairs already settled, are re-embedded in split precision.  The selection must be the ORACLE's
+    (tests/golden/config3_r50.npz: 0 of 1,024 differ), and scores / order / indices must equal the all-exact run's bit
+    for bit.  A band claimed a million times too narrow (delta0 = 1e-9, first sample 8 images) must widen itself."""
+    import os
+    from a_link_amd import distributed as D, siamese
+    from a_link_amd.backbone import IRBackbone
+    gen = _load_script("make_golden_config3.py")
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config3_r50.npz"))
+    pool, gallery, li, ri = gen.inputs()
+    k = 1024
+    pool_d, gal_d = torch.from_numpy(pool).cuda(), torch.from_numpy(gallery).cuda()
+    scr, exa, heads = [], [], []
+    for m, seed in enumerate((1, 2, 3)):
+        params = gen.member_params(seed, gold["bn_stats_%d" % m])
+        scr.append(IRBackbone(params, dtype=screen))
+        bb = IRBackbone(params, dtype="f16x2")
+        bb.calibrate(pool[:64])
+        exa.append(bb)
+        net = siamese.SiameseNetwork((512,), "c%d" % m, 0.1, seed=10 + m)
+        net.siamese_net.set_weights(gen.head_weights(10 + m, gold["gain_%d" % m], gold["bias_%d" % m]))
+        heads.append(net.siamese_net)
+    want_v, want_i = D.committee_pool_topk(exa, heads, pool_d, gal_d, k, shard_offset=0)
+    assert set(want_i.cpu().numpy().tolist()) == set(gold["top1024"].tolist())
+    only_screen = D.committee_pool_topk(scr, heads, pool_d, gal_d, k, shard_offset=0)[1]
+    flips = len(set(only_screen.cpu().numpy().tolist()) - set(gold["top1024"].tolist()))
+    info = {}
+    v, i = D.committee_pool_topk_settled(scr, exa, heads, pool_d, gal_d, k, shard_offset=0, info=info)
+    with capsys.disabled():
+        print("\n[config 3 screen-then-settle, screening %s] screening alone: %d of %d differ; settled: %d of %d images "
+              "re-embedded (%.1f %%) in %d rounds, delta %.2e (largest |dp| seen %.2e), widened %d x"
+              % (screen, flips, k, info["images_settled"], info["images"], 100 * info["fraction_re_embedded"], info["rounds"],
+                 info["delta"], info["d_max"], info["widened"]))
+    assert flips > 10                                             # screening alone is NOT the oracle's selection
+    assert torch.equal(i, want_i) and torch.equal(v, want_v)      # bit for bit the all-exact run
+    assert info["members_unsettled"] == 0 and info["delta"] >= 1.5 * info["d_max"] > 0
+    if screen == "f16":
+        assert info["fraction_re_embedded"] < 0.9
+    # members certain by interval are not re-embedded when only the SET is wanted
+    info2 = {}
+    v2, i2 = D.committee_pool_topk_settled(scr, exa, heads, pool_d, gal_d, k, shard_offset=0, settle_selected=False, info=info2)
+    assert set(i2.cpu().numpy().tolist()) == set(gold["top1024"].tolist()) and info2["images_settled"] <= info["images_settled"]
+    # a deliberately narrow band is caught: it widens itself and the answer stands
+    info3 = {}
+    v3, i3 = D.committee_pool_topk_settled(scr, exa, heads, pool_d, gal_d, k, shard_offset=0, info=info3, delta0=1e-9, min_sample=8)
+    assert torch.equal(i3, want_i) and torch.equal(v3, want_v) and info3["widened"] >= 1 and info3["delta"] > 1e-5
+
+
 _CASES = {}
 
 
@@ -338,3 +390,61 @@ def test_alink_iteration_selection_at_depth(gpu, capsys, arch, dtype):
     _check_alink_iteration(res, P, ens_o, capsys, {"f32": 0.004, "f16x2": 0.004, "f16": 0.05, "bf16": 0.12}[dtype])
     if dtype in ("f32", "f16x2"):  # the reference's own precision, and the split-precision selection mode, reproduce its query sets
         assert all(set(q) == qs for (q, _, qs, *_rest) in res.values())
+
+
+@pytest.mark.parametrize("arch,screen", [("r50", "bf16"), ("r50", "f16"), ("r100", "bf16"), ("r100", "f16")])
+def test_alink_iteration_selection_at_depth_screen_settle(gpu, capsys, arch, screen):
+    """The config-4 iteration at depth with the NOISY passes screened: clean embeddings exact (split precision), every
+    noisy copy embedded in the 16-bit mode, and settle.select_queries_settled re-embedding in split precision only the
+    images of pairs whose side of a cut is uncertain.  Query set, oracle-query count and labels must equal the f32
+    oracle's on BOTH columns (screening alone differs in 2-19 members: DESIGN.md §5)."""
+    from a_link_amd import committee, selection, settle, siamese, weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import al_logic as OA
+    size = (112, 112)
+    params, m1o, m2o, uniq, noises, li, ri, y = _alink_iteration_case(size, W.ARCH_UNITS[arch], seed=21 if arch == "r50" else 22)
+    exact = IRBackbone(params, image_size=size, dtype="f16x2")
+    scr = IRBackbone(params, image_size=size, dtype=screen)
+    heads = []
+    for i, om in enumerate(m1o + [m2o]):
+        net = siamese.SiameseNetwork((512,), "h%d" % i, 0.1, seed=i)
+        net.siamese_net.set_weights(om.get_weights())
+        heads.append(net)
+    E = exact.embed(uniq)
+    ens = committee.Bagging(heads[:-1], []).predict_indexed(E, E, li, ri).cpu().numpy()
+    En_s = [scr.embed(nz) for nz in noises]
+    dis_s = [heads[-1].siamese_net.predict_device(e, e, li, ri).cpu().numpy() for e in En_s]
+    # the test's noisy copies are per unique IMAGE (the loop's are per pair occurrence): settling pair j of noise k embeds
+    # its two images' noise-k copies exactly, once
+    En_x = [np.array(e, copy=True) for e in En_s]
+    done = [np.zeros(len(uniq), bool) for _ in noises]
+    embedded = [0]
+
+    def settle_fn(k, idx):
+        need = np.unique(np.concatenate([li[idx], ri[idx]]))
+        need = need[~done[k][need]]
+        if len(need):
+            En_x[k][need] = exact.embed(noises[k][need])
+            done[k][need] = True
+            embedded[0] += len(need)
+        return heads[-1].siamese_net.predict_device(En_x[k], En_x[k], li[idx], ri[idx]).cpu().numpy()
+    okey = ("oracle", id(params))
+    if okey not in _CASES:
+        _run_alink_iteration(exact, params, m1o, m2o, uniq, noises, li, ri, y)          # fills the oracle cache
+    Eo, ens_o, dis_o = _CASES[okey]
+    for col in (0, 1):
+        for d in done:
+            d[:] = False
+        for k in range(len(noises)):
+            En_x[k][:] = En_s[k]
+        embedded[0] = 0
+        q, active, labels, _, _, info = settle.select_queries_settled(ens, dis_s, y, settle_fn, col=col, disparity_ratio=0.25, eps=0.05)
+        qs, act_o = OA.select_queries(ens_o, dis_o, y, col, 0.25, 0.05)
+        q_scr, _, _ = selection.select_queries(ens, dis_s, y, col=col, disparity_ratio=0.25, eps=0.05)
+        with capsys.disabled():
+            print("\n[config 4 screen-then-settle, %s screening %s, column %d] oracle queries %d (active %d); screening alone differs "
+                  "in %d; settled: differs in %d; (pair, noise) rows settled %.1f %%, noisy images re-embedded %d of %d, delta %.2e"
+                  % (arch, screen, col, len(qs), act_o, len(set(q_scr) ^ qs), len(set(q) ^ qs), 100 * info["fraction_settled"],
+                     embedded[0], len(noises) * len(uniq), info["delta"]))
+        assert set(q) == qs and active == act_o
+        assert np.array_equal(labels, OA.roundoff(ens_o[q, col])) or not q

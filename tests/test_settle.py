@@ -1,0 +1,213 @@
+"""CPU: the screen-then-settle host logic (a-link_amd/settle.py) against brute force.  The exact and the screened
+arithmetic are stand-ins here (an array and the same array plus bounded noise): what is tested is that the selection
+that comes out is the exact arithmetic's, that only images near a cut are settled, that a band claimed too narrow widens
+itself, and that two ranks agree (gloo).  The -m gpu tests run the same engines over the HIP backbones."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import a_link_amd  # noqa: F401
+from a_link_amd import selection, settle
+
+
+def _exact_score32(p0, kind):
+    return settle._score_of_u(np.abs(np.asarray(p0, np.float64) - 0.5), kind).astype(np.float32)
+
+
+def test_directed_rounding():
+    x = np.array([0.1, 1.0, 1e-30, 0.6931471805599453, -0.3])
+    assert (settle._down32(x).astype(np.float64) <= x).all() and (settle._up32(x).astype(np.float64) >= x).all()
+    assert (settle._up32(x) - settle._down32(x) <= np.abs(x).astype(np.float32) * 2.4e-7 + 1e-37).all()
+
+
+def test_topk_undetermined_never_wrong_about_a_certain_item():
+    rng = np.random.default_rng(0)
+    for trial in range(30):
+        P, k = 200, int(rng.integers(1, 60))
+        c = rng.random(P).astype(np.float32)
+        w = np.where(rng.random(P) < 0.5, 0, rng.random(P) * 0.05).astype(np.float32)      # half the items are exact
+        lo, hi = c - w, c + w
+        for largest in (True, False):
+            in_T, need, und, a, b = settle.topk_undetermined(lo, hi, k, largest)
+            assert in_T.sum() == k and not need[w == 0].any() and not (need & ~und).any()
+            for _ in range(20):                                       # realisations inside the intervals
+                v = (lo + (hi - lo) * rng.random(P).astype(np.float32)).astype(np.float32)
+                v = np.clip(v, lo, hi)
+                top = set(np.lexsort((np.arange(P), -v if largest else v))[:k].tolist())
+                assert set(np.flatnonzero(in_T & ~und).tolist()) <= top
+                assert not (set(np.flatnonzero(~in_T & ~und).tolist()) & top)
+            if not need.any():
+                assert set(np.flatnonzero(in_T).tolist()) == top
+
+
+def _pool_case(seed, n=500, g=16, noise=2e-3, heavy=False):
+    rng = np.random.default_rng(seed)
+    p = np.clip(0.5 + rng.normal(0, 0.08, n * g), 0.001, 0.999)                  # many pairs near 1/2, like config 3's
+    err = rng.normal(0, noise / 3, n * g)
+    if heavy:
+        err[rng.integers(0, n * g, 5)] = noise * 3                               # a few outliers far beyond the typical error
+    ps = np.clip(p + err, 0, 1)
+    owner = np.repeat(np.arange(n), g)
+    return p, ps, owner
+
+
+@pytest.mark.parametrize("kind,largest", [("entropy", True), ("uncertainty", True), ("margin", False)])
+@pytest.mark.parametrize("settle_selected", [True, False])
+def test_settle_topk_equals_the_exact_topk(kind, largest, settle_selected):
+    n, g, k = 500, 16, 256
+    p, ps, owner = _pool_case(1, n, g)
+    calls = []
+
+    def exact_fn(imgs):
+        calls.append(len(imgs))
+        pos = (imgs[:, None] * g + np.arange(g)).ravel()
+        return pos, p[pos], _exact_score32(p[pos], kind)
+    vals, idx, info = settle.settle_topk(ps, _exact_score32(ps, kind), owner, n, exact_fn, k, kind=kind, largest=largest,
+                                         settle_selected=settle_selected, stage_above=64)
+    s = _exact_score32(p, kind)
+    want = np.lexsort((np.arange(n * g), -s if largest else s))[:k]
+    assert set(idx.tolist()) == set(want.tolist())
+    if settle_selected:
+        assert np.array_equal(idx, want) and np.array_equal(vals, s[want]) and info["members_unsettled"] == 0
+    assert info["images_settled"] < n and info["images_settled"] == sum(calls)
+    assert info["delta"] >= 1.5 * info["d_max"] > 0
+
+
+def test_settle_topk_band_claimed_too_narrow_widens_itself():
+    """delta0 = 1e-7 (a hundred-thousandth of the real screening error) and a first sample of 8 images: the engine must
+    not believe it — the first settled pairs show the real error, the band widens, the answer is still the exact one."""
+    n, g, k = 400, 16, 128
+    p, ps, owner = _pool_case(2, n, g, heavy=True)
+    exact_fn = lambda imgs: ((imgs[:, None] * g + np.arange(g)).ravel(),) + (lambda pos: (p[pos], _exact_score32(p[pos], "entropy")))((imgs[:, None] * g + np.arange(g)).ravel())
+    vals, idx, info = settle.settle_topk(ps, _exact_score32(ps, "entropy"), owner, n, exact_fn, k, delta0=1e-7, min_sample=8,
+                                         stage_above=32)
+    s = _exact_score32(p, "entropy")
+    assert np.array_equal(idx, np.lexsort((np.arange(n * g), -s))[:k])
+    assert info["widened"] >= 1 and info["delta"] > 1e-4 and info["rounds"] >= 2
+
+
+def test_settle_topk_gives_up_loudly():
+    n, g = 64, 4
+    p, ps, owner = _pool_case(3, n, g)
+    liar = lambda imgs: ((imgs[:, None] * g + np.arange(g)).ravel(), p[(imgs[:, None] * g + np.arange(g)).ravel()],
+                         _exact_score32(p[(imgs[:, None] * g + np.arange(g)).ravel()], "entropy"))
+    with pytest.raises(RuntimeError):
+        settle.settle_topk(ps, _exact_score32(ps, "entropy"), owner, n, liar, 32, max_rounds=0)
+
+
+def test_settle_topk_degenerate_sizes():
+    g = 3
+    for n, k in ((1, 1), (2, 6), (2, 100), (5, 0)):
+        p, ps, owner = _pool_case(4, n, g)
+        fn = lambda imgs: ((imgs[:, None] * g + np.arange(g)).ravel(), p[(imgs[:, None] * g + np.arange(g)).ravel()],
+                           _exact_score32(p[(imgs[:, None] * g + np.arange(g)).ravel()], "entropy"))
+        vals, idx, info = settle.settle_topk(ps, _exact_score32(ps, "entropy"), owner, n, fn, k)
+        s = _exact_score32(p, "entropy")
+        assert np.array_equal(idx, np.lexsort((np.arange(n * g), -s))[:k])
+
+
+def _rule_case(seed, P=2000, n_noise=3, noise=1.5e-3):
+    rng = np.random.default_rng(seed)
+    z = rng.normal(0, 1.5, P)
+    e0 = 1 / (1 + np.exp(-z))
+    ens = np.stack([e0, 1 - e0], 1).astype(np.float32)
+    dis, scr = [], []
+    for k in range(n_noise):
+        m0 = 1 / (1 + np.exp(-(z + rng.normal(0, 0.8, P))))
+        d = np.stack([m0, 1 - m0], 1).astype(np.float32)
+        s = np.clip(d + rng.normal(0, noise / 3, (P, 1)).astype(np.float32) * np.array([1, -1], np.float32), 0, 1)
+        dis.append(d)
+        scr.append(s.astype(np.float32))
+    y = (rng.random((P, 1)) < e0[:, None]).astype(np.int64)
+    return ens, dis, scr, y
+
+
+@pytest.mark.parametrize("col", [0, 1])
+@pytest.mark.parametrize("blind", [False, True])
+def test_select_queries_settled_equals_select_queries_on_exact_predictions(col, blind):
+    ens, dis, scr, y = _rule_case(5, P=4000, noise=4e-3)
+    asked = []
+
+    def settle_fn(k, idx):
+        asked.append((k, len(idx)))
+        return dis[k][idx]
+    q, active, labels, dis_out, settled, info = settle.select_queries_settled(ens, scr, y, settle_fn, col=col, blind_strategy=blind)
+    q0, active0, labels0 = selection.select_queries(ens, dis, y, col=col, blind_strategy=blind)
+    assert q == q0 and active == active0 and np.array_equal(labels, labels0)
+    assert len(q0) >= 10
+    # what the fine-tune set reads from the noisy passes is exact; most (pair, noise) rows were never settled
+    mp = int(len(q) / 3.0)
+    for i in range(3):
+        rows = q[i * mp:(i + 1) * mp]
+        assert settled[i][rows].all() and np.array_equal(dis_out[i][rows], dis[i][rows])
+    assert info["fraction_settled"] < 0.5 and info["delta"] >= 1.5 * info["d_max"] > 0
+    # and the screened predictions alone do NOT give the exact set (the test would be vacuous otherwise)
+    if not blind:
+        assert set(selection.disparity_indices(scr[0], ens, col, 0.25).tolist()) != set(selection.disparity_indices(dis[0], ens, col, 0.25).tolist())
+
+
+def test_select_queries_settled_band_claimed_too_narrow():
+    ens, dis, scr, y = _rule_case(6, noise=6e-3)
+    q, active, labels, _, _, info = settle.select_queries_settled(ens, scr, y, lambda k, idx: dis[k][idx], delta0=1e-8, min_sample=6)
+    q0, active0, _ = selection.select_queries(ens, dis, y)
+    assert q == q0 and active == active0 and info["delta"] > 1e-4
+
+
+def test_select_queries_settled_empty_and_tiny():
+    ens, dis, scr, y = _rule_case(7, P=3, n_noise=2)
+    q, active, labels, _, _, _ = settle.select_queries_settled(ens, scr, y, lambda k, idx: dis[k][idx])
+    q0, active0, labels0 = selection.select_queries(ens, dis, y)
+    assert q == q0 and active == active0 and labels.shape == labels0.shape
+
+
+# ---- two ranks (gloo): both resolve their own shard against the GLOBAL cut --------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from a_link_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, g, k = 301, 8, 200
+        p, ps, _ = _pool_case(8, n, g)
+        lo, hi = D.shard_range(n, rank, world)
+        pl, psl = p[lo * g:hi * g], ps[lo * g:hi * g]
+        owner = np.repeat(np.arange(hi - lo), g)
+
+        def exact_fn(imgs):
+            pos = (imgs[:, None] * g + np.arange(g)).ravel()
+            return pos, pl[pos], _exact_score32(pl[pos], "entropy")
+        vals, idx, info = settle.settle_topk(psl, _exact_score32(psl, "entropy"), owner, hi - lo, exact_fn, k, comm=settle.make_comm(),
+                                             base=lo * g, stage_above=32)
+        s = _exact_score32(p, "entropy")
+        want = np.lexsort((np.arange(n * g), -s))[:k]
+        q.put((rank, bool(np.array_equal(idx, want)), bool(np.array_equal(vals, s[want])), info["images_settled"], hi - lo))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_settle_topk_across_ranks_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert all(r[1] and r[2] for r in res), res
+    assert sum(r[3] for r in res) < sum(r[4] for r in res)
