@@ -72,6 +72,63 @@ def _launch_ranks(n):
     return rc
 
 
+
+def _identity_pool(n, seed, per_person=32, n_gallery=16):
+    """Synthetic pool for the config-3 leg, made on the device: n uint8 112x112 images of n / per_person identities (a blocky
+    random base face of 8x8-pixel blocks + per-image pixel noise and a brightness shift, like tests/golden/make_golden_config3.py)
+    and one further image of each of the first n_gallery identities as the gallery — (pool, gallery) pairs then range
+    from "same person" to "unrelated" like an unlabeled pool against enrolled faces."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    persons = max((n + per_person - 1) // per_person, n_gallery)
+    coarse = torch.randint(40, 216, (persons, 14, 14, 3), generator=g, device="cuda", dtype=torch.int16)
+    bases = coarse.repeat_interleave(8, dim=1).repeat_interleave(8, dim=2)
+
+    def draw(base_idx):
+        m = base_idx.numel()
+        out = torch.empty((m, 112, 112, 3), dtype=torch.uint8, device="cuda")
+        for i in range(0, m, 2048):
+            b = bases[base_idx[i:i + 2048]]
+            nz = torch.randint(-40, 41, b.shape, generator=g, device="cuda", dtype=torch.int16)
+            sh = torch.randint(-20, 21, (b.shape[0], 1, 1, 1), generator=g, device="cuda", dtype=torch.int16)
+            out[i:i + 2048] = (b + nz + sh).clamp_(0, 255).to(torch.uint8)
+        return out
+    pool = draw(torch.arange(n, device="cuda") // per_person)
+    gallery = draw(torch.arange(n_gallery, device="cuda"))
+    return pool, gallery
+
+
+def _spread_head(head, L, R, li, ri):
+    """Rescale the head's last layer so that its logit difference runs from about -2 to +2 (p from 0.12 to 0.88) between the
+    1st and the 99th percentile of these pairs, centred between them — a fresh glorot head puts every pair at 0.5 +- 0.02,
+    where no selection rule has anything to decide (same construction as the golden fixture's heads)."""
+    import numpy as np
+    p = head.predict_device(L, R, li, ri).double().cpu().numpy()
+    t = np.log(p[:, 1]) - np.log(p[:, 0])
+    lo, hi = np.percentile(t, [1, 99])
+    gain = 4.0 / max(hi - lo, 1e-12)
+    ws = head.get_weights()
+    ws[4] = (ws[4] * np.float32(gain)).astype(np.float32)
+    ws[5] = np.array([0, -gain * 0.5 * (lo + hi)], np.float32) + ws[5] * np.float32(gain)
+    head.set_weights(ws)
+
+
+def _timed(fn, reps, barrier, dist):
+    import torch
+    fn()                                   # untimed: workspaces of every stream slot exist afterwards
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+    torch.cuda.synchronize()
+    barrier()
+    t = torch.tensor([(time.perf_counter() - t1) / reps], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,9 +159,11 @@ def main():
     ap.add_argument("--no-c64", action="store_true", help="A/B: without the rolling-row kernel for the 64 -> 64 channel front layers")
     ap.add_argument("--no-fuse-sc", action="store_true", help="A/B: projection shortcuts as launches of their own instead of extra K-steps of conv2")
     ap.add_argument("--generic-epilogue", action="store_true", help="A/B: linear-tile kernel with the run-time-flag epilogue everywhere")
-    ap.add_argument("--config3", action="store_true", help="also time the config-3 leg (3 x IR-50 committee over a pool shard) "
-                    "at N = 1; under torch.distributed.run it always runs")
-    ap.add_argument("--config3-shard", type=int, default=2336, help="pool images per GPU in the config-3 leg")
+    ap.add_argument("--config3", action="store_true", help="(accepted for older scripts: the config-3 leg now always runs unless --no-config3)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the config-3 leg (3 x IR-50 committee over a pool shard: screening, "
+                    "all-exact and screen-then-settle)")
+    ap.add_argument("--config3-shard", type=int, default=12500, help="pool images per GPU in the config-3 leg (BASELINE configs[2]: 100k / 8)")
+    ap.add_argument("--no-configs1", action="store_true", help="skip the configs[1] leg (IR-50, one 256-image batch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile / fine-tune timing")
     ap.add_argument("--select-dtype", default="f16x2", choices=["f16x2", "f32", "none"], help="the exact-selection leg: the same "
@@ -186,12 +245,25 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs_ = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for i_ in range(args.steps):
+        if i_ == 0:
+            evs_[0].record()
+        if i_ == args.steps // 2:
+            evs_[1].record()
         bb.embed_device(x, out)
+    evs_[2].record()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    sustained = None
+    if args.steps >= 4:
+        a_ms, b_ms = evs_[0].elapsed_time(evs_[1]), evs_[1].elapsed_time(evs_[2])
+        h_ = args.steps // 2
+        sustained = {"first_half_ms_per_step": a_ms / h_, "second_half_ms_per_step": b_ms / (args.steps - h_),
+                     "second_over_first": (b_ms / (args.steps - h_)) / (a_ms / h_),
+                     "timing": "HIP events on the launch stream at step 0, steps/2 and the end of the timed region"}
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -222,10 +294,99 @@ def main():
         "tflops_end_to_end": emb_per_s * gflop_per_emb / 1e3,
         "frac_mfma_peak_end_to_end": emb_per_s * gflop_per_emb / 1e3 / (MFMA_PEAK_TFLOPS * world),
         "rccl_world_size": world if dist is not None else 0,
-        "selection_identity": {"bf16": "screening only: 389 of 1,024 config-3 selections differ from the f32 arithmetic",
-                               "f16": "49 of 1,024 differ", "f32": "identical (exact-f32 MFMA, ~3.8 k IR-100 embeddings/s)",
-                               "f16x2": "identical (split precision on the f16 matrix cores)"}.get(args.dtype),
+        "sustained_check": sustained,
+        # what a model built through the reference's API computes in when the caller names no dtype (ArcFace / FaceModel)
+        "default_api_dtype": __import__("a_link_amd.face_model", fromlist=["x"]).default_dtype(),
+        # CITATIONS of the committed test results (tests/test_gpu_pool.py, golden config3_r50.npz), not measurements of this
+        # run — this run's own count for its config-3 pool is config3.screening.selected_pairs_that_differ_from_exact_all
+        "selection_identity_cited": {"bf16": "screening only: 394 of 1,024 golden config-3 selections differ from the f32 oracle's",
+                                     "f16": "41 of 1,024 differ", "f32": "identical (exact-f32 MFMA, ~3.8 k IR-100 embeddings/s)",
+                                     "f16x2": "identical (split precision on the f16 matrix cores)",
+                                     "screen-then-settle": "identical (16-bit screening + split precision near the cuts)"},
+        "headline_mode_note": "value is the %s SCREENING rate; the rate with selection sets identical to the float32 arithmetic is "
+                              "exact_selection (every image exact) and config3.screen_settle (exact only near a cut)" % args.dtype
+                              if args.dtype in ("bf16", "f16") else None,
     }
+
+    def roofline_of(bbx, dt_name):
+        """roofline of the dominant kernel of one forward of `bbx`: HIP events around every launch (alink_embed_profile)"""
+        conv_ms, conv_fl, other_ms, profs = [], [], [], []
+        for _ in range(3):
+            prof = bbx.profile(x[:args.chunk])
+            profs.append(prof)
+            conv_ms.append(sum(ms for k, ms, f in prof if k == 1))
+            conv_fl.append(sum(f for k, ms, f in prof if k == 1))
+            other_ms.append(sum(ms for k, ms, f in prof if k != 1))
+        n_conv = sum(1 for k, _, _ in prof if k == 1)
+        cms = float(np.median(conv_ms))
+        achieved_all = conv_fl[0] / (cms * 1e-3) / 1e12
+        # the DOMINANT kernel: conv launches of one forward grouped by their algorithmic FLOPs (= same
+        # shape = same kernel instantiation); the group with the most time.  For r100/r50 that is the
+        # 14x14x256->256 stage-3 convolution (conv3x3_linear_kernel; conv3x3_direct_kernel with --linear 0).
+        # launch order of the chain: per stage s, unit u: conv1, [shortcut], conv2 (csrc/backbone.hip)
+        n_conv_launches = sum(1 for k, _, _ in profs[0] if k == 1)
+        fused_sc = n_conv_launches == 2 * sum(units)        # projection shortcuts inside the conv2 launch (16-bit modes)
+        shape_of = []
+        for s_ in range(4):
+            for u_ in range(units[s_]):
+                shape_of.append("stage%d %s" % (s_ + 1, "unit1 conv1" if u_ == 0 else "3x3 s1 C->C"))
+                if u_ == 0 and not fused_sc:
+                    shape_of.append("stage%d unit1 shortcut" % (s_ + 1))
+                shape_of.append("stage%d %s" % (s_ + 1, ("unit1 conv2 (stride 2%s)" % (" + 1x1 shortcut" if fused_sc else "")) if u_ == 0 else "3x3 s1 C->C"))
+        groups = {}
+        for run in profs:
+            convs = [(ms, f) for k, ms, f in run if k == 1]
+            assert len(convs) == len(shape_of)
+            for name, (ms, f) in zip(shape_of, convs):
+                g = groups.setdefault(name, [f, []])
+                g[1].append(ms)
+        dom_name, (dom_f, dom_ms) = max(groups.items(), key=lambda kv: sum(kv[1][1]))
+        dom_avg = float(np.mean(dom_ms))
+        dom_achieved = dom_f / (dom_avg * 1e-3) / 1e12
+        # HBM traffic per launch: PMC counters are collected in separate rocprofv3 --pmc passes
+        # (tools/pmc_summary.py -> profiles/*pmc_hbm_traffic*.csv); read the newest committed summary
+        traffic = None
+        try:
+            import glob
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_hbm_traffic_%s_%s_b*.csv" % (args.model, dt_name))))
+            if not pm and dt_name == "bf16":        # rounds 1-2 named the bf16 summaries without the dtype
+                pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_hbm_traffic_%s_b*.csv" % args.model)))
+            if pm:
+                rows = [ln.split(",") for ln in open(pm[-1]).read().splitlines()[1:]]
+                # the dominant instantiation is the 3x3 conv row with the most launches per forward
+                rows = [r for r in rows if r[0] in ("conv3x3_linear_kernel", "conv3x3_direct_kernel") and r[1]]
+                r = max(rows, key=lambda r: float(r[2]))
+                import re
+                nimg = int(re.search(r"_b(\d+)\.csv$", pm[-1]).group(1))       # images per launch of that profile
+                traffic = {"bytes_per_launch": (float(r[3]) + float(r[4])) * 1e6, "fetch_MB": float(r[3]),
+                           "write_MB": float(r[4]), "launches_per_forward": float(r[2]), "per_images": nimg,
+                           "algorithmic_bytes_per_launch": (nimg * 196 * 256 * 2 * 2.5 + 256 * 2304 * 2) * (2 if dt_name == "f16x2" else 1),
+                           "note": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) and WRITE_SIZE, separate passes; "
+                                   "algorithmic = input + output (+ residual on every second launch) + weights",
+                           "source": os.path.basename(pm[-1]),
+                           # PMC counters need rocprofv3 passes of their own (tools/profile_round.sh): this is the newest
+                           # committed summary for this network and dtype, NOT a measurement of this run
+                           "measured_in_this_run": False}
+        except Exception:
+            traffic = None
+        return {"bound": "mfma",
+                            "kernel": "%s, %s: %d launches per %d-image forward, %.1f GFLOP each"
+                                      % ("conv3x3_linear_kernel (linear 16-pixel tiles, 4 waves, 2 workgroups/CU)"
+                                         if (args.linear < 0 or args.linear & 4) else "conv3x3_direct_kernel", dom_name, len(dom_ms) // len(profs), args.chunk, dom_f / 1e9),
+                            "achieved": dom_achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": dom_achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                            "flops_per_launch": dom_f, "avg_launch_ms": dom_avg,
+                            # split precision issues three MFMA FLOPs per algorithmic FLOP (hi*hi, hi*lo, lo*hi): what the matrix
+                            # pipes actually do, beside the algorithmic fraction above
+                            "mfma_flops_issued_per_algorithmic_flop": 3 if dt_name == "f16x2" else 1,
+                            "frac_issued": dom_achieved * (3 if dt_name == "f16x2" else 1) / MFMA_PEAK_TFLOPS,
+                            "timing": "HIP events on the launch stream around 4 back-to-back launches of every kernel of "
+                                      "the chain, kernels run one at a time (alink_embed_profile); rocprofv3 --kernel-trace of "
+                                      "`bench.py --streams 1 --batch %d` gives the same averages (profiles/)" % args.chunk,
+                            "all_conv_launches": {"launches": n_conv, "achieved": achieved_all,
+                                                  "frac": achieved_all / MFMA_PEAK_TFLOPS, "flops_per_forward": conv_fl[0],
+                                                  "kernel_ms_per_forward": cms,
+                                                  "non_conv_ms_per_forward": float(np.median(other_ms))}}
 
     sel_out = None
     if args.select_dtype != "none" and args.select_dtype != args.dtype:
@@ -263,6 +424,9 @@ def main():
             "max_abs_diff_vs_headline_dtype": float((sel_out - out).abs().max()),
             "note": "selection sets identical to the f32 oracle's: tests/test_gpu_pool.py (config 3: 0 of 1,024 differ; config 4: "
                     "both columns equal at IR-50 and IR-100 depth)"}
+        if rank == 0 and not args.no_extras and args.select_dtype == "f16x2":
+            # the exact mode's own dominant kernel: algorithmic fraction, issued fraction (3 MFMA FLOPs per algorithmic FLOP), traffic
+            line["exact_selection"]["roofline"] = roofline_of(bs, "f16x2")
         del bs
     del params
 
@@ -298,43 +462,118 @@ def main():
             del hdp
         line["finetune_step_dp_policy"] = "replicated below %d rows (a-link_amd/distributed.py)" % D.DP_SHARD_MIN_ROWS
 
-    if (dist is not None or args.config3) and not args.no_extras:
-        # ---- BASELINE configs[2] shape, this rank's share: a committee of THREE IR-50 backbones + heads over a pool
-        # shard against a 16-image gallery, entropy, local top-1024, one candidate exchange (device-side merge)
+    if not args.no_config3 and not args.no_extras:
+        # ---- BASELINE configs[2] shape, this rank's share: a committee of THREE IR-50 backbones + heads over a pool shard
+        # against a 16-image gallery, entropy, top-1024, one candidate exchange — three ways:
+        #   screening      everything in the 16-bit mode (f16 where the activations fit, else bf16): the fast number, whose
+        #                  selection is NOT the float32 arithmetic's (the count that differs is measured below);
+        #   exact_all      everything in split precision: the float32 arithmetic's selection;
+        #   screen_settle  screening + exact re-embedding of only the images that own a pair near the cut (settle.py):
+        #                  the SAME scores, order and indices as exact_all (asserted bit for bit here).
+        # Weights: the SURVEY draw with BatchNorm statistics matching the activations, like a trained checkpoint's (the raw
+        # draw's activations leave float16); pool: synthetic identities; heads: glorot, last layer rescaled so that
+        # probabilities spread over (0, 1).  The same calibration sample (seed 999) on every rank: scales and head
+        # rescaling are rank-consistent.
         from a_link_amd import distributed as D
+        from a_link_amd import _abi as _A
         from a_link_amd.head import DenseHead
         n_shard = args.config3_shard
-        c3_dtype = args.select_dtype if args.select_dtype != "none" else args.dtype        # selection: the exact mode
-        bbs = [IRBackbone(W.synthetic_ir_params(W.R50_UNITS, seed=s_), dtype=c3_dtype, device=local_rank,
-                          max_batch=args.chunk if c3_dtype != "f32" else 128, streams=args.streams, lazy_range_check=True) for s_ in (1, 2, 3)]
+        exact_dt = args.select_dtype if args.select_dtype != "none" else "f16x2"
+        cal, cal_gal = _identity_pool(512, 999)
+        shard, _g = _identity_pool(n_shard, 1000 + rank)
+        gal = cal_gal                                                           # the gallery is replicated: one draw for all ranks
+        exa, scr = [], []
+        for s_ in (1, 2, 3):
+            pr = W.synthetic_ir_params(W.R50_UNITS, seed=s_, normalized=True)
+            e_ = IRBackbone(pr, dtype=exact_dt, device=local_rank, max_batch=args.chunk if exact_dt != "f32" else 128, streams=args.streams)
+            if exact_dt == "f16x2":
+                e_.calibrate(cal[:args.chunk])
+            exa.append(e_)
+            s16 = IRBackbone(pr, dtype="auto", device=local_rank, max_batch=args.chunk, streams=args.streams)
+            if s16.dtype == "f16":
+                try:                                                          # the probe images passed; do these?
+                    s16.embed_device(cal)
+                except _A.AlinkError:
+                    s16 = IRBackbone(pr, dtype="bf16", device=local_rank, max_batch=args.chunk, streams=args.streams)
+            scr.append(s16)
+            del pr
         hds = [DenseHead(512, lr=0.1, seed=10 + i, device=local_rank) for i in range(3)]
-        gsh = torch.Generator(device="cpu").manual_seed(1000 + rank)
-        shard = torch.randint(0, 256, (n_shard, 112, 112, 3), generator=gsh, dtype=torch.uint8).cuda()
-        gal = torch.randint(0, 256, (16, 112, 112, 3), generator=torch.Generator(device="cpu").manual_seed(100), dtype=torch.uint8).cuda()
+        ncal = cal.shape[0]
+        lic = torch.arange(ncal, dtype=torch.int32, device="cuda").repeat_interleave(16)
+        ric = torch.arange(16, dtype=torch.int32, device="cuda").repeat(ncal)
+        for h_, e_ in zip(hds, exa):
+            _spread_head(h_, e_.embed_device(cal), e_.embed_device(cal_gal), lic, ric)
         lo_ = rank * n_shard
-        for _ in range(2):
-            tv, ti = D.committee_pool_topk(bbs, hds, shard, gal, 1024, lo_)
-        torch.cuda.synchronize()
-        barrier()
+        k3 = 1024
+        D.committee_pool_topk(exa, hds, shard[:args.chunk], gal, 16, lo_)          # warm-up of every handle
+        D.committee_pool_topk(scr, hds, shard[:args.chunk], gal, 16, lo_)
+        t_x, (xv, xi) = _timed(lambda: D.committee_pool_topk(exa, hds, shard, gal, k3, lo_), 2, barrier, dist)
+        t_s, (sv, si) = _timed(lambda: D.committee_pool_topk(scr, hds, shard, gal, k3, lo_), 2, barrier, dist)
+        inf3 = {}
+        t_ss, (ssv, ssi) = _timed(lambda: D.committee_pool_topk_settled(scr, exa, hds, shard, gal, k3, lo_, info=inf3), 2, barrier, dist)
+        inf3b = {}
+        t_set, (_v, sei) = _timed(lambda: D.committee_pool_topk_settled(scr, exa, hds, shard, gal, k3, lo_, settle_selected=False,
+                                                                         info=inf3b), 1, barrier, dist)
+        identical = bool(torch.equal(ssi, xi) and torch.equal(ssv, xv))
+        assert identical, "screen-then-settle returned a different selection than the all-exact pass"
+        assert set(sei.cpu().numpy().tolist()) == set(xi.cpu().numpy().tolist())
+        pool_n = world * n_shard
+        line["config3"] = {
+            "workload": "committee of 3 IR-50 (BatchNorm statistics matching the activations) + 3 heads (last layer rescaled: "
+                        "probabilities spread over (0,1)), %d synthetic-identity pool images per GPU x 16 gallery images = %d "
+                        "pairs per GPU, entropy, top-%d, candidate all-gather + device merge" % (n_shard, n_shard * 16, k3),
+            "exact_dtype": exact_dt, "screening_dtype": scr[0].dtype,
+            "screening": {"pool_images_per_s": pool_n / t_s, "ms_per_pass": 1e3 * t_s,
+                          "selected_pairs_that_differ_from_exact_all": len(set(si.cpu().numpy().tolist()) - set(xi.cpu().numpy().tolist())),
+                          "measured_in_this_run": True},
+            "exact_all": {"pool_images_per_s": pool_n / t_x, "ms_per_pass": 1e3 * t_x},
+            "screen_settle": {"pool_images_per_s": pool_n / t_ss, "ms_per_pass": 1e3 * t_ss,
+                              "fraction_re_embedded": inf3["fraction_re_embedded"], "rounds": inf3["rounds"],
+                              "delta": inf3["delta"], "largest_dp_seen": inf3["d_max"], "widened": inf3["widened"],
+                              "identical_to_exact_all": "scores, order and indices bit for bit (asserted in this run)",
+                              "speedup_over_exact_all": t_x / t_ss},
+            "screen_settle_set_only": {"pool_images_per_s": pool_n / t_set, "ms_per_pass": 1e3 * t_set,
+                                       "fraction_re_embedded": inf3b["fraction_re_embedded"],
+                                       "note": "members certain by interval keep their screened score: same SET (asserted), no exact scores for them"},
+            "backbone_forwards_per_s_exact_all": 3 * world * (n_shard + 16) / t_x,
+            "selected": int(xi.numel())}
+        del exa, scr, hds, shard, cal
+
+    if not args.no_configs1 and not args.no_extras:
+        # ---- BASELINE configs[1] AS WORDED: "ResNet-50 ArcFace 512-d feature extraction, 112x112 batch=256, 1 MI355X" — IR-50,
+        # ONE 256-image batch per step (one alink_embed call, split into two in-call shards by the library), in the screening
+        # dtype and in the exact mode
+        c1 = {}
+        p50 = W.synthetic_ir_params(W.R50_UNITS, seed=1, normalized=args.weights == "normalized")
+        g50 = ir_resnet.flops_per_image(W.R50_UNITS) / 1e9
+        x256 = x[:256] if B >= 256 else x
+        for dt_ in ([args.dtype] if args.dtype != "f32" else []) + ([args.select_dtype] if args.select_dtype == "f16x2" and args.dtype != "f16x2" else []):
+            b50 = IRBackbone(p50, image_size=(112, 112), dtype=dt_, device=local_rank, max_batch=256, streams=1, lazy_range_check=True)
+            if dt_ == "f16x2":
+                b50.calibrate(x256[:64])
+            o50 = torch.empty((x256.shape[0], 512), dtype=torch.float32, device="cuda")
+            n50 = 60 if dt_ != "f16x2" else 20
+            t50, _ = _timed(lambda: [b50.embed_device(x256, o50) for _ in range(n50)], 1, barrier, dist)
+            b50.check_range()
+            r50 = world * n50 * x256.shape[0] / t50
+            c1[dt_] = {"embeddings_per_s": r50, "ms_per_step": 1e3 * t50 / n50, "steps": n50, "tflops_algorithmic": r50 * g50 / 1e3,
+                       "frac_mfma_peak": r50 * g50 / 1e3 / (MFMA_PEAK_TFLOPS * world)}
+            del b50
+        c1["workload"] = "LResNet50E-IR, ONE %d-image batch per step per GPU, f32 pixels resident in HBM, %.3f GFLOP per embedding" % (x256.shape[0], g50)
+        line["configs1"] = c1
+        del p50
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- the boundary as the reference's callers use it: HOST arrays in, host arrays out (ArcFace.process on a NumPy pool,
+        # reference code/siamese.py:232-234) — PCIe-inclusive, never `value`: uint8 pixels, uploads overlapped with compute
+        hp = px[:B].numpy()
+        bb.embed(hp)
         t1 = time.perf_counter()
-        reps3 = 5
-        for _ in range(reps3):
-            tv, ti = D.committee_pool_topk(bbs, hds, shard, gal, 1024, lo_)
-        torch.cuda.synchronize()
-        barrier()
-        t3 = torch.tensor([(time.perf_counter() - t1) / reps3], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
-        for b_ in bbs:
-            b_.check_range()
-        line["config3"] = {"workload": "committee of 3 IR-50 + 3 heads, %d pool images per GPU x 16 gallery images, entropy, "
-                                       "top-1024, candidate all-gather + device merge" % n_shard,
-                           "dtype": c3_dtype,
-                           "ms_per_pass": 1e3 * float(t3.item()),
-                           "pool_images_per_s": world * n_shard / float(t3.item()),
-                           "backbone_forwards_per_s": 3 * world * (n_shard + 16) / float(t3.item()),
-                           "selected": int(ti.numel())}
-        del bbs, hds, shard
+        for _ in range(3):
+            eh = bb.embed(hp)
+        line["pool_from_host_u8_embeddings_per_s"] = 3 * B / (time.perf_counter() - t1)
+        line["pool_from_host_note"] = "IRBackbone.embed on a (%d,112,112,3) uint8 host array -> (N,512) host array, %s; PCIe-inclusive, not `value`" % (B, args.dtype)
+        assert np.isfinite(eh).all()
 
     if rank == 0 and not args.no_extras and args.dtype == "f32":
         # ---- float32 mode: every convolution and the FC on gemm32_kernel (v_mfma_f32_32x32x2_f32); no per-launch
@@ -356,81 +595,7 @@ def main():
                             "traffic": None, "flops_per_launch": args.chunk * gflop_per_emb * 1e9, "avg_launch_ms": fms,
                             "timing": "HIP events on the launch stream around one forward, median of 3"}
     if rank == 0 and not args.no_extras and args.dtype != "f32":
-        # ---- roofline of the dominant kernel (conv_igemm_kernel): HIP events around every launch
-        conv_ms, conv_fl, other_ms, profs = [], [], [], []
-        for _ in range(3):
-            prof = bb.profile(x[:args.chunk])
-            profs.append(prof)
-            conv_ms.append(sum(ms for k, ms, f in prof if k == 1))
-            conv_fl.append(sum(f for k, ms, f in prof if k == 1))
-            other_ms.append(sum(ms for k, ms, f in prof if k != 1))
-        n_conv = sum(1 for k, _, _ in prof if k == 1)
-        cms = float(np.median(conv_ms))
-        achieved_all = conv_fl[0] / (cms * 1e-3) / 1e12
-        # the DOMINANT kernel: conv launches of one forward grouped by their algorithmic FLOPs (= same
-        # shape = same kernel instantiation); the group with the most time.  For r100/r50 that is the
-        # 14x14x256->256 stage-3 convolution (conv3x3_linear_kernel; conv3x3_direct_kernel with --linear 0).
-        # launch order of the chain: per stage s, unit u: conv1, [shortcut], conv2 (csrc/backbone.hip)
-        n_conv_launches = sum(1 for k, _, _ in profs[0] if k == 1)
-        fused_sc = n_conv_launches == 2 * sum(units)        # projection shortcuts inside the conv2 launch (16-bit modes)
-        shape_of = []
-        for s_ in range(4):
-            for u_ in range(units[s_]):
-                shape_of.append("stage%d %s" % (s_ + 1, "unit1 conv1" if u_ == 0 else "3x3 s1 C->C"))
-                if u_ == 0 and not fused_sc:
-                    shape_of.append("stage%d unit1 shortcut" % (s_ + 1))
-                shape_of.append("stage%d %s" % (s_ + 1, ("unit1 conv2 (stride 2%s)" % (" + 1x1 shortcut" if fused_sc else "")) if u_ == 0 else "3x3 s1 C->C"))
-        groups = {}
-        for run in profs:
-            convs = [(ms, f) for k, ms, f in run if k == 1]
-            assert len(convs) == len(shape_of)
-            for name, (ms, f) in zip(shape_of, convs):
-                g = groups.setdefault(name, [f, []])
-                g[1].append(ms)
-        dom_name, (dom_f, dom_ms) = max(groups.items(), key=lambda kv: sum(kv[1][1]))
-        dom_avg = float(np.mean(dom_ms))
-        dom_achieved = dom_f / (dom_avg * 1e-3) / 1e12
-        # HBM traffic per launch: PMC counters are collected in separate rocprofv3 --pmc passes
-        # (tools/pmc_summary.py -> profiles/*pmc_hbm_traffic*.csv); read the newest committed summary
-        traffic = None
-        try:
-            import glob
-            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_hbm_traffic_%s_%s_b*.csv" % (args.model, args.dtype))))
-            if not pm and args.dtype == "bf16":        # rounds 1-2 named the bf16 summaries without the dtype
-                pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_hbm_traffic_%s_b*.csv" % args.model)))
-            if pm:
-                rows = [ln.split(",") for ln in open(pm[-1]).read().splitlines()[1:]]
-                # the dominant instantiation is the 3x3 conv row with the most launches per forward
-                rows = [r for r in rows if r[0] in ("conv3x3_linear_kernel", "conv3x3_direct_kernel") and r[1]]
-                r = max(rows, key=lambda r: float(r[2]))
-                import re
-                nimg = int(re.search(r"_b(\d+)\.csv$", pm[-1]).group(1))       # images per launch of that profile
-                traffic = {"bytes_per_launch": (float(r[3]) + float(r[4])) * 1e6, "fetch_MB": float(r[3]),
-                           "write_MB": float(r[4]), "launches_per_forward": float(r[2]), "per_images": nimg,
-                           "algorithmic_bytes_per_launch": (nimg * 196 * 256 * 2 * 2.5 + 256 * 2304 * 2) * (2 if args.dtype == "f16x2" else 1),
-                           "note": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) and WRITE_SIZE, separate passes; "
-                                   "algorithmic = input + output (+ residual on every second launch) + weights",
-                           "source": os.path.basename(pm[-1])}
-        except Exception:
-            traffic = None
-        line["roofline"] = {"bound": "mfma",
-                            "kernel": "%s, %s: %d launches per %d-image forward, %.1f GFLOP each"
-                                      % ("conv3x3_linear_kernel (linear 16-pixel tiles, 4 waves, 2 workgroups/CU)"
-                                         if (args.linear < 0 or args.linear & 4) else "conv3x3_direct_kernel", dom_name, len(dom_ms) // len(profs), args.chunk, dom_f / 1e9),
-                            "achieved": dom_achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": dom_achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
-                            "flops_per_launch": dom_f, "avg_launch_ms": dom_avg,
-                            # split precision issues three MFMA FLOPs per algorithmic FLOP (hi*hi, hi*lo, lo*hi): what the matrix
-                            # pipes actually do, beside the algorithmic fraction above
-                            "mfma_flops_issued_per_algorithmic_flop": 3 if args.dtype == "f16x2" else 1,
-                            "frac_issued": dom_achieved * (3 if args.dtype == "f16x2" else 1) / MFMA_PEAK_TFLOPS,
-                            "timing": "HIP events on the launch stream around 4 back-to-back launches of every kernel of "
-                                      "the chain, kernels run one at a time (alink_embed_profile); rocprofv3 --kernel-trace of "
-                                      "`bench.py --streams 1 --batch %d` gives the same averages (profiles/)" % args.chunk,
-                            "all_conv_launches": {"launches": n_conv, "achieved": achieved_all,
-                                                  "frac": achieved_all / MFMA_PEAK_TFLOPS, "flops_per_forward": conv_fl[0],
-                                                  "kernel_ms_per_forward": cms,
-                                                  "non_conv_ms_per_forward": float(np.median(other_ms))}}
+        line["roofline"] = roofline_of(bb, args.dtype)
         # ---- fine-tune step (second half of BASELINE.json's metric): head-512, batch 16
         from a_link_amd.head import DenseHead
         hd = DenseHead(512, lr=0.1, seed=0, device=local_rank)
@@ -535,7 +700,9 @@ def main():
         ps_dt = time.perf_counter() - t1
         line["cpu_baseline"] = {"value": best_rate, "unit": "embeddings/s", "cores": cores, "kind": "port",
                                 "sample": "one batch-%d forward of the same %s network (torch-CPU f32 oracle): the fastest of the batch "
-                                          "sizes tried inside a ~20 s budget, %s" % (best_b, args.model, ", ".join("batch %d: %.2f/s" % t for t in trials)),
+                                          "sizes tried inside a ~20 s budget, %s.  DEVIATES from BASELINE.md §4 (one N = 256 forward): "
+                                          "at this host's rate that single forward alone would take %.0f s, beyond the budget that keeps "
+                                          "the default run within minutes" % (best_b, args.model, ", ".join("batch %d: %.2f/s" % t for t in trials), 256 / best_rate),
                                 "batch": best_b,
                                 "reference_shaped": {"value": n_one / one_dt, "unit": "embeddings/s",
                                                      "sample": "%d batch-1 forwards, each L2-normalised on its own: the "
