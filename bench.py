@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--no-config3", action="store_true", help="skip the config-3 leg (3 x IR-50 committee over a pool shard: screening, "
                     "all-exact and screen-then-settle)")
     ap.add_argument("--config3-shard", type=int, default=12500, help="pool images per GPU in the config-3 leg (BASELINE configs[2]: 100k / 8)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the config-4 leg (one A-LINK iteration, IR-100 teacher: all-exact and screen-then-settle)")
     ap.add_argument("--no-configs1", action="store_true", help="skip the configs[1] leg (IR-50, one 256-image batch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile / fine-tune timing")
@@ -574,6 +575,73 @@ def main():
         line["pool_from_host_u8_embeddings_per_s"] = 3 * B / (time.perf_counter() - t1)
         line["pool_from_host_note"] = "IRBackbone.embed on a (%d,112,112,3) uint8 host array -> (N,512) host array, %s; PCIe-inclusive, not `value`" % (B, args.dtype)
         assert np.isfinite(eh).all()
+
+    if rank == 0 and world == 1 and not args.no_config4 and not args.no_extras:
+        # ---- BASELINE configs[3] shape on one GPU: ONE A-LINK iteration (reference code/ALINK_arc.py:142-254) with an IR-100
+        # teacher — 16 persons x (2 plain + 3 disguised) = 80 unique images, P = 3,840 pairs, four noises drawn per pair
+        # occurrence = 30,720 noisy embeddings (the bulk of an iteration), selection, fine-tune —
+        # twice from identical seeds: every embedding exact, and screen-then-settle (noisy copies in the 16-bit mode, only
+        # the pairs near a cut of the rule and the selected ones again in the exact mode).  Must agree on the oracle-query
+        # count, the number of fine-tunes and the student's weights afterwards, bit for bit (asserted).
+        from a_link_amd import alink_loop as AL, committee, noise as NZ, pairs as PR, siamese
+        import tempfile
+        names = ("gaussian", "saltpepper", "poisson", "speckle")
+        ppl, _ = _identity_pool(16 * 5, 4242, per_person=5)
+        ppl = ppl.float().cpu().numpy().reshape(16, 5, 112, 112, 3)
+        X_plain, X_dig = [q[:2] for q in ppl], [q[2:] for q in ppl]
+        res4 = {}
+        tmpd = tempfile.mkdtemp()
+        for mode in ("exact_all", "screen_settle"):
+            conv = siamese.ArcFace((112, 112), "synthetic:r100:1:normalized", dtype="f16x2",
+                                   screen_dtype="auto" if mode == "screen_settle" else None)
+            conv.model.model.calibrate(torch.from_numpy(ppl.reshape(-1, 112, 112, 3)).cuda())
+            student = siamese.SiameseNetwork((512,), os.path.join(tmpd, "student"), 0.1, seed=1)
+            ens = [siamese.SiameseNetwork((512,), "e%d" % i, 0.1, seed=2 + i) for i in range(2)]
+            nzs = [NZ.get_relevant_noise(n_)(model=student, sess=None, feature_model=conv) for n_ in names]
+            feats = [conv.process(q) for q in X_plain]
+            allf = torch.from_numpy(np.concatenate(feats)).cuda()
+            li4 = torch.arange(len(allf), dtype=torch.int32, device="cuda").repeat_interleave(len(allf))
+            ri4 = torch.arange(len(allf), dtype=torch.int32, device="cuda").repeat(len(allf))
+            for h_ in [student] + ens:
+                _spread_head(h_.siamese_net, allf, allf, li4, ri4)
+            bag = committee.Bagging(ens, nzs)
+            flags = AL.Flags(out_model="", screen_settle=mode == "screen_settle")
+            ts4 = []
+            for rep in range(2):                       # rep 0 warms every handle and workspace; both reps start from the same state
+                student.siamese_net.set_weights(w0) if rep else None
+                w0 = student.siamese_net.get_weights()
+                for i_, z in enumerate(nzs):
+                    z._seed, z._calls = 1000 + i_, 0
+                np.random.seed(0)
+                gen = PR.getGenerator(PR.getNormalGenerator(feats, 16), PR.getNormalGenerator(feats, 16),
+                                      PR.getImposterGenerator(feats, feats, 16), 16)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                st4 = AL.run_alink_dfw(flags, conv, bag, nzs, student, X_plain, X_dig, gen, (112, 112), col=0, verbose=0)
+                torch.cuda.synchronize()
+                ts4.append(time.perf_counter() - t1)
+            res4[mode] = (ts4[-1], st4, student.siamese_net.get_weights(), conv.screen.model.dtype if conv.screen else None)
+            del conv, student, ens, bag, nzs
+        (t_e, st_e, w_e, _), (t_q, st_q, w_q, sdt) = res4["exact_all"], res4["screen_settle"]
+        same4 = (st_e.active_count == st_q.active_count and st_e.finetunes == st_q.finetunes and st_e.un_size == st_q.un_size
+                 and all(np.array_equal(a_, b_) for a_, b_ in zip(w_e, w_q)))
+        assert same4, "screen-then-settle A-LINK iteration differs from the all-exact one"
+        P4 = st_e.un_size
+        n_emb = 80 + 2 * P4 * len(names)
+        g100 = ir_resnet.flops_per_image(W.ARCH_UNITS["r100"]) / 1e9
+        inf4 = st_q.settle_info[-1]
+        line["config4"] = {
+            "workload": "one A-LINK iteration, IR-100 teacher (BatchNorm statistics matching the activations), 16 persons, 80 unique "
+                        "images, %d pairs, noises %s per pair occurrence = %d embeddings, heads' last layers rescaled (probabilities "
+                        "spread), selection + fine-tune" % (P4, "/".join(names), n_emb),
+            "exact_all": {"s_per_iteration": t_e, "embeddings_per_s": n_emb / t_e},
+            "screen_settle": {"s_per_iteration": t_q, "embeddings_per_s": n_emb / t_q, "screening_dtype": sdt,
+                              "fraction_pair_noise_rows_settled": inf4["fraction_settled"], "rounds": inf4["rounds"], "delta": inf4["delta"],
+                              "tflops_algorithmic": n_emb / t_q * g100 / 1e3, "frac_mfma_peak": n_emb / t_q * g100 / 1e3 / MFMA_PEAK_TFLOPS,
+                              "speedup_over_exact_all": t_e / t_q,
+                              "identical_to_exact_all": "oracle-query count, fine-tunes and the student's weights afterwards bit for bit (asserted in this run)"},
+            "oracle_queries": st_e.active_count, "finetunes": st_e.finetunes,
+            "note": "whole iteration on the wall clock: noise kernels, embeddings, heads, host-side selection, fine-tune"}
 
     if rank == 0 and not args.no_extras and args.dtype == "f32":
         # ---- float32 mode: every convolution and the FC on gemm32_kernel (v_mfma_f32_32x32x2_f32); no per-launch
