@@ -46,6 +46,9 @@ PROTOTYPES = {
     "alink_backbone_set_small_batch_split": (_i, [_vp, _i]),
     "alink_backbone_calibrate": (_i, [_vp, _vp, _i, _i, _vp, _sz, _i, _vp]),
     "alink_backbone_range_flag": (_i, [_vp, _i]),
+    "alink_backbone_num_scales": (_i, [_vp]),
+    "alink_backbone_get_scales": (_i, [_vp, _vp, _i]),
+    "alink_backbone_set_scales": (_i, [_vp, _vp, _i]),
     "alink_conv_nhwc_x2": (_i, [_vp] * 6 + [_i] * 14 + [_vp]),
     "alink_backbone_grad_workspace_bytes": (_sz, [_vp, _i]),
     "alink_embed_cached": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
@@ -62,6 +65,9 @@ PROTOTYPES = {
     "alink_resnet50_embed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "alink_resnet50_calibrate": (_i, [_vp, _vp, _i, _i, _vp, _sz, _i, _vp]),
     "alink_resnet50_range_flag": (_i, [_vp, _i]),
+    "alink_resnet50_num_scales": (_i, [_vp]),
+    "alink_resnet50_get_scales": (_i, [_vp, _vp, _i]),
+    "alink_resnet50_set_scales": (_i, [_vp, _vp, _i]),
     "alink_resnet50_profile": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp, _vp, _vp, C.POINTER(_i)]),
     "alink_resnet50_op_name": (C.c_char_p, [_vp, _i]),
     "alink_vgg16_create": (_vp, [_i, _i, _i]),

@@ -47,8 +47,11 @@ class IRBackbone(object):
         # hi + lo (22 significant bits) under a power-of-two scale per tensor, three products on the f16 matrix cores
         # into f32 accumulators.  The accuracy of the float32 mode (active-learning selection sets identical to the f32
         # arithmetic: DESIGN.md §5) at about a third of the bf16 rate.  Scales are calibrated on the same three probe
-        # images plus whatever `calibrate()` is given later; they change no bit of any embedding (powers of two), a batch
-        # that leaves the range (32x above the calibration images' largest activation) is re-calibrated and re-run.
+        # images plus whatever `calibrate()` is given later.  For FIXED scales an image embeds to the same bits whatever
+        # batch it arrives in; a different calibration moves embeddings by ~2e-7 (the lo halves of values 2^13 below a
+        # tensor's maximum are subnormal f16 and round differently) — far below the mode's error, not zero: share scales
+        # with state() / load_state().  A batch that leaves the range (32x above the calibration images' largest
+        # activation) is re-calibrated on (every chunk of it) and re-run, which changes the scales from then on.
         self._shards_fixed = None if shards_per_call is None else int(shards_per_call)
         self.lazy_range_check = bool(lazy_range_check)
         order = ["f16", "bf16"] if dtype == "auto" else [dtype]
@@ -110,19 +113,47 @@ class IRBackbone(object):
 
     def calibrate(self, x, merge=False):
         """dtype 'f16x2': choose the per-tensor power-of-two scales from these images (CUDA tensor or host array in any
-        accepted layout, at most max_batch of them are used).  merge=True only ever lowers a scale."""
+        accepted layout; ALL of them, max_batch at a time: the first chunk sets the scales unless merge, every further
+        chunk only lowers them).  merge=True only ever lowers a scale.  Embeddings are bit-reproducible for FIXED
+        scales: share them with state() / load_state() (checkpoints, the ranks of a job)."""
         if self.dtype != "f16x2":
             raise _abi.AlinkError("only dtype='f16x2' is calibrated")
         torch = self.torch
         if isinstance(x, np.ndarray):
             x = torch.from_numpy(np.ascontiguousarray(x if x.dtype == np.uint8 else x.astype(np.float32)))
-        x = x[:self.max_batch].to("cuda:%d" % self.device).contiguous()
         layout = self._layout_of(x, self.image_size)
-        n = x.shape[0]
-        ws, wsb = self._workspace(n)
-        torch.cuda.synchronize(self.device)
-        _abi.check(self.lib.alink_backbone_calibrate(self.h, _abi.ptr(x), layout, n, C.c_void_p(ws), wsb, 1 if merge else 0,
-                                                     _abi.current_stream(self.device)), "alink_backbone_calibrate")
+        for i in range(0, x.shape[0], self.max_batch):
+            xc = x[i:i + self.max_batch].to("cuda:%d" % self.device).contiguous()
+            n = xc.shape[0]
+            ws, wsb = self._workspace(n)
+            torch.cuda.synchronize(self.device)
+            _abi.check(self.lib.alink_backbone_calibrate(self.h, _abi.ptr(xc), layout, n, C.c_void_p(ws), wsb,
+                                                         1 if (merge or i) else 0, _abi.current_stream(self.device)),
+                       "alink_backbone_calibrate")
+
+    def state(self):
+        """The calibration state of the split-precision mode as a small dict of plain ints ({} for any other dtype): what
+        has to travel with a checkpoint, and from the rank that calibrated to every other rank, for embeddings to be
+        bit-identical there (include/alink_hip.h: alink_backbone_get_scales)."""
+        n = self.lib.alink_backbone_num_scales(self.h)
+        if n == 0:
+            return {}
+        e = (C.c_int * n)()
+        _abi.check(self.lib.alink_backbone_get_scales(self.h, e, n), "alink_backbone_get_scales")
+        return {"dtype": self.dtype, "units": [int(u) for u in self.units], "image_size": [int(v) for v in self.image_size],
+                "scale_exponents": [int(v) for v in e]}
+
+    def load_state(self, st):
+        """Install scales saved by state() (same architecture and image size)."""
+        if not st:
+            return
+        if st.get("dtype") != self.dtype or list(st.get("units", [])) != [int(u) for u in self.units] or \
+                list(st.get("image_size", [])) != [int(v) for v in self.image_size]:
+            raise _abi.AlinkError("calibration state of a %s %s network at %s does not fit this %s %s network at %s"
+                                  % (st.get("dtype"), st.get("units"), st.get("image_size"), self.dtype, list(self.units), list(self.image_size)))
+        v = [int(x) for x in st["scale_exponents"]]
+        e = (C.c_int * len(v))(*v)
+        _abi.check(self.lib.alink_backbone_set_scales(self.h, e, len(v)), "alink_backbone_set_scales")
 
     def _range_probe_ok(self):
         torch = self.torch

@@ -198,6 +198,12 @@ uint16_t f32_to_f16_rne(float f);
 
 int init_kernels();   // function attributes (dynamic LDS sizes)
 
+// ReLU and max that KEEP a NaN (v_max_f32 returns the other operand): 16-bit float storage that left its range turns into
+// inf - inf = NaN in the next convolution, and a ReLU written as fmaxf(v, 0) would turn that NaN into a plausible 0 — the
+// range flag is raised where a NaN reaches the pooled features, so it must get there (PReLU's select already keeps it).
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ float max_keep_nan(float a, float b) { return (a < b || b != b) ? b : a; }
+
 }  // namespace alink
 #include <map>
 #include <string>

@@ -1072,6 +1072,9 @@ int alink_backbone_calibrate(alink_backbone_t* bb, const void* dev_in, int layou
     DeviceGuard dg(bb->device);
     hipStream_t st = (hipStream_t)stream;
     ALINK_HIP(hipStreamSynchronize(st));
+    // a report still pending from an earlier forward (lazy range checks read the flag later) must survive the calibration run
+    const int pending = *(volatile int*)bb->h_flag;
+    struct Keep { int* f; int v; ~Keep() { if (v) *(volatile int*)f = 1; } } keep{bb->h_flag, pending};
     *bb->h_flag = 0;
     float* scratch = nullptr;           // the embeddings of the calibration batch are not wanted
     ALINK_HIP(hipMalloc((void**)&scratch, (size_t)n_images * bb->cfg.emb * sizeof(float)));
@@ -1079,6 +1082,35 @@ int alink_backbone_calibrate(alink_backbone_t* bb, const void* dev_in, int layou
                               nullptr, nullptr, nullptr, merge ? 2 : 1);
     (void)hipFree(scratch);
     return rc;
+}
+
+int alink_backbone_num_scales(const alink_backbone_t* bb) {
+    if (!bb || !bb->finalized || bb->cfg.dtype != ALINK_DT_F16X2) return 0;
+    return 1 + (int)bb->convs.size();
+}
+
+int alink_backbone_get_scales(const alink_backbone_t* bb, int* exponents, int n) {
+    ALINK_REQUIRE(bb && bb->finalized, ALINK_ESTATE, "alink_backbone_get_scales before alink_backbone_finalize");
+    ALINK_REQUIRE(bb->cfg.dtype == ALINK_DT_F16X2, ALINK_ESTATE, "only the split-precision mode (ALINK_DT_F16X2) has scales");
+    ALINK_REQUIRE(bb->calibrated, ALINK_ESTATE, "alink_backbone_get_scales before alink_backbone_calibrate / set_scales");
+    ALINK_REQUIRE(exponents && n == 1 + (int)bb->convs.size(), ALINK_EINVAL, "expected room for %d exponents, got %d",
+                  1 + (int)bb->convs.size(), n);
+    exponents[0] = bb->stem_e_out;
+    for (size_t i = 0; i < bb->convs.size(); ++i) exponents[1 + i] = bb->convs[i].e_out;
+    return ALINK_OK;
+}
+
+int alink_backbone_set_scales(alink_backbone_t* bb, const int* exponents, int n) {
+    ALINK_REQUIRE(bb && bb->finalized, ALINK_ESTATE, "alink_backbone_set_scales before alink_backbone_finalize");
+    ALINK_REQUIRE(bb->cfg.dtype == ALINK_DT_F16X2, ALINK_ESTATE, "only the split-precision mode (ALINK_DT_F16X2) has scales");
+    ALINK_REQUIRE(exponents && n == 1 + (int)bb->convs.size(), ALINK_EINVAL, "expected %d exponents, got %d",
+                  1 + (int)bb->convs.size(), n);
+    for (int i = 0; i < n; ++i)
+        ALINK_REQUIRE(exponents[i] >= -126 && exponents[i] <= 126, ALINK_EINVAL, "exponent %d of tensor %d is not a float32 power of two", exponents[i], i);
+    bb->stem_e_out = exponents[0];
+    for (size_t i = 0; i < bb->convs.size(); ++i) bb->convs[i].e_out = exponents[1 + i];
+    bb->calibrated = true;
+    return ALINK_OK;
 }
 
 int alink_backbone_range_flag(alink_backbone_t* bb, int reset) {

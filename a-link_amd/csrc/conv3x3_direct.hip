@@ -328,7 +328,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv3x3_direct_kernel(const ConvP
         }
         if (p.post_relu) {
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) v[i] = fmaxf(v[i], 0.f);
+            for (int i = 0; i < CPL; ++i) v[i] = relu_keep_nan(v[i]);
         }
         if (ok[u]) {
 #pragma unroll

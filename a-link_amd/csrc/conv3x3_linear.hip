@@ -377,7 +377,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float v = acc[2 * h + (i >> 2)][u][i & 3];
-                    if (p.post_relu) v = fmaxf(v, 0.f);
+                    if (p.post_relu) v = relu_keep_nan(v);
                     o8[i] = (T)v;
                     l8[i] = (T)(v - (float)o8[i]);
                 }
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
         }
         if (EPI == 0 && p.post_relu) {
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) v[i] = fmaxf(v[i], 0.f);
+            for (int i = 0; i < CPL; ++i) v[i] = relu_keep_nan(v[i]);
         }
         if (ok[u]) {
 #pragma unroll

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         }
         if (p.post_relu) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+            for (int i = 0; i < 16; ++i) v[i] = relu_keep_nan(v[i]);
         }
         if (ok[u]) {
             vec8 o0, o1;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void stem7_kernel(const Stem7Params p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = 4 * t + j;
-                    const float v = fmaxf(acc[t][j] + bi[i], 0.f);
+                    const float v = relu_keep_nan(acc[t][j] + bi[i]);
                     if (i < 8) o0[i] = (T)v; else o1[i - 8] = (T)v;
                 }
             T* o = (T*)p.out + (((size_t)n * p.Ho + oy) * Wo + ox) * 64 + cbase;
@@ -159,7 +159,7 @@ __global__ void maxpool3s2_kernel(const T* __restrict__ in, T* __restrict__ out,
         for (int dx = 0; dx < 3; ++dx) {
             const vec8 v = *(const vec8*)(in + (((size_t)n * H + 2 * oy + dy) * W + 2 * ox + dx) * C + c8 * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)v[j]);
+            for (int j = 0; j < 8; ++j) m[j] = max_keep_nan(m[j], (float)v[j]);
         }
     vec8 o;
 #pragma unroll
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void stem7_x2_kernel(const Stem7Params p, floa
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = 4 * t + j;
-                    const float v = fmaxf(fmaf(acc[t][j], acc_scale, bi[i]), 0.f);
+                    const float v = relu_keep_nan(fmaf(acc[t][j], acc_scale, bi[i]));
                     const T hi = (T)v;
                     const T lo = (T)(v - (float)hi);
                     if (i < 8) { o0[i] = hi; l0[i] = lo; } else { o1[i - 8] = hi; l1[i - 8] = lo; }
@@ -302,7 +302,7 @@ __global__ void maxpool3s2_x2_kernel(const _Float16* __restrict__ in, _Float16* 
             const _Float16* px = in + (((size_t)n * H + 2 * oy + dy) * W + 2 * ox + dx) * (2 * C) + coff;
             const f16x8 h = *(const f16x8*)px, l = *(const f16x8*)(px + 64);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)h[j] + (float)l[j]);
+            for (int j = 0; j < 8; ++j) m[j] = max_keep_nan(m[j], (float)h[j] + (float)l[j]);
         }
     f16x8 oh, ol;
 #pragma unroll
@@ -792,6 +792,8 @@ int alink_resnet50_calibrate(alink_resnet50_t* r, const float* dev_in, int n_ima
     DeviceGuard dg(r->device);
     hipStream_t st = (hipStream_t)stream;
     ALINK_HIP(hipStreamSynchronize(st));
+    const int pending = *(volatile int*)r->h_flag;          // a report not read yet survives the calibration run
+    struct Keep { int* f; int v; ~Keep() { if (v) *(volatile int*)f = 1; } } keep{r->h_flag, pending};
     *r->h_flag = 0;
     float* scratch = nullptr;
     ALINK_HIP(hipMalloc((void**)&scratch, (size_t)n_images * 2048 * sizeof(float)));
@@ -799,6 +801,31 @@ int alink_resnet50_calibrate(alink_resnet50_t* r, const float* dev_in, int n_ima
                            merge ? 2 : 1);
     (void)hipFree(scratch);
     return rc;
+}
+
+int alink_resnet50_num_scales(const alink_resnet50_t* r) {
+    if (!r || !r->finalized || r->dtype != ALINK_DT_F16X2) return 0;
+    return (int)r->ops.size();
+}
+
+int alink_resnet50_get_scales(const alink_resnet50_t* r, int* exponents, int n) {
+    ALINK_REQUIRE(r && r->finalized, ALINK_ESTATE, "alink_resnet50_get_scales before finalize");
+    ALINK_REQUIRE(r->dtype == ALINK_DT_F16X2, ALINK_ESTATE, "only the split-precision mode (ALINK_DT_F16X2) has scales");
+    ALINK_REQUIRE(r->calibrated, ALINK_ESTATE, "alink_resnet50_get_scales before alink_resnet50_calibrate / set_scales");
+    ALINK_REQUIRE(exponents && n == (int)r->ops.size(), ALINK_EINVAL, "expected room for %d exponents, got %d", (int)r->ops.size(), n);
+    for (size_t i = 0; i < r->ops.size(); ++i) exponents[i] = r->ops[i].e_out;
+    return ALINK_OK;
+}
+
+int alink_resnet50_set_scales(alink_resnet50_t* r, const int* exponents, int n) {
+    ALINK_REQUIRE(r && r->finalized, ALINK_ESTATE, "alink_resnet50_set_scales before finalize");
+    ALINK_REQUIRE(r->dtype == ALINK_DT_F16X2, ALINK_ESTATE, "only the split-precision mode (ALINK_DT_F16X2) has scales");
+    ALINK_REQUIRE(exponents && n == (int)r->ops.size(), ALINK_EINVAL, "expected %d exponents, got %d", (int)r->ops.size(), n);
+    for (int i = 0; i < n; ++i)
+        ALINK_REQUIRE(exponents[i] >= -126 && exponents[i] <= 126, ALINK_EINVAL, "exponent %d of op %d is not a float32 power of two", exponents[i], i);
+    for (size_t i = 0; i < r->ops.size(); ++i) r->ops[i].e_out = exponents[i];
+    r->calibrated = true;
+    return ALINK_OK;
 }
 
 int alink_resnet50_range_flag(alink_resnet50_t* r, int reset) {

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void conv_split_finish_kernel(const ConvParams
             if (p.alpha) x = x > 0.f ? x : x * p.alpha[c0 + j];
             if (p.resid) x += (float)e8[j];
         }
-        if (p.post_relu) x = fmaxf(x, 0.f);
+        if (p.post_relu) x = relu_keep_nan(x);
         v[j] = x;
     }
     vec8 o8;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void conv_split_finish_x2_kernel(const ConvPar
         float x = fmaf(v[j], p.acc_scale, p.bias[(size_t)cls * p.Cout + c0 + j] * p.bias_scale);
         if (p.alpha) x = x > 0.f ? x : x * p.alpha[c0 + j];
         if (p.resid) x = fmaf((float)rh[j] + (float)rl[j], p.res_scale, x);
-        if (p.post_relu) x = fmaxf(x, 0.f);
+        if (p.post_relu) x = relu_keep_nan(x);
         oh[j] = (T)x;
         ol[j] = (T)(x - (float)oh[j]);
     }

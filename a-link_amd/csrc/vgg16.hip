@@ -44,7 +44,7 @@ __global__ void maxpool2_kernel(const T* __restrict__ in, OUT* __restrict__ out,
     const vec8 c = *(const vec8*)(base + (size_t)W * C), d = *(const vec8*)(base + (size_t)W * C + C);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float m = fmaxf(fmaxf((float)a[j], (float)b[j]), fmaxf((float)c[j], (float)d[j]));
+        const float m = max_keep_nan(max_keep_nan((float)a[j], (float)b[j]), max_keep_nan((float)c[j], (float)d[j]));
         out[(size_t)i * 8 + j] = (OUT)m;
     }
 }

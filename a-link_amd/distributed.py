@@ -47,15 +47,21 @@ def merge_topk(local_vals, local_global_idx, k, largest=True, group=None):
     # rests on every rank handing in its candidates best-first with ties in ascending index order, from a contiguous
     # ascending shard (what shard_range + alink_topk produce)
     if n:
+        # ONE device reduction and ONE read-back for all of them (this runs once per pass of the config-3 path)
         gi = local_global_idx[:n].to(torch.int64)
-        if int(gi.max()) >= 2 ** 31 or int(gi.min()) < 0:
-            raise ValueError("merge_topk: global pair indices must lie in [0, 2^31) (got up to %d): shard the pool into "
-                             "passes of fewer pairs" % int(gi.max()))
+        v_ = local_vals[:n].to(torch.float32)
+        flags = [((gi >= 2 ** 31) | (gi < 0)).any(), torch.isnan(v_).any()]
         if n > 1:
-            v_ = local_vals[:n].to(torch.float32)
-            dv = (v_[1:] - v_[:-1]) if not largest else (v_[:-1] - v_[1:])
-            if bool((dv < 0).any()) or bool(((dv == 0) & (gi[1:] <= gi[:-1])).any()):
-                raise ValueError("merge_topk: candidates must be sorted best-first with ties in ascending index order")
+            worse = (v_[1:] > v_[:-1]) if largest else (v_[1:] < v_[:-1])          # comparisons, not differences: equal
+            flags.append((worse | ((v_[1:] == v_[:-1]) & (gi[1:] <= gi[:-1]))).any())   # infinities must count as ties
+        code = int((torch.stack(flags).to(torch.int32) * torch.tensor([1, 2, 4][:len(flags)], dtype=torch.int32, device=dev)).sum())
+        if code & 1:
+            raise ValueError("merge_topk: global pair indices must lie in [0, 2^31): shard the pool into passes of fewer pairs")
+        if code & 2:
+            raise ValueError("merge_topk: a candidate score is NaN (scores must be ordered: an embedding left the float16 "
+                             "range, or a head produced NaN)")
+        if code & 4:
+            raise ValueError("merge_topk: candidates must be sorted best-first with ties in ascending index order")
     pad = float("-inf") if largest else float("inf")
     mine = torch.empty((k, 2), dtype=torch.int32, device=dev)
     mine[:, 0] = torch.full((k,), pad, dtype=torch.float32, device=dev).view(torch.int32)
@@ -244,6 +250,21 @@ def committee_pool_topk_settled(screen_backbones, exact_backbones, heads, pool_s
         info.update(inf)
     out_dev = Eg[0].device
     return torch.from_numpy(np.ascontiguousarray(vals)).to(out_dev), torch.from_numpy(np.ascontiguousarray(gidx)).to(out_dev)
+
+
+def broadcast_calibration(backbones, src=0, group=None):
+    """Make the split-precision calibration state of rank `src` the state of every rank (IRBackbone / VGGResNet50
+    objects; other dtypes carry none and are skipped).  A rank calibrates on the images IT sees (its shard); the scales it
+    picks decide the last bits of every embedding, and the job-wide top-k merge assumes the same arithmetic on every rank
+    — so calibrate on one rank (or on a sample every rank draws identically), then call this; call it again after any
+    re-calibration (IRBackbone re-calibrates by itself when a batch leaves the range: check `state()` for a change).  One
+    small object broadcast per call."""
+    dist = _dist()
+    states = [bb.state() for bb in backbones] if dist.get_rank(group) == src else [None] * len(backbones)
+    dist.broadcast_object_list(states, src=src, group=group)
+    for bb, st in zip(backbones, states):
+        bb.load_state(st)
+    return states
 
 
 def embed_pool_sharded(feature_model, X, group=None, gather=True):

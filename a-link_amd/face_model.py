@@ -21,7 +21,8 @@ def default_dtype(enable_grad=False, small_batch_split=False):
     "f16x2" — split precision, whose active-learning selection sets equal the f32 arithmetic's (the reference computes
     in float32: code/face_model.py:90) at ~16 k IR-100 embeddings/s.  The input-gradient pass exists for 16-bit
     storage only: asking for it selects "bf16".  dtype="bf16" (44 k embeddings/s, 1 - cos ~3e-4: good for SCREENING, a
-    third of a tight top-k turns over) and "f16" / "f32" remain explicit choices."""
+    third of a tight top-k turns over) and "f16" / "f32" remain explicit choices.  small_batch_split (the opt-in latency
+    mode for batches <= 32) works in every 16-bit mode and does not change the dtype."""
     return "bf16" if enable_grad else "f16x2"
 
 

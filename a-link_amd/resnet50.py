@@ -125,17 +125,37 @@ class VGGResNet50(object):
             self.calibrate(probe)
 
     def calibrate(self, x, preprocessed=False, merge=False):
-        """dtype 'f16x2': choose the per-tensor power-of-two scales from these images (at most max_batch are used)."""
+        """dtype 'f16x2': choose the per-tensor power-of-two scales from these images (all of them, max_batch at a time;
+        every chunk after the first only lowers a scale, like merge=True)."""
         if self.dtype != "f16x2":
             raise _abi.AlinkError("only dtype='f16x2' is calibrated")
         torch = self.torch
         if isinstance(x, np.ndarray):
             x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
-        x = x[:self.max_batch].to("cuda:%d" % self.device).to(torch.float32).contiguous()
-        ws, wsb = self._workspace(x.shape[0])
-        torch.cuda.synchronize(self.device)
-        _abi.check(self.lib.alink_resnet50_calibrate(self.h, _abi.ptr(x), x.shape[0], 1 if preprocessed else 0, C.c_void_p(ws), wsb,
-                                                     1 if merge else 0, _abi.current_stream(self.device)), "alink_resnet50_calibrate")
+        for i in range(0, x.shape[0], self.max_batch):
+            xc = x[i:i + self.max_batch].to("cuda:%d" % self.device).to(torch.float32).contiguous()
+            ws, wsb = self._workspace(xc.shape[0])
+            torch.cuda.synchronize(self.device)
+            _abi.check(self.lib.alink_resnet50_calibrate(self.h, _abi.ptr(xc), xc.shape[0], 1 if preprocessed else 0, C.c_void_p(ws), wsb,
+                                                         1 if (merge or i) else 0, _abi.current_stream(self.device)), "alink_resnet50_calibrate")
+
+    def state(self):
+        """calibration state of the split-precision mode ({} otherwise): see IRBackbone.state"""
+        n = self.lib.alink_resnet50_num_scales(self.h)
+        if n == 0:
+            return {}
+        e = (C.c_int * n)()
+        _abi.check(self.lib.alink_resnet50_get_scales(self.h, e, n), "alink_resnet50_get_scales")
+        return {"dtype": self.dtype, "image_size": [int(v) for v in self.image_size], "scale_exponents": [int(v) for v in e]}
+
+    def load_state(self, st):
+        if not st:
+            return
+        if st.get("dtype") != self.dtype or list(st.get("image_size", [])) != [int(v) for v in self.image_size]:
+            raise _abi.AlinkError("calibration state does not fit this network")
+        v = [int(x) for x in st["scale_exponents"]]
+        e = (C.c_int * len(v))(*v)
+        _abi.check(self.lib.alink_resnet50_set_scales(self.h, e, len(v)), "alink_resnet50_set_scales")
 
     def __del__(self):
         try:

@@ -213,7 +213,7 @@ class ArcFace:
     def __init__(self, shape, model_path, dtype=None, max_batch=292, enable_grad=False, small_batch_split=False,
                  gpu=None, screen_dtype=None):
         # dtype=None: face_model.default_dtype — "f16x2" (selection sets identical to the reference's float32
-        # arithmetic), or "bf16" when the gradient pass / latency mode is requested
+        # arithmetic), or "bf16" when the gradient pass is requested
         args = _Args({
             "enable_grad": enable_grad,
             "small_batch_split": small_batch_split,   # latency mode for batches <= 32 (include/alink_hip.h)
@@ -238,6 +238,36 @@ class ArcFace:
     def backbones(self):
         """(screening IRBackbone or None, exact IRBackbone): what distributed.committee_pool_topk_settled takes"""
         return (self.screen.model if self.screen is not None else None), self.model.model
+
+    # The split-precision mode's calibration state travels with the checkpoint (the persistence contract of the
+    # reference's models is save / maybeLoadFromMemory, code/siamese.py:114-125: a file beside the model, False when it
+    # cannot be read): embeddings are bit-reproducible only under the same scales.
+    def _calibration_path(self, path=None):
+        if path:
+            return path
+        prefix = self.model.args.model.split(",")[0]
+        if prefix.startswith("synthetic:"):
+            raise ValueError("a synthetic checkpoint has no file to keep the calibration beside: pass a path")
+        return prefix + ".alink_scales.json"
+
+    def calibrate(self, X):
+        """choose the split-precision scales from images like the ones to come (any dtype other than f16x2: no-op)"""
+        if self.model.model.dtype == "f16x2":
+            self.model.model.calibrate(np.stack(X) if isinstance(X, (list, tuple)) else X)
+
+    def save_calibration(self, path=None):
+        import json
+        with open(self._calibration_path(path), "w") as f:
+            json.dump(self.model.model.state(), f)
+
+    def maybeLoadCalibration(self, path=None):
+        import json
+        try:
+            with open(self._calibration_path(path)) as f:
+                self.model.model.load_state(json.load(f))
+            return True
+        except Exception:
+            return False
 
     def preprocess(self, X):
         return X

@@ -143,6 +143,16 @@ int alink_backbone_calibrate(alink_backbone_t* bb, const void* dev_in, int layou
  * written by alink_embed was non-finite.  The word lives in pinned host memory the last kernel of a forward writes;
  * the caller must have synchronised the streams it embedded on.  reset != 0 clears it. */
 int alink_backbone_range_flag(alink_backbone_t* bb, int reset);
+/* The calibration state of the split-precision mode, portable: one scale exponent per tensor (the stem's output, then every
+ * convolution launch's output, in launch order; stored value = true value x 2^e).  An embedding is bit-reproducible for
+ * FIXED scales only (a different scale moves the lo halves of values far below the tensor's maximum through different
+ * f16 roundings: drift ~2e-7, far below the mode's own error, but not zero) — so a checkpoint saved for later
+ * (reference code/siamese.py:114-125 is the save / load contract of the models) and the ranks of a one-process-per-GPU
+ * job, whose top-k merge assumes replicated arithmetic, must SHARE them: get them on the rank / in the process that
+ * calibrated, set them everywhere else.  num_scales is 0 for any other dtype.  set_scales marks the handle calibrated. */
+int alink_backbone_num_scales(const alink_backbone_t* bb);
+int alink_backbone_get_scales(const alink_backbone_t* bb, int* exponents, int n);
+int alink_backbone_set_scales(alink_backbone_t* bb, const int* exponents, int n);
 size_t alink_backbone_grad_workspace_bytes(const alink_backbone_t* bb, int n_images);
 int alink_embed_cached(alink_backbone_t* bb, const void* dev_in, int layout, int n_images, float* dev_out,
                        void* dev_workspace, size_t workspace_bytes, void* stream);
@@ -196,6 +206,10 @@ int alink_resnet50_embed(alink_resnet50_t* r, const float* dev_in, int n_images,
 int alink_resnet50_calibrate(alink_resnet50_t* r, const float* dev_in, int n_images, int preprocessed,
                              void* dev_workspace, size_t workspace_bytes, int merge, void* stream);
 int alink_resnet50_range_flag(alink_resnet50_t* r, int reset);
+/* the portable calibration state, as for the IR backbone (one exponent per op of the chain, in op order) */
+int alink_resnet50_num_scales(const alink_resnet50_t* r);
+int alink_resnet50_get_scales(const alink_resnet50_t* r, int* exponents, int n);
+int alink_resnet50_set_scales(alink_resnet50_t* r, const int* exponents, int n);
 /* per-op HIP-event timing of one forward (synchronous): ms[i] / flops[i] for op i, name via op_name */
 int alink_resnet50_profile(alink_resnet50_t* r, const float* dev_in, int n_images, float* dev_out,
                            void* dev_workspace, size_t workspace_bytes, void* stream, float* ms,

@@ -133,3 +133,72 @@ def test_bench_starts_its_own_ranks():
     assert p.returncode != 0
     assert "needs a ROCm device" in p.stderr and "WORLD_SIZE=" not in p.stderr
     assert p.stdout.strip() == ""
+
+
+def _worker8(rank, world, port, q):
+    """Eight ranks (the node the driver scales to): shards shorter than the world, several EMPTY shards, eight candidate
+    lists of different lengths in one merge."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = []
+        # ---- n < world: 5 pool images over 8 ranks -> ranks 5..7 hold nothing, and say so
+        class Fake(object):
+            def process(self, X):
+                if len(X) == 0:                      # what ArcFace.process returns for an empty shard
+                    return np.zeros((0, 4), np.float32)
+                return np.repeat(np.asarray(X, np.float32).reshape(len(X), -1)[:, :1], 4, axis=1).reshape(len(X), 4)
+        X = np.arange(5, dtype=np.float32).reshape(5, 1, 1, 1)
+        E, (l0, h0) = D.embed_pool_sharded(Fake(), X)
+        ok.append(np.array_equal(E.numpy()[:, 0], np.arange(5)) and (l0, h0) == D.shard_range(5, rank, world) and (h0 - l0 == 0) == (rank >= 5))
+        # ---- top-k over 8 candidate lists: pool of 37 pairs (ranks hold 5,5,5,5,5,4,4,4), k = 16 > any local length,
+        # ties across ranks; then a pool of 3 pairs (five empty ranks), k = 8 > the whole pool
+        for n, k in ((37, 16), (3, 8), (1000, 64)):
+            rng = np.random.RandomState(n)
+            scores = rng.rand(n).astype(np.float32)
+            scores[rng.randint(0, n, max(1, n // 4))] = 0.5
+            lo, hi = D.shard_range(n, rank, world)
+            loc = scores[lo:hi]
+            for largest in (True, False):
+                order = np.lexsort((np.arange(lo, hi), -loc if largest else loc))[:k]
+                v, i = D.merge_topk(torch.from_numpy(loc[order]), torch.from_numpy(order + lo), k, largest=largest)
+                want = np.lexsort((np.arange(n), -scores if largest else scores))[:k]
+                ok.append(np.array_equal(i.numpy(), want) and np.array_equal(v.numpy(), scores[want]))
+        # ---- batch slices cover a 16-row fine-tune batch at 8 ranks (2 rows each) and a 3-row batch (five empty slices)
+        ok.append(D.dp_batch_slices(16, 8) == [(2 * r, 2 * r + 2) for r in range(8)])
+        s3 = D.dp_batch_slices(3, 8)
+        ok.append(s3[:3] == [(0, 1), (1, 2), (2, 3)] and all(a == b == 3 for a, b in s3[3:]))
+        # ---- screen-then-settle across 8 ranks, three of them with an empty shard
+        from a_link_amd import settle
+        n, g, k = 5, 4, 7
+        rs = np.random.default_rng(0)
+        p = np.clip(0.5 + rs.normal(0, 0.1, n * g), 0.01, 0.99)
+        ps = np.clip(p + rs.normal(0, 1e-3, n * g), 0, 1)
+        lo, hi = D.shard_range(n, rank, world)
+        pl, psl = p[lo * g:hi * g], ps[lo * g:hi * g]
+        sc = lambda x: settle._score_of_u(np.abs(np.asarray(x, np.float64) - 0.5), "entropy").astype(np.float32)
+        fn = lambda imgs: ((imgs[:, None] * g + np.arange(g)).ravel(), pl[(imgs[:, None] * g + np.arange(g)).ravel()],
+                           sc(pl[(imgs[:, None] * g + np.arange(g)).ravel()]))
+        vals, idx, info = settle.settle_topk(psl, sc(psl), np.repeat(np.arange(hi - lo), g), hi - lo, fn, k, comm=settle.make_comm(), base=lo * g)
+        ok.append(np.array_equal(idx, np.lexsort((np.arange(n * g), -sc(p)))[:k]))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_8_gloo_short_and_empty_shards():
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert len(res) == 8
+    for r, ok in res:
+        assert all(ok), (r, ok)

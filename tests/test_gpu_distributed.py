@@ -180,3 +180,83 @@ def test_sharded_finetune_step_world_size_2(gpu, tmp_path):
             assert np.abs(z[exch + "_m"] - np.asarray(want_m, np.float64)).max() < 2e-6, (r, exch, z[exch + "_m"], want_m)
     assert "host" in ran
     print("sharded fine-tune step at world size 2: exchanges exercised = %s" % sorted(ran))
+
+
+def _calib_worker(rank, world, port, path):
+    """One rank of a two-process job sharing cuda:0: calibrates its split-precision backbone on ITS shard, embeds the shared
+    gallery, then takes rank 0's scales (distributed.broadcast_calibration) and embeds it again."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import a_link_amd  # noqa: F401
+        from a_link_amd import distributed as D, weights as W
+        from a_link_amd.backbone import IRBackbone
+        size = (32, 32)
+        params = W.synthetic_ir_params((1, 2, 1, 1), size=size, seed=3)
+        rng = np.random.default_rng(0)
+        gallery = rng.integers(0, 256, (16, 32, 32, 3)).astype(np.float32)
+        shard = rng.integers(0, 256, (2, 24, 32, 32, 3)).astype(np.float32)[rank] * (1.0 if rank == 0 else 40.0)   # rank 1: far brighter images
+        bb = IRBackbone(params, image_size=size, max_batch=16, dtype="f16x2")
+        bb.calibrate(shard)                                      # 24 images: two chunks of <= 16
+        own = bb.embed(gallery)
+        st_own = bb.state()
+        D.broadcast_calibration([bb])
+        shared = bb.embed(gallery)
+        np.savez(path % rank, own=own, shared=shared, e_own=np.asarray(st_own["scale_exponents"]),
+                 e_shared=np.asarray(bb.state()["scale_exponents"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_calibration_state_is_portable_across_ranks_and_processes(gpu, tmp_path):
+    """Portable, rank-consistent calibration of the split-precision mode (include/alink_hip.h: alink_backbone_get_scales /
+    set_scales; the persistence contract it serves is reference code/siamese.py:114-125).  Two spawned processes calibrate on
+    different shards: their scales differ and the shared gallery embeds to different bits (drift far below the mode's
+    error); after the broadcast both embed it to the SAME bits.  Then a save / load round trip: a fresh handle that loads
+    the saved state reproduces the embeddings bit for bit, without calibrating."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    path = str(tmp_path / "rank%d.npz")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_calib_worker, args=(r, 2, port, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    z0, z1 = np.load(path % 0), np.load(path % 1)
+    assert not np.array_equal(z0["e_own"], z1["e_own"])                       # different shards -> different scales
+    drift = float(np.abs(z0["own"] - z1["own"]).max())
+    assert 0 < drift < 2e-6, drift                                            # different bits, far below the mode's error
+    assert np.array_equal(z0["e_shared"], z0["e_own"]) and np.array_equal(z1["e_shared"], z0["e_own"])
+    assert np.array_equal(z0["shared"], z1["shared"]) and np.array_equal(z0["shared"], z0["own"])
+    print("calibration on different shards: max |d embedding| %.2e; after the broadcast: bit-equal" % drift)
+    # save / load round trip in THIS process (a third one): no calibration run, same bits
+    from a_link_amd import siamese, weights as W
+    from a_link_amd.backbone import IRBackbone
+    size = (32, 32)
+    params = W.synthetic_ir_params((1, 2, 1, 1), size=size, seed=3)
+    gallery = np.random.default_rng(0).integers(0, 256, (16, 32, 32, 3)).astype(np.float32)
+    bb = IRBackbone(params, image_size=size, max_batch=16, dtype="f16x2")
+    st = json.loads(json.dumps({"dtype": "f16x2", "units": [1, 2, 1, 1], "image_size": [32, 32], "scale_exponents": z0["e_own"].tolist()}))
+    assert not np.array_equal(bb.embed(gallery), z0["own"]) or bb.state()["scale_exponents"] == st["scale_exponents"]
+    bb.load_state(st)
+    assert np.array_equal(bb.embed(gallery), z0["own"])
+    with pytest.raises(Exception):
+        bb.load_state(dict(st, units=[1, 1, 1, 1]))
+    # ... and through the feature model's own save / load next to a checkpoint path
+    fm = siamese.ArcFace(size, "synthetic:r18:3", max_batch=16)
+    fm.calibrate(gallery * 3.0)
+    e1 = fm.process(gallery)
+    fm.save_calibration(str(tmp_path / "scales.json"))
+    fm2 = siamese.ArcFace(size, "synthetic:r18:3", max_batch=16)
+    assert fm2.maybeLoadCalibration(str(tmp_path / "scales.json")) and not fm2.maybeLoadCalibration(str(tmp_path / "absent.json"))
+    assert np.array_equal(fm2.process(gallery), e1)

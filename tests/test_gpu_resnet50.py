@@ -184,3 +184,35 @@ def test_alink_py_iteration_selection_through_resnet50_features(gpu, capsys, dty
               "column 0 %s, column 1 %s" % (dtype, len(li), d_ens, d_dis, diffs[0], diffs[1]))
     assert max(d[0] for d in diffs) >= 10
     assert d_ens < (2e-5 if dtype == "f16x2" else 0.1), d_ens
+
+
+def test_split_precision_overflow_is_reported_not_hidden(gpu):
+    """16-bit float storage that leaves its range must never come back as plausible finite features: in split precision a
+    value beyond 65504 stores as (inf, -inf), the next convolution makes NaN of it — and a ReLU written as fmaxf(v, 0) would
+    turn that NaN into 0 (the IR backbone's PReLU is a select and keeps it).  Scales calibrated on images 200x darker than
+    the batch (the headroom is 32x): the flag must go up (the ReLU / max-pool keep NaN), the network re-calibrates on the
+    batch and re-runs, and the features equal those of a handle calibrated on such images from the start.  (Pixels
+    themselves must stay within +-1023: the stem's loader keeps them as f16 x 2^6.)"""
+    from a_link_amd.resnet50 import VGGResNet50
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (4, 224, 224, 3)).astype(np.float32)
+    big = x * 3.9
+    m = VGGResNet50(dtype="f16x2", max_batch=4, seed=1)
+    m.calibrate(x * 0.02)
+    e0 = list(m.state()["scale_exponents"])
+    f = m.predict(big, preprocessed=False)
+    assert np.isfinite(f).all()
+    assert list(m.state()["scale_exponents"]) != e0, "the overflow went unnoticed: no re-calibration happened"
+    m2 = VGGResNet50(dtype="f16x2", max_batch=4, seed=1)
+    m2.calibrate(big)
+    f2 = m2.predict(big, preprocessed=False)
+    scale = np.abs(f2).max()
+    assert np.abs(f - f2).max() < 2e-6 * scale, (np.abs(f - f2).max(), scale)
+    # plain f16 cannot re-calibrate: it must raise, not return zeros where NaN was
+    from a_link_amd import _abi
+    m3 = VGGResNet50(dtype="f16", max_batch=4, seed=1)
+    try:
+        f3 = m3.predict(big, preprocessed=False)
+        assert np.isfinite(f3).all() and np.abs(f3).max() > 0
+    except _abi.AlinkError:
+        pass
