@@ -147,14 +147,26 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
         noisy_data = [[f.clone() if hasattr(f, "detach") else np.array(f, copy=True) for f in part] for part in noisy_data]
         screened = [_np(student.predict([noisy_data[0][jj], noisy_data[1][jj]])) for jj in range(n_noise)]
 
-        def settle_fn(jj, idx):
-            sides = [noisy_for_student(_rows(pixels[s][jj], idx)) for s in (0, 1)]
-            for s in (0, 1):
-                _set_rows(noisy_data[s][jj], idx, sides[s])          # the exact rows replace the screened ones
-            return _np(student.predict(sides))
+        def settle_many(requests):
+            """a round's requests [(noise, pairs)]: both sides of every request converted in ONE exact call"""
+            parts = [_rows(pixels[s][jj], idx) for jj, idx in requests for s in (0, 1)]
+            if hasattr(parts[0], "detach"):
+                import torch
+                conv = noisy_for_student(torch.cat(parts))
+            else:
+                conv = noisy_for_student(np.concatenate([np.asarray(p) for p in parts]))
+            out, o = [], 0
+            for jj, idx in requests:
+                sides = []
+                for s in (0, 1):
+                    sides.append(conv[o:o + len(idx)])
+                    _set_rows(noisy_data[s][jj], idx, sides[-1])     # the exact rows replace the screened ones
+                    o += len(idx)
+                out.append(_np(student.predict(sides)))
+            return out
         queryIndices, active, labels, disguisedPredictions, _, info = settle.select_queries_settled(
-            ensemblePredictions, screened, batch_y, settle_fn, col=col, disparity_ratio=flags.disparity_ratio,
-            eps=flags.eps, blind_strategy=flags.blind_strategy)
+            ensemblePredictions, screened, batch_y, None, col=col, disparity_ratio=flags.disparity_ratio,
+            eps=flags.eps, blind_strategy=flags.blind_strategy, settle_many=settle_many)
         state.settle_info.append(info)
     else:
         noisy_data = [[noisy_for_student(p) for p in part] for part in noisy_data]

@@ -131,6 +131,20 @@ class IRBackbone(object):
                                                          1 if (merge or i) else 0, _abi.current_stream(self.device)),
                        "alink_backbone_calibrate")
 
+    def set_products(self, n):
+        """dtype 'f16x2': matrix-core products per multiplication for the launches that follow — 3 = the exact mode
+        (default), 1 = X_hi W_hi alone, the screening form on this same handle (include/alink_hip.h)."""
+        _abi.check(self.lib.alink_backbone_set_products(self.h, int(n)), "alink_backbone_set_products")
+
+    def screening_view(self):
+        """An object with this backbone's embed / embed_device that runs them in the ONE-product screening form (same
+        weights, scales and workspace; products are switched back to 3 after every call).  What screen-then-settle
+        takes as its screening model when the exact model is this handle: no second copy of the network, no float16
+        range to leave."""
+        if self.dtype != "f16x2":
+            raise _abi.AlinkError("screening_view is the one-product form of dtype='f16x2'")
+        return _ScreeningView(self)
+
     def state(self):
         """The calibration state of the split-precision mode as a small dict of plain ints ({} for any other dtype): what
         has to travel with a checkpoint, and from the rank that calibrated to every other rank, for embeddings to be
@@ -364,3 +378,23 @@ class IRBackbone(object):
         _abi.check(self.lib.alink_embed_profile(self.h, _abi.ptr(x), layout, n, _abi.ptr(out), C.c_void_p(ws), wsb,
                                                 _abi.current_stream(self.device), ms, fl, kd, C.byref(nl)), "alink_embed_profile")
         return [(kd[i], ms[i], fl[i]) for i in range(nl.value)]
+
+
+class _ScreeningView(object):
+    def __init__(self, bb):
+        self.bb = bb
+        self.dtype = "f16x2/1"
+        self.max_batch, self.image_size, self.emb, self.device = bb.max_batch, bb.image_size, bb.emb, bb.device
+
+    def _run(self, fn, *a, **k):
+        self.bb.set_products(1)
+        try:
+            return fn(*a, **k)
+        finally:
+            self.bb.set_products(3)
+
+    def embed_device(self, x, out=None):
+        return self._run(self.bb.embed_device, x, out=out)
+
+    def embed(self, x):
+        return self._run(self.bb.embed, x)

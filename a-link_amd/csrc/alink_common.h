@@ -97,6 +97,9 @@ struct ConvParams {
     float acc_scale;      // 2^(e_out - e_in - e_w): accumulator -> output units
     float bias_scale;     // 2^e_out
     float res_scale;      // 2^(e_out - e_resid)
+    int nprod;            // ALINK_DT_F16X2: 3 (0 = 3) = hi x W_hi + hi x W_lo + lo x W_hi, the exact mode; 1 = hi x W_hi only — the
+                          // SCREENING form on the same handle: one matrix-core product like plain f16, but under the handle's
+                          // power-of-two scales (no range to leave) and with the residual stream still carried as hi + lo
     void* stamps;         // diagnostic: 4 x u64 s_memtime stamps per workgroup, or nullptr
 };
 

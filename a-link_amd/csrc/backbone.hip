@@ -149,6 +149,7 @@ struct alink_backbone {
     F32Net* f32 = nullptr;      // cfg.dtype == ALINK_DT_F32: the float32 precision mode (backbone_f32.hip) runs every call
     // ALINK_DT_F16X2 (split precision)
     bool calibrated = false;
+    int  products = 3;                      // split precision: matrix-core products per multiplication (alink_backbone_set_products)
     int  stem_e_w = 0, stem_e_out = 0, fc_e_w = 0;
     unsigned* d_absmax = nullptr;           // calibration scratch: bits of the largest |value| of a tensor
     int* h_flag = nullptr;                  // pinned, device-visible: set by fc_finish when an embedding is not finite
@@ -917,6 +918,7 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         if (L.Cin2) { p.in2 = buf(L.in2_buf); p.Cin2 = L.Cin2; p.in2_compact = (front && &L == &bb->convs[1]) ? 1 : 0; }
         p.ablate = g_ablate;
         p.stagger = g_stagger;
+        p.nprod = (x2 && !calib) ? bb->products : 0;
         // few images (128-channel grid under 3/4 of the chip, g_fine_max): those workgroups cover only part of the chip and
         // each walks all of K alone on its CU; the 64-channel form doubles their number and halves a K-step
         // (bit-identical results: same weights, same summation order per output)
@@ -978,6 +980,7 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
         p.N = N; p.H = 1; p.W = 1; p.Cin = bb->fc_K; p.Cout = cfg.emb; p.Ho = 1; p.Wo = 1;
         p.stride = 1; p.ksz = 1; p.pad = 0; p.M = N; p.border_cls = 0;
         p.splitk = bb->fc_splitk; p.ksteps_per_split = bb->fc_kps * (x2 ? 3 : 1);
+        p.nprod = (x2 && !calib) ? bb->products : 0;
         ALINK_REQUIRE(p.splitk > 1, ALINK_EINVAL, "FC split-K must be > 1 (K=%d)", bb->fc_K);
         for (int r = 0; r < reps; ++r) ALINK_HIP(launch_conv_igemm(cfg.dtype, p, stream));
         note(conv_flops(p), 2);
@@ -1125,6 +1128,14 @@ int alink_backbone_range_flag(alink_backbone_t* bb, int reset) {
 int alink_backbone_set_small_batch_split(alink_backbone_t* bb, int on) {
     ALINK_REQUIRE(bb, ALINK_EINVAL, "NULL backbone");
     bb->split_small = on != 0;
+    return ALINK_OK;
+}
+
+int alink_backbone_set_products(alink_backbone_t* bb, int n) {
+    ALINK_REQUIRE(bb && bb->finalized, ALINK_ESTATE, "alink_backbone_set_products before alink_backbone_finalize");
+    ALINK_REQUIRE(bb->cfg.dtype == ALINK_DT_F16X2, ALINK_ESTATE, "only the split-precision mode (ALINK_DT_F16X2) has a product count");
+    ALINK_REQUIRE(n == 1 || n == 3, ALINK_EINVAL, "products must be 3 (exact) or 1 (screening), got %d", n);
+    bb->products = n;
     return ALINK_OK;
 }
 

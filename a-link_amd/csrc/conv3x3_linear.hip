@@ -98,7 +98,9 @@ struct Lin {
 // A chunk is walked three times — X = hi against W_hi, X = hi against W_lo, X = lo against W_hi — into the same f32
 // accumulators (27 K-steps per chunk instead of 9, two input refills instead of one); the dropped lo x W_lo term is 2^-22
 // of the sum.  Power-of-two scales per tensor (ConvParams::acc_scale, bias_scale, res_scale) keep hi in range and lo normal.
-template <typename T, int W, int TCW, int EPI, bool SP>
+// NP (SP only): matrix-core products per multiplication — 3 = the exact mode; 1 = X_hi W_hi alone (ConvParams::nprod: the
+// screening form on a split-precision handle): nine K-steps per chunk, the lo halves of input and weights never fetched.
+template <typename T, int W, int TCW, int EPI, bool SP, int NP = 3>
 __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams p) {
     typedef typename Vec8<T>::type vec8;
     typedef Lin<W, TCW> G;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
     // split mode (small batches: too few workgroups to fill the chip): blockIdx.y owns ncc / splitk of the
     // 64-channel input chunks and leaves its f32 partial sums in slab blockIdx.y (conv_split_finish_kernel
     // adds the slabs in order and applies the epilogue)
-    constexpr int NPH = SP ? 3 : 1;
+    constexpr int NPH = SP ? NP : 1;
     const int CinP = SP ? 2 * Cin : Cin;                               // pixel pitch of the input tensor in elements
     const int ncc_all = Cin >> 6;
     const int ncc = ncc_all / p.splitk, cc_first = (int)blockIdx.y * ncc;
@@ -177,7 +179,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
 #pragma unroll
         for (int i = 0; i < WSLOTS; ++i)
             dma16(wstep + (woff0 + (unsigned)(32 * i * K)), smem + G::WOFF + bufoff + (NT * i + wave * 64) * 16);
-        if (SP) {
+        if (SP && NP == 1) {
+            // the hi blocks 0..8 only, then over the chunk's lo blocks to the next chunk (18)
+            wstep += wr == 8 ? 10 * 64 : 64;
+            wr = wr == 8 ? 0 : wr + 1;
+        } else if (SP) {
             // blocks of the chunk: 0..8 hi, 9..17 lo; the walk is 0..17, back to 0..8, then on to the next chunk (18)
             wstep += wr == 17 ? -17 * 64 : (wr == 26 ? 10 * 64 : 64);
             wr = wr == 26 ? 0 : wr + 1;
@@ -477,6 +483,11 @@ hipError_t launch_one(const ConvParams& p, hipStream_t st) {
     const dim3 grid((unsigned)nwg, (unsigned)p.splitk);
     if (SP) {      // one epilogue form: it is a third of the 16-bit kernel's share of the time
         if (p.dact) return hipErrorInvalidValue;
+        if (p.nprod == 1) {
+            if (p.splitk > 1) hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 3, SP, 1>), grid, dim3(NT), G::lds_bytes(), st, p);
+            else              hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 0, SP, 1>), grid, dim3(NT), G::lds_bytes(), st, p);
+            return hipGetLastError();
+        }
         if (p.splitk > 1) hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 3, SP>), grid, dim3(NT), G::lds_bytes(), st, p);
         else              hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 0, SP>), grid, dim3(NT), G::lds_bytes(), st, p);
         return hipGetLastError();
@@ -504,6 +515,12 @@ hipError_t set_attr_sp() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lin<W, TCW>::lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<_Float16, W, TCW, 3, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lin<W, TCW>::lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<_Float16, W, TCW, 0, true, 1>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lin<W, TCW>::lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<_Float16, W, TCW, 3, true, 1>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lin<W, TCW>::lds_bytes());
     return e;
 }

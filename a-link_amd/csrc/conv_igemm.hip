@@ -236,6 +236,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             }
         };
         const int r1 = kt1 / 3;                            // real steps r0 .. r1 (a K split cuts between real steps)
+        if (p.nprod == 1) {
+            // the screening form (ConvParams::nprod): X_hi W_hi alone — (A1, W0) and (A0, W1) as a plain double buffer
+            if (r0 < r1) {
+                stage_a(A1, 0);
+                stage_w(W0, 0);
+                __syncthreads();
+                for (int r = r0; r < r1; ++r) {
+                    const bool odd = (r - r0) & 1;
+                    advance();
+                    if (r + 1 < r1) {
+                        stage_a(odd ? A1 : A0, 0);
+                        stage_w(odd ? W0 : W1, 0);
+                    }
+                    mma((odd ? A0 : A1) + (wp * 64) * 128, (odd ? W1 : W0) + (wc * 64) * 128);
+                    __syncthreads();
+                }
+            }
+        } else
         if (r0 < r1) {
             stage_a(A0, 1);
             stage_w(W0, 0);

@@ -288,7 +288,8 @@ def _disparity_interval(m, e, delta):
 
 
 def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, settle_fn, col=0, disparity_ratio=0.25,
-                           eps=0.05, blind_strategy=False, safety=1.5, delta0=0.0, min_sample=32, max_rounds=24):
+                           eps=0.05, blind_strategy=False, safety=1.5, delta0=0.0, min_sample=32, max_rounds=24,
+                           settle_many=None):
     """selection.select_queries with the noisy passes SCREENED: the clean pass (`ensemblePredictions`, every unique image
     of the mini-batch once: a few dozen embeddings) is exact, the 2 P n_noise noisy pair occurrences — the bulk of an
     iteration's embeddings — were embedded in the 16-bit mode, and `settle_fn(k, pairs)` returns the
@@ -299,7 +300,8 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
     (chunk i of the query list takes noise i, code/ALINK_arc.py:213-222) are settled too: what goes to the fine-tune set
     is exact.  Returns (queryIndices ascending, active_count, labels, disguisedPredictions with the settled rows exact,
     settled masks per noise, info) — queryIndices / active_count / labels equal selection.select_queries on all-exact
-    predictions."""
+    predictions.  settle_many (optional): f([(k, pairs), ...]) -> [predictions, ...] — a whole round's requests in ONE
+    call, so that the caller can embed them as one batch (a round asks for a few dozen to a few hundred pairs per noise)."""
     from .helpers import roundoff
     ens = np.asarray(ensemblePredictions)
     P = len(ens)
@@ -314,19 +316,26 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
     rounds = 0
     n_settled = 0
 
-    def settle(k, idx):
+    state = {"d": 0.0}
+
+    def settle_all(requests):
+        """requests: [(k, pair indices)] — drop what is settled already, ask for the rest in one call"""
         nonlocal n_settled
-        idx = np.asarray(sorted(set(int(i) for i in idx)), np.int64)
-        idx = idx[~settled[k][idx]]
-        if len(idx) == 0:
+        todo = []
+        for k, idx in requests:
+            idx = np.asarray(sorted(set(int(i) for i in idx)), np.int64)
+            idx = idx[~settled[k][idx]] if len(idx) else idx
+            if len(idx):
+                todo.append((k, idx))
+        if not todo:
             return
-        px = np.asarray(settle_fn(k, idx), np.float32)
-        bound_d = float(np.abs(px[:, col].astype(np.float64) - scr[k][idx]).max())
-        dis[k][idx] = px
-        settled[k][idx] = True
-        n_settled += len(idx)
-        settle.d = max(settle.d, bound_d)
-    settle.d = 0.0
+        got = settle_many(todo) if settle_many is not None else [settle_fn(k, idx) for k, idx in todo]
+        for (k, idx), px in zip(todo, got):
+            px = np.asarray(px, np.float32)
+            state["d"] = max(state["d"], float(np.abs(px[:, col].astype(np.float64) - scr[k][idx]).max()))
+            dis[k][idx] = px
+            settled[k][idx] = True
+            n_settled += len(idx)
 
     def membership():
         """per noise: (member mask by the pessimistic rule, pairs settling can help, pairs whose own side is uncertain,
@@ -353,7 +362,7 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
             mem = membership()
             # a pair outside T whose own side is certain is certainly cut by that noise (valid at any time)
             certainly_out = [~m[0] & ~m[2] for m in mem]
-            todo = 0
+            todo, requests = 0, []
             for k in range(n_noise):
                 in_T, need, und, lo, hi, dist = mem[k]
                 alive = notgrey.copy()                                # pairs that can still reach the query set
@@ -376,8 +385,9 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
                     near = np.argsort(np.where(settled[k], np.inf, dist), kind="stable")[:want]
                     idx = np.union1d(idx, near[~settled[k][near]])
                 todo += len(idx)
-                settle(k, idx)
-            bound.observe(settle.d)
+                requests.append((k, idx))
+            settle_all(requests)
+            bound.observe(state["d"])
             rounds += 1
             if todo == 0:
                 break
@@ -394,10 +404,9 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
         # what the fine-tune set takes from the noisy passes: chunk i of the query list <- noise i
         mp = int(len(queryIndices) / float(n_noise)) if n_noise else 0
         before = n_settled
-        for i in range(n_noise):
-            settle(i, queryIndices[i * mp:(i + 1) * mp])
+        settle_all([(i, queryIndices[i * mp:(i + 1) * mp]) for i in range(n_noise)])
         held = bound.delta
-        if n_settled == before or bound.observe(settle.d) == held:
+        if n_settled == before or bound.observe(state["d"]) == held:
             break             # the bound did not move: the determination above stands (points only replaced intervals)
     labels = roundoff(ens[queryIndices, col]) if queryIndices else np.zeros((0, 1), dtype=int)
     info = {"pairs": P, "noises": n_noise, "pair_noise_settled": int(n_settled), "fraction_settled": n_settled / float(max(P * n_noise, 1)),

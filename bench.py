@@ -495,7 +495,11 @@ def main():
                 try:                                                          # the probe images passed; do these?
                     s16.embed_device(cal)
                 except _A.AlinkError:
-                    s16 = IRBackbone(pr, dtype="bf16", device=local_rank, max_batch=args.chunk, streams=args.streams)
+                    s16 = None
+            if (s16 is None or s16.dtype != "f16") and exact_dt == "f16x2":
+                s16 = e_.screening_view()        # the one-product form of the exact handle: nothing to overflow, 8x finer than bf16
+            elif s16 is None:
+                s16 = IRBackbone(pr, dtype="bf16", device=local_rank, max_batch=args.chunk, streams=args.streams)
             scr.append(s16)
             del pr
         hds = [DenseHead(512, lr=0.1, seed=10 + i, device=local_rank) for i in range(3)]

@@ -150,6 +150,13 @@ int alink_backbone_range_flag(alink_backbone_t* bb, int reset);
  * (reference code/siamese.py:114-125 is the save / load contract of the models) and the ranks of a one-process-per-GPU
  * job, whose top-k merge assumes replicated arithmetic, must SHARE them: get them on the rank / in the process that
  * calibrated, set them everywhere else.  num_scales is 0 for any other dtype.  set_scales marks the handle calibrated. */
+/* Split precision only.  n = 3 (default): every multiplication as X_hi W_hi + X_hi W_lo + X_lo W_hi — the exact mode.
+ * n = 1: X_hi W_hi alone — the SCREENING form on the same handle (same folded weights, same calibrated scales, same
+ * workspace): one matrix-core product per multiplication like the plain f16 mode, but with nothing to overflow (the scales)
+ * and the residual stream still carried and added as hi + lo, so only the rounding of each convolution's operands to 11 bits
+ * remains.  For screen-then-settle selection (a-link_amd/settle.py): screen with n = 1, settle with n = 3.  Takes effect
+ * for launches enqueued after the call.  Calibration always runs with n = 3. */
+int alink_backbone_set_products(alink_backbone_t* bb, int n);
 int alink_backbone_num_scales(const alink_backbone_t* bb);
 int alink_backbone_get_scales(const alink_backbone_t* bb, int* exponents, int n);
 int alink_backbone_set_scales(alink_backbone_t* bb, const int* exponents, int n);

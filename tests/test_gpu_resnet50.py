@@ -195,24 +195,24 @@ def test_split_precision_overflow_is_reported_not_hidden(gpu):
     themselves must stay within +-1023: the stem's loader keeps them as f16 x 2^6.)"""
     from a_link_amd.resnet50 import VGGResNet50
     rng = np.random.default_rng(0)
-    x = rng.integers(0, 256, (4, 224, 224, 3)).astype(np.float32)
-    big = x * 3.9
+    x = rng.integers(0, 256, (4, 224, 224, 3)).astype(np.float32) - 128.0          # already-preprocessed pixels (no mean to subtract)
+    big = x * 7.0                                                                   # +-900
     m = VGGResNet50(dtype="f16x2", max_batch=4, seed=1)
-    m.calibrate(x * 0.02)
+    m.calibrate(x * 0.01, preprocessed=True)                                        # +-1.3: 700x below the batch
     e0 = list(m.state()["scale_exponents"])
-    f = m.predict(big, preprocessed=False)
+    f = m.predict(big, preprocessed=True)
     assert np.isfinite(f).all()
     assert list(m.state()["scale_exponents"]) != e0, "the overflow went unnoticed: no re-calibration happened"
     m2 = VGGResNet50(dtype="f16x2", max_batch=4, seed=1)
-    m2.calibrate(big)
-    f2 = m2.predict(big, preprocessed=False)
+    m2.calibrate(big, preprocessed=True)
+    f2 = m2.predict(big, preprocessed=True)
     scale = np.abs(f2).max()
     assert np.abs(f - f2).max() < 2e-6 * scale, (np.abs(f - f2).max(), scale)
     # plain f16 cannot re-calibrate: it must raise, not return zeros where NaN was
     from a_link_amd import _abi
     m3 = VGGResNet50(dtype="f16", max_batch=4, seed=1)
     try:
-        f3 = m3.predict(big, preprocessed=False)
+        f3 = m3.predict(big, preprocessed=True)
         assert np.isfinite(f3).all() and np.abs(f3).max() > 0
     except _abi.AlinkError:
         pass
