@@ -124,6 +124,7 @@ PROTOTYPES = {
     "alink_perlin_vectors": (_i, [_i, _i, _u64, _vp, _vp]),
     "alink_noise_perlin": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i), _vp, _vp]),
     "alink_resize_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "alink_pgd_step": (_i, [_vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _vp]),
     "alink_perturb_images": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "alink_arcface_margin_workspace_bytes": (_sz, [_i, _i, _i]),
     "alink_arcface_margin_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

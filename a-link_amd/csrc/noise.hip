@@ -476,6 +476,46 @@ int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64
     return ALINK_OK;
 }
 
+// ---- signed-gradient step + projection (FGSM / PGD extension, a-link_amd/noise.py) -------------------------------------
+// adv <- clip(clip(adv + step * sign(grad), clean - eps, clean + eps), lo, hi), in place; 16 B per lane, HBM-bound
+// (three float32 streams in, one out)
+namespace alink {
+namespace {
+__global__ __launch_bounds__(256) void pgd_step_kernel(float* __restrict__ adv, const float* __restrict__ clean,
+                                                       const float* __restrict__ grad, long long n4, long long n,
+                                                       float step, float eps, float lo, float hi) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    auto one = [&](float a, float c, float g) {
+        const float s = (g > 0.f ? 1.f : 0.f) - (g < 0.f ? 1.f : 0.f);
+        a = fmaf(step, s, a);
+        a = fminf(fmaxf(a, c - eps), c + eps);
+        return fminf(fmaxf(a, lo), hi);
+    };
+    if (i < n4) {
+        float4 a = ((const float4*)adv)[i];
+        const float4 c = ((const float4*)clean)[i], g = ((const float4*)grad)[i];
+        a.x = one(a.x, c.x, g.x); a.y = one(a.y, c.y, g.y); a.z = one(a.z, c.z, g.z); a.w = one(a.w, c.w, g.w);
+        ((float4*)adv)[i] = a;
+    } else if (i == n4) {
+        for (long long k = 4 * n4; k < n; ++k) adv[k] = one(adv[k], clean[k], grad[k]);
+    }
+}
+}  // namespace
+}  // namespace alink
+
+int alink_pgd_step(float* dev_adv, const float* dev_clean, const float* dev_grad, int64_t n, float step, float eps,
+                   float lo, float hi, void* stream) {
+    ALINK_REQUIRE(dev_adv && dev_clean && dev_grad && n >= 0, ALINK_EINVAL, "bad argument");
+    ALINK_REQUIRE((((uintptr_t)dev_adv | (uintptr_t)dev_clean | (uintptr_t)dev_grad) & 15) == 0, ALINK_EINVAL, "buffers must be 16-byte aligned");
+    if (n == 0) return ALINK_OK;
+    DeviceGuard dg(device_of_pointer(dev_adv));
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL(alink::pgd_step_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       dev_adv, dev_clean, dev_grad, n4, (long long)n, step, eps, lo, hi);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
 int alink_resize_bilinear(const float* dev_in, float* dev_out, int n, int H, int W, int C, int Ho, int Wo,
                           void* stream) {
     ALINK_REQUIRE(dev_in && dev_out && n >= 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, ALINK_EINVAL, "bad argument");

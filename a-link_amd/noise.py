@@ -287,6 +287,8 @@ class FGSM(Noise):
             al += (torch.rand(al.shape, generator=g, device=al.device) * 2 - 1) * self.eps
             ar += (torch.rand(ar.shape, generator=g, device=ar.device) * 2 - 1) * self.eps
         mb = bb.max_batch
+        lib = _abi.init(self.device)
+        al, ar = al.float().contiguous(), ar.float().contiguous()
         for _ in range(self.steps):
             for s in range(0, n, mb):
                 sl = slice(s, min(n, s + mb))
@@ -297,13 +299,12 @@ class FGSM(Noise):
                 er = bb.embed_with_cache(ar[sl])                  # right side against the un-stepped left
                 _, dR = head.input_gradients(el, er, y[sl])
                 gr = bb.input_gradient(dR)
-                al[sl] += sign * step * torch.sign(gl)
-                ar[sl] += sign * step * torch.sign(gr)
-            # stay inside the eps-ball of the clean images and inside the pixel range
-            al = torch.max(torch.min(al, xl + self.eps), xl - self.eps)
-            ar = torch.max(torch.min(ar, xr + self.eps), xr - self.eps)
-            if self.clip is not None:
-                al, ar = al.clamp(self.clip[0], self.clip[1]), ar.clamp(self.clip[0], self.clip[1])
+                # the step, the projection into the eps-ball of the clean images and the pixel clip: one kernel, in place
+                lo, hi = (self.clip if self.clip is not None else (float("-inf"), float("inf")))
+                for adv, clean, grad in ((al, xl, gl), (ar, xr, gr)):
+                    a_, c_, g_ = adv[sl], clean[sl].contiguous(), grad.contiguous()
+                    _abi.check(lib.alink_pgd_step(_abi.ptr(a_), _abi.ptr(c_), _abi.ptr(g_), a_.numel(), sign * step, self.eps,
+                                                  float(lo), float(hi), _abi.current_stream()), "alink_pgd_step")
         return [_ret(al, as_torch), _ret(ar, as_torch)]
 
     def addNoise(self, images, target_labels):
