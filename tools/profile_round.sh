@@ -1,19 +1,20 @@
 # usage (on the GPU box): bash tools/profile_round.sh <prefix, e.g. r03a>
 # Every bench line / rocprofv3 summary the round's documents cite; writes gpurun_out/<prefix>_*.
 set -x
-P=${1:-r03a}
+P=${1:-r04a}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O/prof
 cd $R
-python bench.py --config3 --steps 100 --warmup 10 > $O/${P}_bench_r100.json 2> $O/${P}_bench_r100.err
-python bench.py --dtype f16x2 --no-cpu-baseline > $O/${P}_bench_r100_f16x2.json 2>/dev/null
-python bench.py --dtype f16x2 --weights normalized --no-cpu-baseline > $O/${P}_bench_r100_f16x2_normalized.json 2>/dev/null
-python bench.py --dtype f16 --weights normalized --no-cpu-baseline --select-dtype none > $O/${P}_bench_r100_f16_normalized.json 2>/dev/null
-python bench.py --dtype f32 --batch 256 --chunk 128 --steps 5 --warmup 2 --no-cpu-baseline --select-dtype none > $O/${P}_bench_r100_f32.json 2>/dev/null
-python bench.py --model r50 --no-cpu-baseline > $O/${P}_bench_r50.json 2>/dev/null
-python bench.py --model r50 --batch 256 --chunk 256 --streams 1 --no-cpu-baseline > $O/${P}_bench_r50_b256.json 2>/dev/null
+python bench.py --steps 100 --warmup 10 > $O/${P}_bench_r100.json 2> $O/${P}_bench_r100.err      # the driver's command: every leg
+X="--no-config3 --no-config4 --no-configs1"        # the secondary lines: headline + roofline + exact leg only
+python bench.py $X --dtype f16x2 --no-cpu-baseline > $O/${P}_bench_r100_f16x2.json 2>/dev/null
+python bench.py $X --dtype f16x2 --weights normalized --no-cpu-baseline > $O/${P}_bench_r100_f16x2_normalized.json 2>/dev/null
+python bench.py $X --dtype f16 --weights normalized --no-cpu-baseline --select-dtype none > $O/${P}_bench_r100_f16_normalized.json 2>/dev/null
+python bench.py $X --dtype f32 --batch 256 --chunk 128 --steps 5 --warmup 2 --no-cpu-baseline --select-dtype none > $O/${P}_bench_r100_f32.json 2>/dev/null
+python bench.py $X --model r50 --no-cpu-baseline > $O/${P}_bench_r50.json 2>/dev/null
+python bench.py $X --model r50 --batch 256 --chunk 256 --streams 1 --no-cpu-baseline > $O/${P}_bench_r50_b256.json 2>/dev/null
 python tools/layer_profile.py --batch 292 > $O/${P}_layers_r100_b292.txt 2>&1
 python tools/layer_profile.py --batch 292 --dtype f16x2 > $O/${P}_layers_r100_b292_f16x2.txt 2>&1
 python tools/layer_profile.py --model r50 --batch 256 > $O/${P}_layers_r50_b256.txt 2>&1
