@@ -46,6 +46,7 @@ PROTOTYPES = {
     "alink_backbone_set_small_batch_split": (_i, [_vp, _i]),
     "alink_backbone_calibrate": (_i, [_vp, _vp, _i, _i, _vp, _sz, _i, _vp]),
     "alink_backbone_range_flag": (_i, [_vp, _i]),
+    "alink_backbone_device": (_i, [_vp]),
     "alink_backbone_set_products": (_i, [_vp, _i]),
     "alink_backbone_num_scales": (_i, [_vp]),
     "alink_backbone_get_scales": (_i, [_vp, _vp, _i]),

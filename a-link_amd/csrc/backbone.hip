@@ -1116,6 +1116,8 @@ int alink_backbone_set_scales(alink_backbone_t* bb, const int* exponents, int n)
     return ALINK_OK;
 }
 
+int alink_backbone_device(const alink_backbone_t* bb) { return bb ? bb->device : -1; }
+
 int alink_backbone_range_flag(alink_backbone_t* bb, int reset) {
     ALINK_REQUIRE(bb && bb->finalized, ALINK_ESTATE, "alink_backbone_range_flag before alink_backbone_finalize");
     if (!bb->h_flag) return 0;          // float32 mode: nothing to leave

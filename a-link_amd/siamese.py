@@ -183,13 +183,24 @@ class RESNET50:
     the keras-vggface weight file (`rcmalli_vggface_tf_notop_resnet50.h5`), a dict, or None for
     synthetic weights (keras-vggface downloads its file; there is no network here)."""
 
-    def __init__(self, shape, weights=None, dtype=None, max_batch=128, seed=1):
+    def __init__(self, shape, weights=None, dtype=None, max_batch=128, seed=1, screen_dtype=None):
         from .resnet50 import VGGResNet50
         self.shape = shape + (3,)
         # dtype=None: "f16x2", split precision — features to float32 accuracy, so that the selection the drivers make from
         # them (code/ALINK.py:67, code/ALINK_MTP.py:84, code/existing_al.py:58) follows the reference's float32 arithmetic;
         # "bf16" (3x faster, 1 - cos ~1e-4) and "f16" remain explicit choices
         self.model = VGGResNet50(image_size=tuple(shape), weights=weights, dtype=dtype or "f16x2", max_batch=max_batch, seed=seed)
+        # screen_dtype ("bf16" | "f16"): a second handle on the same weights in a 16-bit mode, for screen-then-settle selection
+        # (settle.py; the loop of alink_loop.py uses `process_screen` for the noisy copies when it exists).  Not in the reference.
+        self.screen = None
+        if screen_dtype:
+            self.screen = VGGResNet50(image_size=tuple(shape), weights=weights, dtype=screen_dtype, max_batch=max_batch, seed=seed)
+            self.process_screen = self._process_screen
+
+    def _process_screen(self, X):
+        if isinstance(X, (list, tuple)):
+            X = np.stack(X)
+        return self.screen.predict(X, batch_size=128, preprocessed=False)
 
     def preprocess(self, X):
         """utils.preprocess_input(np.copy(X), version=2): RGB -> BGR, subtract the VGGFace2 channel means."""

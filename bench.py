@@ -792,7 +792,19 @@ def main():
             line["exact_selection"]["one_minus_cos_vs_cpu_oracle_max"] = float((1.0 - (s8 * ref8).sum(1)).max())
             assert line["exact_selection"]["max_abs_diff_vs_cpu_oracle"] < 2e-5, line["exact_selection"]
 
+    # which device every rank's handles live on (the C ABI's device rule: a handle belongs to the device current at its create
+    # call; rank k of a one-process-per-GPU job must see its models on GPU LOCAL_RANK), gathered from all ranks
+    from a_link_amd import _abi as _AB
+    mine = torch.tensor([rank, local_rank, torch.cuda.current_device(), int(bb.device),
+                         int(_AB.load().alink_backbone_device(bb.h))],
+                        dtype=torch.int32, device="cuda")
+    seen = [mine.clone() for _ in range(world)]
+    if dist is not None:
+        dist.all_gather(seen, mine)
+    seen = [t.cpu().tolist() for t in seen]
+    assert all(r[1] == r[2] == r[3] == r[4] for r in seen), "a rank's handle is not on its own device: %s" % seen
     if rank == 0:
+        line["devices_seen"] = [{"rank": r[0], "local_rank": r[1], "current_device": r[2], "backbone_device": r[3], "handle_device": r[4]} for r in seen]
         line["parity"] = parity
         print(json.dumps(line))
     if dist is not None:

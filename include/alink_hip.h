@@ -143,6 +143,8 @@ int alink_backbone_calibrate(alink_backbone_t* bb, const void* dev_in, int layou
  * written by alink_embed was non-finite.  The word lives in pinned host memory the last kernel of a forward writes;
  * the caller must have synchronised the streams it embedded on.  reset != 0 clears it. */
 int alink_backbone_range_flag(alink_backbone_t* bb, int reset);
+/* the device this handle lives on (the one current at alink_backbone_create: the device rule at the top of this header); -1 for NULL */
+int alink_backbone_device(const alink_backbone_t* bb);
 /* The calibration state of the split-precision mode, portable: one scale exponent per tensor (the stem's output, then every
  * convolution launch's output, in launch order; stored value = true value x 2^e).  An embedding is bit-reproducible for
  * FIXED scales only (a different scale moves the lo halves of values far below the tensor's maximum through different

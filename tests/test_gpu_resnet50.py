@@ -95,14 +95,16 @@ def test_alink_py_shape_pipeline(net):
     assert p.shape == (2, 2) and np.allclose(p.sum(1), 1.0, atol=1e-6)
 
 
-@pytest.mark.parametrize("dtype", ["f16x2", "bf16"])
+@pytest.mark.parametrize("dtype", ["f16x2", "bf16", "f16x2+bf16"])
 def test_alink_py_iteration_selection_through_resnet50_features(gpu, capsys, dtype):
     """One A-LINK iteration the way code/ALINK.py runs it — VGGFace2 ResNet-50 features (code/ALINK.py:67), an ensemble
     of two pair heads on 2048-d features plus the disguised-faces head on two noisy copies, the selection rule of
     code/ALINK.py:170-201 (column 1) and code/ALINK_arc.py:167-198 (column 0) — against the oracle's query sets on the
     f32 torch-CPU ResNet-50's features of the same pixels.  Heads are trained oracle-side on other identities so that
     probabilities spread over (0, 1).  Split precision (the default of siamese.RESNET50) must reproduce both query sets;
-    bf16 storage is measured beside it (screening)."""
+    bf16 storage is measured beside it (screening); "f16x2+bf16" = SCREEN-THEN-SETTLE (a-link_amd/settle.py): clean features
+    exact, the noisy copies through the bf16 screening handle (RESNET50(screen_dtype="bf16")), only the images of pairs near a
+    cut re-embedded in split precision — must reproduce both query sets too."""
     from a_link_amd import committee, pairs, resnet50 as R, selection, siamese
     from oracle import al_logic as OA
     from oracle import vgg_resnet50 as O
@@ -154,10 +156,12 @@ def test_alink_py_iteration_selection_through_resnet50_features(gpu, capsys, dty
     ens_o = OA.bagging_predict([m.predict([Eo[li], Eo[ri]]) for m in m1])
     dis_o = [m2.predict([En[li], En[ri]]) for En in Eno]
     # device
-    fm = siamese.RESNET50(size, weights=params, dtype=dtype, max_batch=32)
+    settled_mode = dtype == "f16x2+bf16"
+    fm = siamese.RESNET50(size, weights=params, dtype="f16x2" if settled_mode else dtype, max_batch=32,
+                          screen_dtype="bf16" if settled_mode else None)
 
-    def feats_g(x):
-        f = fm.process(x)
+    def feats_g(x, screen=False):
+        f = fm.process_screen(x) if screen else fm.process(x)
         return (f / np.linalg.norm(f, axis=1, keepdims=True)).astype(np.float32)
 
     heads = []
@@ -167,7 +171,32 @@ def test_alink_py_iteration_selection_through_resnet50_features(gpu, capsys, dty
         heads.append(net)
     E = feats_g(uniq)
     ens = committee.Bagging(heads[:-1], []).predict_indexed(E, E, li, ri).cpu().numpy()
-    dis = [heads[-1].siamese_net.predict_device(En, En, li, ri).cpu().numpy() for En in (feats_g(nz) for nz in noises)]
+    En_g = [feats_g(nz, screen=settled_mode) for nz in noises]
+    dis = [heads[-1].siamese_net.predict_device(En, En, li, ri).cpu().numpy() for En in En_g]
+    if settled_mode:
+        from a_link_amd import settle
+        done = [np.zeros(len(uniq), bool) for _ in noises]
+
+        def settle_fn(k, idx):                   # noisy copies are per unique IMAGE here: a pair's two images, exactly, once
+            need = np.unique(np.concatenate([li[idx], ri[idx]]))
+            need = need[~done[k][need]]
+            if len(need):
+                En_g[k][need] = feats_g(noises[k][need])
+                done[k][need] = True
+            return heads[-1].siamese_net.predict_device(En_g[k], En_g[k], li[idx], ri[idx]).cpu().numpy()
+        screened = [np.array(d, copy=True) for d in dis]
+        for col in (0, 1):
+            for k in range(len(noises)):
+                done[k][:] = False
+            q, active, labels, _, _, info = settle.select_queries_settled(ens, screened, y, settle_fn, col=col, disparity_ratio=0.25, eps=0.05)
+            qs, act_o = OA.select_queries(ens_o, dis_o, y, col, 0.25, 0.05)
+            q_scr = selection.select_queries(ens, screened, y, col=col, disparity_ratio=0.25, eps=0.05)[0]
+            with capsys.disabled():
+                print("\n[ALINK.py shape, VGGFace2 ResNet-50 screen-then-settle (bf16 screening), column %d] oracle queries %d; screening alone "
+                      "differs in %d; settled differs in %d; (pair, noise) rows settled %.1f %%" % (col, len(qs), len(set(q_scr) ^ qs),
+                                                                                                  len(set(q) ^ qs), 100 * info["fraction_settled"]))
+            assert set(q) == qs and active == act_o, (col, sorted(set(q) ^ qs))
+        return
     d_ens = float(np.abs(ens - ens_o).max())
     d_dis = float(max(np.abs(a - b).max() for a, b in zip(dis, dis_o)))
     pct = np.percentile(ens_o[:, 0], [1, 99])
