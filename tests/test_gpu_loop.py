@@ -92,18 +92,27 @@ def test_loop_equals_reference_shaped_loop(gpu, col, tmp_path):
                                  pairs.getImposterGenerator(feats_plain, feats_plain, 8), 8)
         np.random.seed(5)                                      # balanced sampling + fit() shuffles
         if which == "library":
+            # the library loop on a default-built ArcFace goes through screen-then-settle (its feature model carries a screening
+            # form): the literal loop below embeds everything exactly — equal results are the point
+            from a_link_amd import settle
             sets = []
-            orig = AL.selection.select_queries
+            orig, orig_s = AL.selection.select_queries, settle.select_queries_settled
 
             def spy(*a, **k):
                 r = orig(*a, **k)
                 sets.append(list(r[0]))
                 return r
-            AL.selection.select_queries = spy
+
+            def spy_s(*a, **k):
+                r = orig_s(*a, **k)
+                sets.append(list(r[0]))
+                return r
+            AL.selection.select_queries, settle.select_queries_settled = spy, spy_s
             try:
                 st = AL.run_alink_dfw(flags, conv, bag, nz, student, X_plain, X_dig, gen, SIZE, col=col, verbose=0)
             finally:
-                AL.selection.select_queries = orig
+                AL.selection.select_queries, settle.select_queries_settled = orig, orig_s
+            assert st.settle_info, "the default feature model should have taken the screen-then-settle path"
             results.append((st.active_count, st.un_size, sets, st.finetunes, student.siamese_net.get_weights()))
             assert (tmp_path / "post.h5").exists()
         else:
