@@ -132,9 +132,11 @@ int alink_backbone_set_small_batch_split(alink_backbone_t* bb, int on);
 
 /* ALINK_DT_F16X2 (split precision) only.  The mode stores every activation as an f16 pair scaled by a power of two
  * per tensor, chosen so that the largest value a tensor takes on the calibration images lands in [1024, 2048) —
- * 32x below the f16 overflow threshold, lo halves far above the subnormals.  A power-of-two scale changes no bit of
- * any result (binary floating point), so embeddings do not depend on the calibration images: they only have to be
- * "like" later inputs within that 32x.  Synchronous; runs the n_images (<= what the workspace was sized for) through
+ * 32x below the f16 overflow threshold, the lo halves of values down to 2^-13 of it normal f16.  A power-of-two scale is
+ * exact for every value whose lo half stays normal; far smaller values (lo subnormal) round differently under another
+ * scale, so two calibrations move an embedding by ~2e-7 — far below the mode's own error (2e-6), not zero: embeddings are
+ * bit-reproducible for FIXED scales (alink_backbone_get_scales / set_scales carry them between processes, ranks and
+ * checkpoints).  The calibration images only have to be "like" later inputs within that 32x.  Synchronous; runs the n_images (<= what the workspace was sized for) through
  * the network layer by layer.  merge != 0 keeps every exponent at or below its current value (re-calibration after
  * alink_backbone_range_flag reported a batch that left the range).  Must run once before the first alink_embed. */
 int alink_backbone_calibrate(alink_backbone_t* bb, const void* dev_in, int layout, int n_images,
