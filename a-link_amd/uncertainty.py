@@ -134,3 +134,39 @@ def topk_device(scores, k, largest=True):
     _abi.check(lib.alink_topk(_abi.ptr(scores), P, int(k), 1 if largest else 0, _abi.ptr(idx), _abi.ptr(vals),
                               C.c_void_p(scratch.data_ptr() + off), _abi.current_stream(scores.device)), "alink_topk")
     return idx, vals
+
+
+# ---- screen-then-settle forms of the three samplers (round 4; a-link_amd/settle.py) -----------------------------------------
+def _sampling_settled(kind, largest, classifier, X_screen, exact_rows, n_instances, **settle_kw):
+    """The sampler's query_idx (as a set: the order inside the top-n is not contractual, reference code/uncertainty.py uses modAL's
+    argpartition) from SCREENED pair features, identical to the sampler run on exact features.
+
+    classifier   the pair scorer (`predict_proba([L, R])` -> (P, 2)); it is evaluated exactly — what is screened is its INPUT
+    X_screen     [L, R] pair features from the 16-bit screening mode of the feature model (`ArcFace.process_screen`)
+    exact_rows   f(sorted pair indices) -> [L, R] exact features of those pairs (re-embeds their images in the exact mode)
+    Pairs whose side of the n-th cut is uncertain under the measured screening error are settled, the rest keep their side."""
+    from . import settle as _settle
+    proba_s = np.asarray(classifier.predict_proba(X_screen))
+    if proba_s.shape[1] != 2:
+        raise ValueError("screen-then-settle sampling is built for two-class pair scorers (got %d classes)" % proba_s.shape[1])
+    score = {"uncertainty": _proba_uncertainty, "margin": _proba_margin, "entropy": _proba_entropy}[kind]
+    P = len(proba_s)
+
+    def exact_fn(rows):
+        pr = np.asarray(classifier.predict_proba(exact_rows(rows)))
+        return rows, pr[:, 0], score(pr).astype(np.float32)
+    vals, idx, info = _settle.settle_topk(proba_s[:, 0], score(proba_s).astype(np.float32), np.arange(P), P, exact_fn, n_instances,
+                                          kind=kind, largest=largest, **settle_kw)
+    return np.asarray(idx), info
+
+
+def uncertainty_sampling_settled(classifier, X_screen, exact_rows, n_instances=1, **settle_kw):
+    return _sampling_settled("uncertainty", True, classifier, X_screen, exact_rows, n_instances, **settle_kw)
+
+
+def margin_sampling_settled(classifier, X_screen, exact_rows, n_instances=1, **settle_kw):
+    return _sampling_settled("margin", False, classifier, X_screen, exact_rows, n_instances, **settle_kw)
+
+
+def entropy_sampling_settled(classifier, X_screen, exact_rows, n_instances=1, **settle_kw):
+    return _sampling_settled("entropy", True, classifier, X_screen, exact_rows, n_instances, **settle_kw)

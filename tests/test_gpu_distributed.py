@@ -260,3 +260,81 @@ def test_calibration_state_is_portable_across_ranks_and_processes(gpu, tmp_path)
     fm2 = siamese.ArcFace(size, "synthetic:r18:3", max_batch=16)
     assert fm2.maybeLoadCalibration(str(tmp_path / "scales.json")) and not fm2.maybeLoadCalibration(str(tmp_path / "absent.json"))
     assert np.array_equal(fm2.process(gallery), e1)
+
+
+def _settle_case():
+    """a small committee workload: 3 members ((1,1,1,1) nets at 32x32), 120 pool images of 12 identities x 16 gallery images"""
+    from a_link_amd import weights as W
+    rng = np.random.default_rng(4)
+    bases = rng.integers(40, 216, (12, 4, 4, 3)).repeat(8, axis=1).repeat(8, axis=2)
+    pool = np.clip(bases[np.arange(120) // 10] + rng.integers(-40, 41, (120, 32, 32, 3)), 0, 255).astype(np.uint8)
+    gallery = np.clip(bases[:12] + rng.integers(-40, 41, (12, 32, 32, 3)), 0, 255).astype(np.uint8)
+    params = [W.synthetic_ir_params((1, 1, 1, 1), size=(32, 32), seed=s, normalized=True) for s in (1, 2, 3)]
+    return pool, gallery, params
+
+
+def _settle_members(params, pool, gallery):
+    from a_link_amd.backbone import IRBackbone
+    from a_link_amd.head import DenseHead
+    exa, scr, heads = [], [], []
+    for m, p in enumerate(params):
+        e = IRBackbone(p, image_size=(32, 32), max_batch=64, dtype="f16x2")
+        e.calibrate(pool[:32])                                      # the SAME images on every rank: rank-consistent scales
+        exa.append(e)
+        scr.append(IRBackbone(p, image_size=(32, 32), max_batch=64, dtype="bf16"))
+        h = DenseHead(512, lr=0.1, seed=10 + m)
+        ws = h.get_weights()
+        ws[4] = ws[4] * np.float32(40.0)                            # spread the probabilities (a fresh head: 0.5 +- 0.02)
+        h.set_weights(ws)
+        heads.append(h)
+    return exa, scr, heads
+
+
+def _settle_worker(rank, world, port, path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import a_link_amd  # noqa: F401
+        from a_link_amd import distributed as D
+        pool, gallery, params = _settle_case()
+        exa, scr, heads = _settle_members(params, pool, gallery)
+        lo, hi = D.shard_range(len(pool), rank, world)
+        info = {}
+        v, i = D.committee_pool_topk_settled(scr, exa, heads, torch.from_numpy(pool[lo:hi]).cuda(), torch.from_numpy(gallery).cuda(),
+                                             64, shard_offset=lo, info=info)
+        np.savez(path % rank, v=v.cpu().numpy(), i=i.cpu().numpy(), settled=info["images_settled"], n=hi - lo, rounds=info["rounds"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_screen_then_settle_over_two_ranks_equals_single_process_exact(gpu, tmp_path):
+    """distributed.committee_pool_topk_settled with TWO ranks (two processes on one card, gloo carrying the candidate exchange
+    and the two scalars per round): both ranks return the scores, order and indices of the single-process all-exact pass."""
+    import socket
+    import torch.multiprocessing as mp
+    from a_link_amd import distributed as D
+    pool, gallery, params = _settle_case()
+    exa, scr, heads = _settle_members(params, pool, gallery)
+    want_v, want_i = D.committee_pool_topk(exa, heads, torch.from_numpy(pool).cuda(), torch.from_numpy(gallery).cuda(), 64, shard_offset=0)
+    only_screen = D.committee_pool_topk(scr, heads, torch.from_numpy(pool).cuda(), torch.from_numpy(gallery).cuda(), 64, shard_offset=0)[1]
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    path = str(tmp_path / "rank%d.npz")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_settle_worker, args=(r, 2, port, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    z = [np.load(path % r) for r in range(2)]
+    for r in range(2):
+        assert np.array_equal(z[r]["i"], want_i.cpu().numpy()) and np.array_equal(z[r]["v"], want_v.cpu().numpy()), r
+    print("two ranks: settled %d + %d of %d + %d images in %d rounds; screening alone differs in %d of 64"
+          % (z[0]["settled"], z[1]["settled"], z[0]["n"], z[1]["n"], z[0]["rounds"],
+             len(set(only_screen.cpu().numpy().tolist()) ^ set(want_i.cpu().numpy().tolist())) // 2))

@@ -211,3 +211,32 @@ def test_settle_topk_across_ranks_gloo(world):
     res = sorted(q.get(timeout=10) for _ in range(world))
     assert all(r[1] and r[2] for r in res), res
     assert sum(r[3] for r in res) < sum(r[4] for r in res)
+
+
+def test_settled_samplers_equal_the_reference_samplers_on_exact_features():
+    """uncertainty / margin / entropy sampling (reference code/uncertainty.py:133-217) from SCREENED pair features: the query
+    set equals the sampler's on exact features; only pairs near the n-th cut had their exact features asked for."""
+    from a_link_amd import uncertainty as U
+    rng = np.random.default_rng(3)
+    P, D, n = 3000, 8, 200
+    w = rng.normal(0, 1.5, D)
+
+    class Clf(object):
+        def predict_proba(self, X):
+            z = (np.abs(np.asarray(X[0], np.float64) - np.asarray(X[1], np.float64)) @ w) - 4.0
+            p = 1.0 / (1.0 + np.exp(-z))
+            return np.stack([p, 1 - p], 1).astype(np.float32)
+    L, R = rng.normal(0, 1, (P, D)).astype(np.float32), rng.normal(0, 1, (P, D)).astype(np.float32)
+    Ls = (L + rng.normal(0, 3e-4, L.shape)).astype(np.float32)          # the screening mode's features
+    Rs = (R + rng.normal(0, 3e-4, R.shape)).astype(np.float32)
+    clf = Clf()
+    for name in ("uncertainty", "margin", "entropy"):
+        asked = []
+
+        def exact_rows(rows):
+            asked.append(len(rows))
+            return [L[rows], R[rows]]
+        idx, info = getattr(U, name + "_sampling_settled")(clf, [Ls, Rs], exact_rows, n_instances=n)
+        want, _ = getattr(U, name + "_sampling")(clf, [L, R], n_instances=n)
+        assert set(idx.tolist()) == set(np.asarray(want).tolist()), name
+        assert sum(asked) < P // 2 and info["delta"] > 0
