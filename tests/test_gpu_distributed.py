@@ -281,7 +281,7 @@ def _settle_members(params, pool, gallery):
         e = IRBackbone(p, image_size=(32, 32), max_batch=64, dtype="f16x2")
         e.calibrate(pool[:32])                                      # the SAME images on every rank: rank-consistent scales
         exa.append(e)
-        scr.append(IRBackbone(p, image_size=(32, 32), max_batch=64, dtype="bf16"))
+        scr.append(IRBackbone(p, image_size=(32, 32), max_batch=64, dtype="f16"))
         h = DenseHead(512, lr=0.1, seed=10 + m)
         ws = h.get_weights()
         ws[4] = ws[4] * np.float32(40.0)                            # spread the probabilities (a fresh head: 0.5 +- 0.02)
@@ -304,7 +304,7 @@ def _settle_worker(rank, world, port, path):
         lo, hi = D.shard_range(len(pool), rank, world)
         info = {}
         v, i = D.committee_pool_topk_settled(scr, exa, heads, torch.from_numpy(pool[lo:hi]).cuda(), torch.from_numpy(gallery).cuda(),
-                                             64, shard_offset=lo, info=info)
+                                             64, shard_offset=lo, info=info, min_sample=8)
         np.savez(path % rank, v=v.cpu().numpy(), i=i.cpu().numpy(), settled=info["images_settled"], n=hi - lo, rounds=info["rounds"])
     finally:
         dist.destroy_process_group()
@@ -335,6 +335,7 @@ def test_screen_then_settle_over_two_ranks_equals_single_process_exact(gpu, tmp_
     z = [np.load(path % r) for r in range(2)]
     for r in range(2):
         assert np.array_equal(z[r]["i"], want_i.cpu().numpy()) and np.array_equal(z[r]["v"], want_v.cpu().numpy()), r
+    assert z[0]["settled"] + z[1]["settled"] < z[0]["n"] + z[1]["n"]                  # not the trivial "settle everything"
     print("two ranks: settled %d + %d of %d + %d images in %d rounds; screening alone differs in %d of 64"
           % (z[0]["settled"], z[1]["settled"], z[0]["n"], z[1]["n"], z[0]["rounds"],
              len(set(only_screen.cpu().numpy().tolist()) ^ set(want_i.cpu().numpy().tolist())) // 2))
