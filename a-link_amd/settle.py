@@ -218,18 +218,24 @@ def settle_topk(p_screen, score_screen, owner, n_owner, exact_fn, k, kind="entro
     img_settled = np.zeros(int(n_owner), bool)
     bound = ErrorBound(delta0, safety)
     rounds = 0
+    # a screened probability that is not finite (a 16-bit forward that left its range) says nothing: such a pair can be anywhere
+    unknown = ~np.isfinite(p_screen)
+    p_screen = np.where(unknown, 0.5, p_screen)
     while True:
         lo, hi = binary_score_interval(p_screen, bound.delta, kind)
+        lo = np.where(unknown, _NEG, lo)
+        hi = np.where(unknown, _POS, hi)
         lo = np.where(pair_settled, val, lo)
         hi = np.where(pair_settled, val, hi)
         in_T, need, _, a, b = topk_undetermined(lo, hi, k, largest, comm, base)
         if settle_selected:
             need = need | (in_T & ~pair_settled)
         mid = 0.5 * (a + b) if np.isfinite(a) and np.isfinite(b) else (a if np.isfinite(a) else (b if np.isfinite(b) else 0.0))
-        centre = 0.5 * (lo.astype(np.float64) + hi.astype(np.float64))
+        with np.errstate(invalid="ignore"):          # an unknown pair is (-inf, +inf): its distance to the cut counts as 0
+            centre = 0.5 * (lo.astype(np.float64) + hi.astype(np.float64))
         if not largest:
             centre = -centre
-        dist = np.abs(centre - mid)
+        dist = np.where(np.isfinite(centre), np.abs(centre - mid), 0.0)
         imgs = np.unique(owner[need])
         if rounds == 0 and len(imgs) < min(min_sample, int((~img_settled).sum())):
             # the mandatory first sample: the images owning the pairs nearest the cut, whatever delta0 claims
@@ -259,8 +265,12 @@ def settle_topk(p_screen, score_screen, owner, n_owner, exact_fn, k, kind="entro
         if len(imgs):
             pos, p_x, s_x = exact_fn(imgs)
             pos = np.asarray(pos, np.int64)
-            d_loc = float(np.abs(np.asarray(p_x, np.float64) - p_screen[pos]).max()) if len(pos) else 0.0
-            val[pos] = np.asarray(s_x, np.float32)
+            p_x, s_x = np.asarray(p_x, np.float64), np.asarray(s_x, np.float32)
+            if not (np.isfinite(p_x).all() and np.isfinite(s_x).all()):
+                raise RuntimeError("settle_topk: the exact mode returned a non-finite probability or score")
+            known = ~unknown[pos]
+            d_loc = float(np.abs(p_x[known] - p_screen[pos][known]).max()) if known.any() else 0.0
+            val[pos] = s_x
             pair_settled[pos] = True
             img_settled[imgs] = True
         bound.observe(float(comm.max([d_loc])[0]))

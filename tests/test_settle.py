@@ -240,3 +240,26 @@ def test_settled_samplers_equal_the_reference_samplers_on_exact_features():
         want, _ = getattr(U, name + "_sampling")(clf, [L, R], n_instances=n)
         assert set(idx.tolist()) == set(np.asarray(want).tolist()), name
         assert sum(asked) < P // 2 and info["delta"] > 0
+
+
+def test_settle_topk_non_finite_screened_probabilities_are_settled_not_trusted():
+    n, g, k = 200, 8, 40
+    p, ps, owner = _pool_case(9, n, g)
+    ps = ps.copy()
+    bad = np.random.default_rng(0).integers(0, n * g, 25)
+    ps[bad] = np.nan
+    s_scr = _exact_score32(np.where(np.isfinite(ps), ps, 0.5), "entropy")
+    s_scr[bad] = np.nan
+    seen = []
+
+    def exact_fn(imgs):
+        seen.extend(imgs.tolist())
+        pos = (imgs[:, None] * g + np.arange(g)).ravel()
+        return pos, p[pos], _exact_score32(p[pos], "entropy")
+    vals, idx, info = settle.settle_topk(ps, s_scr, owner, n, exact_fn, k, min_sample=8)
+    s = _exact_score32(p, "entropy")
+    assert np.array_equal(idx, np.lexsort((np.arange(n * g), -s))[:k]) and np.isfinite(vals).all()
+    assert set((bad // g).tolist()) <= set(seen)                    # every image that owns an unknown pair was re-embedded
+    with pytest.raises(RuntimeError):
+        settle.settle_topk(ps, s_scr, owner, n, lambda imgs: ((imgs[:, None] * g + np.arange(g)).ravel(), np.full(len(imgs) * g, np.nan),
+                                                              np.full(len(imgs) * g, np.nan, np.float32)), k)
