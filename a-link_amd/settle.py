@@ -318,7 +318,11 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
     n_noise = len(disguisedScreened)
     e = ens[:, col].astype(np.float32)
     dis = [np.array(d, np.float32, copy=True) for d in disguisedScreened]
+    for d in dis:                                          # placeholders for unknown rows until they are settled
+        d[~np.isfinite(d).all(axis=1)] = 0.5
     scr = [np.asarray(d)[:, col].astype(np.float64) for d in disguisedScreened]
+    unknown = [~np.isfinite(v) for v in scr]               # a non-finite screened prediction says nothing: such a row can be anywhere
+    scr = [np.where(u, 0.5, v) for u, v in zip(unknown, scr)]
     settled = [np.zeros(P, bool) for _ in range(n_noise)]
     notgrey = (e <= 0.5 - eps) | (e >= 0.5 + eps)
     K = int(P * disparity_ratio)
@@ -342,7 +346,11 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
         got = settle_many(todo) if settle_many is not None else [settle_fn(k, idx) for k, idx in todo]
         for (k, idx), px in zip(todo, got):
             px = np.asarray(px, np.float32)
-            state["d"] = max(state["d"], float(np.abs(px[:, col].astype(np.float64) - scr[k][idx]).max()))
+            if not np.isfinite(px).all():
+                raise RuntimeError("select_queries_settled: the exact mode returned a non-finite prediction")
+            known = ~unknown[k][idx]
+            if known.any():
+                state["d"] = max(state["d"], float(np.abs(px[known, col].astype(np.float64) - scr[k][idx][known]).max()))
             dis[k][idx] = px
             settled[k][idx] = True
             n_settled += len(idx)
@@ -355,16 +363,19 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
             m = dis[k][:, col]
             if blind_strategy:
                 mem = (m >= 0.5) != (e >= 0.5)
-                und = ~settled[k] & (np.abs(scr[k] - 0.5) <= bound.delta + DIFF_GUARD)
+                und = ~settled[k] & ((np.abs(scr[k] - 0.5) <= bound.delta + DIFF_GUARD) | unknown[k])
                 out.append((mem, und, und, None, None, np.abs(scr[k] - 0.5)))
                 continue
             d_exact = np.abs(m - e)                                   # float32, the exact path's own expression
             lo, hi = _disparity_interval(scr[k], e, bound.delta)
+            lo, hi = np.where(unknown[k], np.float32(0), lo), np.where(unknown[k], _POS, hi)
             lo = np.where(settled[k], d_exact, lo)
             hi = np.where(settled[k], d_exact, hi)
             in_T, need, und, a, b = topk_undetermined(lo, hi, K, largest=True)
             mid = 0.5 * (a + b) if np.isfinite(a) and np.isfinite(b) else 0.0
-            out.append((in_T, need, und, lo, hi, np.abs(0.5 * (lo.astype(np.float64) + hi) - mid)))
+            with np.errstate(invalid="ignore"):
+                centre = 0.5 * (lo.astype(np.float64) + hi)
+            out.append((in_T, need, und, lo, hi, np.where(np.isfinite(centre), np.abs(centre - mid), 0.0)))
         return out
 
     while True:

@@ -263,3 +263,20 @@ def test_settle_topk_non_finite_screened_probabilities_are_settled_not_trusted()
     with pytest.raises(RuntimeError):
         settle.settle_topk(ps, s_scr, owner, n, lambda imgs: ((imgs[:, None] * g + np.arange(g)).ravel(), np.full(len(imgs) * g, np.nan),
                                                               np.full(len(imgs) * g, np.nan, np.float32)), k)
+
+
+def test_select_queries_settled_non_finite_screened_rows_are_settled_not_trusted():
+    ens, dis, scr, y = _rule_case(8, P=1500)
+    scr = [s.copy() for s in scr]
+    rng = np.random.default_rng(1)
+    bad = [rng.integers(0, 1500, 12) for _ in scr]
+    for s, b in zip(scr, bad):
+        s[b] = np.nan
+    asked = [set() for _ in scr]
+
+    def settle_fn(k, idx):
+        asked[k].update(idx.tolist())
+        return dis[k][idx]
+    q, active, labels, _, settled, _ = settle.select_queries_settled(ens, scr, y, settle_fn)
+    q0, active0, labels0 = selection.select_queries(ens, dis, y)
+    assert q == q0 and active == active0 and np.array_equal(labels, labels0)
