@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 leg (one A-LINK iteration, IR-100 teacher: all-exact and screen-then-settle)")
     ap.add_argument("--no-configs1", action="store_true", help="skip the configs[1] leg (IR-50, one 256-image batch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strict", action="store_true", help="make the identity checks of the screen-then-settle legs fatal instead of reported")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile / fine-tune timing")
     ap.add_argument("--select-dtype", default="f16x2", choices=["f16x2", "f32", "none"], help="the exact-selection leg: the same "
                     "workload in the mode whose active-learning selection sets equal the f32 arithmetic's (DESIGN.md §5), reported "
@@ -519,9 +520,10 @@ def main():
         inf3b = {}
         t_set, (_v, sei) = _timed(lambda: D.committee_pool_topk_settled(scr, exa, hds, shard, gal, k3, lo_, settle_selected=False,
                                                                          info=inf3b), 1, barrier, dist)
+        # checked in the run and REPORTED (a line that says "false" is worth more than no line); --strict makes them fatal
         identical = bool(torch.equal(ssi, xi) and torch.equal(ssv, xv))
-        assert identical, "screen-then-settle returned a different selection than the all-exact pass"
-        assert set(sei.cpu().numpy().tolist()) == set(xi.cpu().numpy().tolist())
+        same_set = set(sei.cpu().numpy().tolist()) == set(xi.cpu().numpy().tolist())
+        assert (identical and same_set) or not args.strict, "screen-then-settle returned a different selection than the all-exact pass"
         pool_n = world * n_shard
         line["config3"] = {
             "workload": "committee of 3 IR-50 (BatchNorm statistics matching the activations) + 3 heads (last layer rescaled: "
@@ -535,11 +537,13 @@ def main():
             "screen_settle": {"pool_images_per_s": pool_n / t_ss, "ms_per_pass": 1e3 * t_ss,
                               "fraction_re_embedded": inf3["fraction_re_embedded"], "rounds": inf3["rounds"],
                               "delta": inf3["delta"], "largest_dp_seen": inf3["d_max"], "widened": inf3["widened"],
-                              "identical_to_exact_all": "scores, order and indices bit for bit (asserted in this run)",
+                              "identical_to_exact_all": identical,
+                              "identical_means": "scores, order and indices of the top-%d equal the all-exact pass's bit for bit (compared in this run)" % k3,
                               "speedup_over_exact_all": t_x / t_ss},
             "screen_settle_set_only": {"pool_images_per_s": pool_n / t_set, "ms_per_pass": 1e3 * t_set,
                                        "fraction_re_embedded": inf3b["fraction_re_embedded"],
-                                       "note": "members certain by interval keep their screened score: same SET (asserted), no exact scores for them"},
+                                       "same_set_as_exact_all": same_set,
+                                       "note": "members certain by interval keep their screened score: same SET (compared in this run), no exact scores for them"},
             "backbone_forwards_per_s_exact_all": 3 * world * (n_shard + 16) / t_x,
             "selected": int(xi.numel())}
         del exa, scr, hds, shard, cal
@@ -629,7 +633,7 @@ def main():
         (t_e, st_e, w_e, _), (t_q, st_q, w_q, sdt) = res4["exact_all"], res4["screen_settle"]
         same4 = (st_e.active_count == st_q.active_count and st_e.finetunes == st_q.finetunes and st_e.un_size == st_q.un_size
                  and all(np.array_equal(a_, b_) for a_, b_ in zip(w_e, w_q)))
-        assert same4, "screen-then-settle A-LINK iteration differs from the all-exact one"
+        assert same4 or not args.strict, "screen-then-settle A-LINK iteration differs from the all-exact one"
         P4 = st_e.un_size
         n_emb = 80 + 2 * P4 * len(names)
         g100 = ir_resnet.flops_per_image(W.ARCH_UNITS["r100"]) / 1e9
@@ -643,7 +647,8 @@ def main():
                               "fraction_pair_noise_rows_settled": inf4["fraction_settled"], "rounds": inf4["rounds"], "delta": inf4["delta"],
                               "tflops_algorithmic": n_emb / t_q * g100 / 1e3, "frac_mfma_peak": n_emb / t_q * g100 / 1e3 / MFMA_PEAK_TFLOPS,
                               "speedup_over_exact_all": t_e / t_q,
-                              "identical_to_exact_all": "oracle-query count, fine-tunes and the student's weights afterwards bit for bit (asserted in this run)"},
+                              "identical_to_exact_all": bool(same4),
+                              "identical_means": "oracle-query count, number of fine-tunes and the student's weights afterwards equal the all-exact iteration's bit for bit (compared in this run)"},
             "oracle_queries": st_e.active_count, "finetunes": st_e.finetunes,
             "note": "whole iteration on the wall clock: noise kernels, embeddings, heads, host-side selection, fine-tune"}
 
