@@ -186,6 +186,9 @@ int        linear_variant_cpl(int v);
 hipError_t linear_set_attributes();
 hipError_t linear_check_contract();   // probes the LDS out-of-range read contract; disables the linear kernel if it fails
 hipError_t launch_conv3x3_linear(int variant, int dtype, const ConvParams& p, hipStream_t st);
+// conv3x3_lat.hip: the latency form for launches of a handful of images (one wave per 32 x 32 output block, operands straight from L2)
+bool       conv3x3_lat_applies(int dtype, const ConvParams& p);
+hipError_t launch_conv3x3_lat(int dtype, const ConvParams& p, hipStream_t stream);
 
 // backward.hip (input-gradient pass)
 hipError_t launch_l2norm_bwd(int dtype, const float* g, const float* e, const float* norms, void* dz, int M, int E,

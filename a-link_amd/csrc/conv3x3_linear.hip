@@ -653,6 +653,8 @@ hipError_t linear_set_attributes() {
 
 hipError_t launch_conv3x3_linear(int variant, int dtype, const ConvParams& p, hipStream_t st) {
     if (p.ksz != 3 || p.stride != 1 || p.pad != 1 || p.H != p.W) return hipErrorInvalidValue;
+    // a handful of images: the latency form (same packed weights, same sums in the same order: bit-identical)
+    if (conv3x3_lat_applies(dtype, p)) return launch_conv3x3_lat(dtype, p, st);
     if (p.splitk < 1 || (p.Cin / 64) % p.splitk) return hipErrorInvalidValue;      // whole chunks per split
     if ((long long)p.N * p.H * p.W * p.Cin * (dtype == ALINK_DT_F16X2 ? 2 : 1) >= (1ll << 31)) return hipErrorInvalidValue;
 #define L(W_, TCW_) (dtype == ALINK_DT_BF16 ? launch_one<__bf16, W_, TCW_>(p, st) : (dtype == ALINK_DT_F16X2 ? launch_one<_Float16, W_, TCW_, true>(p, st) : launch_one<_Float16, W_, TCW_>(p, st)))

@@ -556,3 +556,40 @@ def test_one_product_screening_form_of_the_split_precision_handle(gpu):
         IRBackbone(params, image_size=size, max_batch=16, dtype="bf16").set_products(1)
     with pytest.raises(_abi.AlinkError):
         bb.set_products(2)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x2"])
+def test_latency_form_of_small_launches_is_bit_identical_to_the_tile_kernels(gpu, dtype):
+    """conv3x3_lat.hip: launches of a handful of images run the 3x3 stride-1 convolutions one WAVE per 16-pixel x 16/32-channel
+    block, operands straight from L2 with 18 K-sub-steps in flight, no LDS and no barrier (FaceModel.get_feature, reference
+    code/face_model.py:86-93, is a batch-1 call: 2.07 -> 1.01 ms in bf16, 6.05 -> 2.91 ms in split precision).  Every output is the
+    same sum in the same order, and the same epilogue operations, as in the tile kernels: embeddings of 1 / 2 / 3 / 4 / 5 images —
+    both block shapes, partial pixel tiles, every border class, PReLU and residual epilogues, 28-, 14- and 7-wide layers — equal
+    the tile kernels' bit for bit, equal their rows of a 292-image batch, and so does the one-product screening form."""
+    from a_link_amd import _abi, weights as W
+    from a_link_amd.backbone import IRBackbone
+    lib = _abi.load()
+    params = W.synthetic_ir_params((1, 2, 2, 2), seed=9, normalized=True)
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, 256, (300, 112, 112, 3), dtype=np.uint8)
+    bb = IRBackbone(params, dtype=dtype, max_batch=292)
+    big = bb.embed(x)                                              # 292 + 8 images: the tile kernels' throughput forms
+    views = [("exact", bb)] + ([("one product", bb.screening_view())] if dtype == "f16x2" else [])
+    try:
+        for name, m in views:
+            ref_big = m.embed(x) if name != "exact" else big
+            for n in (1, 2, 3, 4, 5):
+                lib.alink_debug_set_latency_form(784)
+                lat = m.embed(x[:n])
+                lib.alink_debug_set_latency_form(0)
+                tile = m.embed(x[:n])
+                assert np.array_equal(lat, tile), (dtype, name, n, np.abs(lat - tile).max())
+                assert np.array_equal(lat, ref_big[:n]), (dtype, name, n)
+            for form in (0, 1, 2):                                 # each block shape alone, 3 images
+                lib.alink_debug_set_latency_form(784)
+                lib.alink_debug_set_latency_tiles(form)
+                assert np.array_equal(m.embed(x[:3]), ref_big[:3]), (dtype, name, form)
+                lib.alink_debug_set_latency_tiles(-1)
+    finally:
+        lib.alink_debug_set_latency_form(784)
+        lib.alink_debug_set_latency_tiles(-1)
