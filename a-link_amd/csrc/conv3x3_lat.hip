@@ -12,15 +12,16 @@
 //     consecutive k of the packed weight tensor the tile kernels read ([cout'][chunk][tap][64], split precision
 //     [chunk][hi 9 x 64 | lo 9 x 64]), the B fragment 16 pixels x 8 channels of the NHWC activation at the tap's shift (a lane
 //     whose tap falls outside the image reads the zero page instead);
-//   * EIGHTEEN K-sub-steps of loads are in flight (a ring of register sets: 36-54 loads of 1 KiB), the compiler's counted waits
-//     order them: a sub-step costs max(its MFMAs, an L2 round trip / 18), not a round trip;
+//   * EIGHTEEN K-sub-steps of loads are in flight (a ring of register sets: 36-72 loads of 1 KiB), the compiler's counted waits
+//     order them, and a sub-step is nothing but its loads and MFMAs (addresses: a VGPR set up once + an SGPR per 18 sub-steps + the
+//     instruction's immediate; zero padding by the buffer descriptor's range check);
 //   * no LDS, no barrier, no workgroup: 208 independent waves for a 14 x 14 x 256 layer, 392 at 28 wide, spread over the chip.
 // Every output is the SAME sum in the SAME order as in conv3x3_linear (chunk, [product phase,] tap, k half; the same 8-channel
 // slices on the same MFMA k positions; a border tap adds the same zeros) and the epilogue is the same sequence of float
 // operations, so the result is bit-identical to the tile kernels' — asserted by every batch-1-equals-in-batch test of the suite.
 // Traffic grows with the batch (each wave re-reads its weight rows and pixels through L2: ~90 MB per image and stage-3 layer),
 // so the form is used for launches of at most g_lat_max_pixels output pixels (four 14 x 14 maps); above, the tile kernels.
-// Measured (IR-100, one image): 2.07 -> 1.01 ms in bf16, 6.05 -> 2.91 ms in split precision, embeddings unchanged bit for bit.
+// Measured (IR-100, one image): 2.07 -> 1.04 ms in bf16, 6.05 -> 2.28 ms in split precision, embeddings unchanged bit for bit.
 #include "alink_common.h"
 
 namespace alink {
@@ -41,13 +42,25 @@ __device__ __forceinline__ f32x4 mfma16<_Float16>(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// TA x TB MFMA tiles per wave (TA: 16-channel tiles of one 32-channel block of the packed weights, TB: 16-pixel tiles); DEPTH
-// K-sub-steps of operand loads in flight (a ring of register sets; 18 sub-steps per chunk and phase, so 6, 9 and 18 divide every
-// walk).  A wave's step costs max(its TA x TB MFMAs, the L2 round trip / DEPTH): small blocks and a deep ring for a lone image.
-// SP: split precision (T = _Float16): NP product phases per chunk — 3 (hi x W_hi, hi x W_lo, lo x W_hi) or 1 (the screening form)
-template <typename T, bool SP, int NP, int TA, int TB, int DEPTH>
+// TA x TB MFMA tiles per wave (TA: 16-channel tiles of one 32-channel block of the packed weights, TB: 16-pixel tiles).
+// SP: split precision (T = _Float16): NP product phases per chunk — 3 (hi x W_hi, hi x W_lo, lo x W_hi) or 1 (the screening form).
+//
+// The walk is the tile kernels': for every chunk, [phase,] tap, k half.  One ITERATION = the 18 sub-steps (tap, k half) of a
+// (chunk, phase); its operand loads are issued one whole iteration ahead into a ring of 18 register sets, so 18 sub-steps (36-54
+// loads of 1 KiB) are always in flight.  A lone wave per SIMD issues in order, so what a sub-step COSTS is its instructions: the
+// first form of this kernel computed every address in vector registers (~20 VALU per sub-step = ~80 cycles against one 16-cycle
+// MFMA).  Here a sub-step is TA + TB buffer loads and TA x TB MFMAs and nothing else:
+//   * weights: one buffer descriptor over the packed tensor, the lane's row offset in a VGPR for the whole kernel, the iteration's
+//     (chunk, phase) offset in an SGPR, the sub-step's (tap, k half) in the instruction's immediate;
+//   * pixels: one descriptor PER TAP whose base is the activation shifted by the tap ((ky - 1) W + kx - 1 pixels), the lane's pixel
+//     offset in a VGPR per tap — or an offset beyond the descriptor's range where the tap leaves the image: the load then returns
+//     zeros without touching memory (the zero padding) —, the iteration's chunk / half offset in an SGPR, the k half in the immediate.
+template <typename T, bool SP, int NP, int TA, int TB>
 __global__ __launch_bounds__(64) void conv3x3_lat_kernel(const ConvParams p) {
     typedef typename Vec8<T>::type vec8;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    constexpr unsigned RSRC3 = 0x00020000u;                   // raw buffer, 32-bit data format (gfx9 family)
+    constexpr unsigned OOB = 0x80000000u;                      // beyond every descriptor's num_records (< 2^31), and no immediate wraps it
     const int lane = threadIdx.x;
     const int q = lane >> 4, lr = lane & 15;
     const int H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
@@ -57,16 +70,14 @@ __global__ __launch_bounds__(64) void conv3x3_lat_kernel(const ConvParams p) {
     const int ncb = Cout / (16 * TA);                         // channel blocks of this launch
     const int cb = (int)blockIdx.x % ncb, bp = (int)blockIdx.x / ncb;
     const long long totpix = (long long)p.N * H * W;
+    const unsigned xbytes = (unsigned)(totpix * CinP * 2), wbytes = (unsigned)((long long)Cout * K * 2);   // < 2^31: the launcher checks
 
-    const T* __restrict__ gin = (const T*)p.in;
-    const T* __restrict__ gw = (const T*)p.wgt;
-    const T* __restrict__ gz = (const T*)p.zero;
-
-    // ---- this lane's pixels (tile u, column lr), their image coordinates and the taps that stay inside the image ----
+    // ---- this lane's pixels (tile u, column lr), their image coordinates, and per tap the byte offset of its 8-channel slice
+    // or OOB where the tap leaves the image ----
     long long pix[TB];
     bool okp[TB];
-    unsigned inside[TB];
-    int py[TB], px[TB], xoff[TB];
+    int py[TB], px[TB];
+    unsigned vox[TB][9];
 #pragma unroll
     for (int u = 0; u < TB; ++u) {
         pix[u] = (long long)bp * (16 * TB) + 16 * u + lr;
@@ -75,36 +86,50 @@ __global__ __launch_bounds__(64) void conv3x3_lat_kernel(const ConvParams p) {
         const int rem = (int)(pc % ((long long)H * W));
         py[u] = rem / W;
         px[u] = rem - py[u] * W;
-        unsigned m = 0;
-        for (int ky = 0; ky < 3; ++ky)
-            for (int kx = 0; kx < 3; ++kx)
-                if (okp[u] && (unsigned)(py[u] + ky - 1) < (unsigned)H && (unsigned)(px[u] + kx - 1) < (unsigned)W) m |= 1u << (ky * 3 + kx);
-        inside[u] = m;
         pix[u] = pc;
-        xoff[u] = (int)(pc * CinP) + q * 8;                   // element offsets fit 32 bits: the launcher checks
+        const unsigned off = (unsigned)((pc * CinP + q * 8) * 2);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const bool in = okp[u] && (unsigned)(py[u] + ky - 1) < (unsigned)H && (unsigned)(px[u] + kx - 1) < (unsigned)W;
+            vox[u][tap] = in ? off : OOB;
+        }
     }
     // packed weight rows: 32-channel block b holds rows 32 b + 16 t + 4 q' + j  <->  channel 32 b + 8 q' + 4 t + j
     const int row0 = TA == 2 ? cb * 32 : (cb >> 1) * 32 + (cb & 1) * 16;
-    const int woff = (row0 + lr) * K + q * 8;
+    unsigned vow[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) vow[t] = (unsigned)(((row0 + 16 * t + lr) * K + q * 8) * 2);
 
-    // ---- the walk: S = ((cc * NPH + ph) * 9 + tap) * 2 + ks, the tile kernels' order --------------------------------------------
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, (int)wbytes, RSRC3);
+    __amdgpu_buffer_rsrc_t rx[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const long long shift = ((long long)(tap / 3 - 1) * W + (tap % 3 - 1)) * CinP * 2;
+        rx[tap] = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.in + shift), 0, (int)xbytes, RSRC3);
+    }
+
     constexpr int NPH = SP ? NP : 1;
-    const int total = ncc * NPH * 18;
+    const int iters = ncc * NPH;
+    // scalar byte offsets of iteration `it`: weights [chunk][tap][64] (split precision [chunk][hi 9 x 64 | lo 9 x 64], W_lo in
+    // phase 1); pixels: the chunk's 64 channels (split precision: its hi half, its lo half in phase 2)
+    auto s_w = [&](int it) { const int cc = it / NPH, ph = it - cc * NPH; return (SP ? (cc * 18 + (ph == 1 ? 9 : 0)) : cc * 9) * 128; };
+    auto s_x = [&](int it) { const int cc = it / NPH, ph = it - cc * NPH; return (SP ? 2 * cc + (ph == 2 ? 1 : 0) : cc) * 128; };
+
     struct Frag { vec8 a[TA], b[TB]; };
-    auto fetch = [&](int S) -> Frag {
-        const int ks = S & 1, t9 = S >> 1;
-        const int tap = t9 % 9, cp = t9 / 9;
-        const int ph = SP ? cp % NPH : 0, cc = SP ? cp / NPH : cp;
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        // weights: 16-bit [chunk][tap][64]; split precision [chunk][hi: 9 x 64 | lo: 9 x 64], W_lo in phase 1
-        const int wk = SP ? (cc * 18 + (ph == 1 ? 9 : 0) + tap) * 64 + ks * 32 : (cc * 9 + tap) * 64 + ks * 32;
-        // pixels: the chunk's 64 channels (split precision: its hi half, or its lo half in phase 2) at the tap's shift
-        const int xk = ((ky - 1) * W + (kx - 1)) * CinP + (SP ? (2 * cc + (ph == 2 ? 1 : 0)) * 64 : cc * 64) + ks * 32;
+    auto fetch = [&](int sub, int sw, int sx) -> Frag {       // sub = tap * 2 + ks: a compile-time constant after unrolling
+        const int tap = sub >> 1, ks = sub & 1;
         Frag f;
 #pragma unroll
-        for (int t = 0; t < TA; ++t) f.a[t] = *(const vec8*)(gw + (woff + 16 * t * K + wk));
+        for (int t = 0; t < TA; ++t) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, vow[t] + (unsigned)(tap * 128 + ks * 64), sw, 0);
+            __builtin_memcpy(&f.a[t], &v, 16);
+        }
 #pragma unroll
-        for (int u = 0; u < TB; ++u) f.b[u] = *(const vec8*)(((inside[u] >> tap) & 1u) ? gin + (xoff[u] + xk) : gz + q * 8);
+        for (int u = 0; u < TB; ++u) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx[tap], vox[u][tap] + (unsigned)(ks * 64), sx, 0);
+            __builtin_memcpy(&f.b[u], &v, 16);
+        }
         return f;
     };
 
@@ -114,14 +139,19 @@ __global__ __launch_bounds__(64) void conv3x3_lat_kernel(const ConvParams p) {
 #pragma unroll
         for (int u = 0; u < TB; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    Frag ring[DEPTH];
+    Frag ring[18];
+    {
+        const int sw = s_w(0), sx = s_x(0);
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) ring[d] = fetch(d);       // total >= 36 > DEPTH
-    for (int S0 = 0; S0 < total; S0 += DEPTH) {
+        for (int d = 0; d < 18; ++d) ring[d] = fetch(d, sw, sx);
+    }
+    for (int it = 0; it < iters; ++it) {
+        const bool more = it + 1 < iters;
+        const int sw = more ? s_w(it + 1) : 0, sx = more ? s_x(it + 1) : 0;
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
+        for (int d = 0; d < 18; ++d) {
             const Frag f = ring[d];
-            if (S0 + d + DEPTH < total) ring[d] = fetch(S0 + d + DEPTH);
+            if (more) ring[d] = fetch(d, sw, sx);
 #pragma unroll
             for (int t = 0; t < TA; ++t)
 #pragma unroll
@@ -189,7 +219,7 @@ __global__ __launch_bounds__(64) void conv3x3_lat_kernel(const ConvParams p) {
 
 // launches of at most this many output pixels take the latency form (0 = never).  784 = four 14 x 14 maps, one 28 x 28 map.
 int g_lat_max_pixels = 784;
-int g_lat_form = -1;              // A/B (alink_debug_set_latency_tiles): -1 = by size (below); 0 = 1x1 tiles, ring 18; 1 = 2x1, 18; 2 = 2x2, 9; 3 = 2x2, 6
+int g_lat_form = -1;              // A/B (alink_debug_set_latency_tiles): -1 = by size (below); 0 = 1 x 1 MFMA tiles per wave; 1 = 2 x 1; 2 = 2 x 2
 
 }  // namespace
 
@@ -200,36 +230,35 @@ bool conv3x3_lat_applies(int dtype, const ConvParams& p) {
     if (g_lat_max_pixels <= 0 || p.ksz != 3 || p.stride != 1 || p.pad != 1 || p.splitk != 1 || p.dact || p.stamps || p.in2) return false;
     if (p.Cin % 64 || p.Cout % 32 || p.Cin < 128) return false;                 // the 64-channel layers are HBM-shaped, not K walks
     if ((long long)p.N * p.H * p.W > g_lat_max_pixels) return false;
-    if ((long long)p.N * p.H * p.W * p.Cin * (dtype == ALINK_DT_F16X2 ? 2 : 1) >= (1ll << 31)) return false;
-    if ((long long)p.Cout * 9 * p.Cin * (dtype == ALINK_DT_F16X2 ? 2 : 1) >= (1ll << 31)) return false;
+    if ((long long)p.N * p.H * p.W * p.Cin * (dtype == ALINK_DT_F16X2 ? 4 : 2) >= (1ll << 31)) return false;       // byte offsets in 31 bits
+    if ((long long)p.Cout * 9 * p.Cin * (dtype == ALINK_DT_F16X2 ? 4 : 2) >= (1ll << 31)) return false;
     return dtype == ALINK_DT_BF16 || dtype == ALINK_DT_F16 || dtype == ALINK_DT_F16X2;
 }
 
 namespace {
-template <int TA, int TB, int D>
+template <int TA, int TB>
 hipError_t launch_form(int dtype, const ConvParams& p, hipStream_t st) {
     const long long totpix = (long long)p.N * p.H * p.W;
     const unsigned grid = (unsigned)(((totpix + 16 * TB - 1) / (16 * TB)) * (p.Cout / (16 * TA)));
-    if (dtype == ALINK_DT_BF16)       hipLaunchKernelGGL((conv3x3_lat_kernel<__bf16, false, 1, TA, TB, D>), dim3(grid), dim3(64), 0, st, p);
-    else if (dtype == ALINK_DT_F16)   hipLaunchKernelGGL((conv3x3_lat_kernel<_Float16, false, 1, TA, TB, D>), dim3(grid), dim3(64), 0, st, p);
-    else if (p.nprod == 1)            hipLaunchKernelGGL((conv3x3_lat_kernel<_Float16, true, 1, TA, TB, D>), dim3(grid), dim3(64), 0, st, p);
-    else                              hipLaunchKernelGGL((conv3x3_lat_kernel<_Float16, true, 3, TA, TB, D>), dim3(grid), dim3(64), 0, st, p);
+    if (dtype == ALINK_DT_BF16)       hipLaunchKernelGGL((conv3x3_lat_kernel<__bf16, false, 1, TA, TB>), dim3(grid), dim3(64), 0, st, p);
+    else if (dtype == ALINK_DT_F16)   hipLaunchKernelGGL((conv3x3_lat_kernel<_Float16, false, 1, TA, TB>), dim3(grid), dim3(64), 0, st, p);
+    else if (p.nprod == 1)            hipLaunchKernelGGL((conv3x3_lat_kernel<_Float16, true, 1, TA, TB>), dim3(grid), dim3(64), 0, st, p);
+    else                              hipLaunchKernelGGL((conv3x3_lat_kernel<_Float16, true, 3, TA, TB>), dim3(grid), dim3(64), 0, st, p);
     return hipGetLastError();
 }
 }  // namespace
 
 hipError_t launch_conv3x3_lat(int dtype, const ConvParams& p, hipStream_t st) {
-    // By size: 16 x 16 blocks (one MFMA per sub-step, 36 loads in flight) while that makes at most 448 waves — a lone 14 x 14 x
-    // 256 map is 208 of them, each bounded by its L2 round trips / 18 —, 32-channel blocks above (half the pixel traffic per MFMA).
-    // Measured, IR-100, forward of n images in bf16 / split precision (tile kernels 2.07 / 6.05 ms whatever n <= 4):
-    //   n = 1: 1.01 / 2.91 ms with 16 x 16 blocks, 1.13 / 3.20 with 32-channel blocks;  n = 4: 1.78 / 4.57 against 1.64 / 4.20.
+    // By size: 16 x 16 blocks (one MFMA per sub-step) while that makes at most 448 waves — a lone 14 x 14 x 256 map is 208 —, 32 x 32
+    // blocks above (half the loads per MFMA).  Measured, IR-100, forward of n images in bf16 / split precision (tile kernels: 2.07-2.10 /
+    // 6.02-6.09 ms for n <= 4): n = 1: 1.04 / 2.28 ms with 16 x 16 blocks, 1.51 / 3.39 with 32 x 32; n = 2: 1.38 / 3.15 against 1.59 /
+    // 3.74; n = 4: 1.77 / 4.48 against 1.60 / 3.82.
     int form = g_lat_form;
-    if (form < 0) form = ((long long)p.N * p.H * p.W + 15) / 16 * (p.Cout / 16) <= 448 ? 0 : 1;
+    if (form < 0) form = ((long long)p.N * p.H * p.W + 15) / 16 * (p.Cout / 16) <= 448 ? 0 : 2;
     switch (form) {
-        case 1: return launch_form<2, 1, 18>(dtype, p, st);
-        case 2: return launch_form<2, 2, 9>(dtype, p, st);
-        case 3: return launch_form<2, 2, 6>(dtype, p, st);
-        default: return launch_form<1, 1, 18>(dtype, p, st);
+        case 1: return launch_form<2, 1>(dtype, p, st);
+        case 2: return launch_form<2, 2>(dtype, p, st);
+        default: return launch_form<1, 1>(dtype, p, st);
     }
 }
 

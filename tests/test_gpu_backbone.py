@@ -561,8 +561,8 @@ def test_one_product_screening_form_of_the_split_precision_handle(gpu):
 @pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x2"])
 def test_latency_form_of_small_launches_is_bit_identical_to_the_tile_kernels(gpu, dtype):
     """conv3x3_lat.hip: launches of a handful of images run the 3x3 stride-1 convolutions one WAVE per 16-pixel x 16/32-channel
-    block, operands straight from L2 with 18 K-sub-steps in flight, no LDS and no barrier (FaceModel.get_feature, reference
-    code/face_model.py:86-93, is a batch-1 call: 2.07 -> 1.01 ms in bf16, 6.05 -> 2.91 ms in split precision).  Every output is the
+    block, operands straight from L2 by buffer loads with 18 K-sub-steps in flight, no LDS and no barrier (FaceModel.get_feature, reference
+    code/face_model.py:86-93, is a batch-1 call: 2.07 -> 1.04 ms in bf16, 6.05 -> 2.28 ms in split precision).  Every output is the
     same sum in the same order, and the same epilogue operations, as in the tile kernels: embeddings of 1 / 2 / 3 / 4 / 5 images —
     both block shapes, partial pixel tiles, every border class, PReLU and residual epilogues, 28-, 14- and 7-wide layers — equal
     the tile kernels' bit for bit, equal their rows of a 292-image batch, and so does the one-product screening form."""

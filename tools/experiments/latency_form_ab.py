@@ -10,7 +10,7 @@ from a_link_amd.backbone import IRBackbone
 lib = _abi.load()
 params = W.synthetic_ir_params(W.ARCH_UNITS["r100"], seed=1, normalized=True)
 limits = [784]
-forms = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3]
+forms = [int(a) for a in sys.argv[1:]] or [0, 1, 2]
 for dt in ("bf16", "f16x2"):
     bb = IRBackbone(params, dtype=dt, max_batch=292)
     for n in (1, 2, 4, 8, 16):
