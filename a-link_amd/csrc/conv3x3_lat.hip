@@ -55,7 +55,7 @@ __device__ __forceinline__ f32x4 mfma16<_Float16>(f16x8 a, f16x8 b, f32x4 c) {
 //   * pixels: one descriptor PER TAP whose base is the activation shifted by the tap ((ky - 1) W + kx - 1 pixels), the lane's pixel
 //     offset in a VGPR per tap — or an offset beyond the descriptor's range where the tap leaves the image: the load then returns
 //     zeros without touching memory (the zero padding) —, the iteration's chunk / half offset in an SGPR, the k half in the immediate.
-template <typename T, bool SP, int NP, int TA, int TB>
+template <typename T, bool SP, int NP, int TA, int TB, int AHEAD = 1>
 __global__ __launch_bounds__(64) void conv3x3_lat_kernel(const ConvParams p) {
     typedef typename Vec8<T>::type vec8;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -139,23 +139,34 @@ __global__ __launch_bounds__(64) void conv3x3_lat_kernel(const ConvParams p) {
 #pragma unroll
         for (int u = 0; u < TB; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    Frag ring[18];
-    {
-        const int sw = s_w(0), sx = s_x(0);
+    // AHEAD whole iterations of loads in flight: 18 x AHEAD sub-steps (AHEAD = 2 where the registers allow: a layer's weights come
+    // from DRAM once per forward and 18 round trips in flight do not cover a 16-cycle MFMA step)
+    Frag ring[18 * AHEAD];
 #pragma unroll
-        for (int d = 0; d < 18; ++d) ring[d] = fetch(d, sw, sx);
+    for (int a = 0; a < AHEAD; ++a) {
+        if (a < iters) {
+            const int sw = s_w(a), sx = s_x(a);
+#pragma unroll
+            for (int d = 0; d < 18; ++d) ring[a * 18 + d] = fetch(d, sw, sx);
+        }
     }
-    for (int it = 0; it < iters; ++it) {
-        const bool more = it + 1 < iters;
-        const int sw = more ? s_w(it + 1) : 0, sx = more ? s_x(it + 1) : 0;
+    for (int it0 = 0; it0 < iters; it0 += AHEAD) {
 #pragma unroll
-        for (int d = 0; d < 18; ++d) {
-            const Frag f = ring[d];
-            if (more) ring[d] = fetch(d, sw, sx);
+        for (int a = 0; a < AHEAD; ++a) {
+            const int it = it0 + a;
+            if (it < iters) {
+                const bool more = it + AHEAD < iters;
+                const int sw = more ? s_w(it + AHEAD) : 0, sx = more ? s_x(it + AHEAD) : 0;
 #pragma unroll
-            for (int t = 0; t < TA; ++t)
+                for (int d = 0; d < 18; ++d) {
+                    const Frag f = ring[a * 18 + d];
+                    if (more) ring[a * 18 + d] = fetch(d, sw, sx);
 #pragma unroll
-                for (int u = 0; u < TB; ++u) acc[t][u] = mfma16<T>(f.a[t], f.b[u], acc[t][u]);
+                    for (int t = 0; t < TA; ++t)
+#pragma unroll
+                        for (int u = 0; u < TB; ++u) acc[t][u] = mfma16<T>(f.a[t], f.b[u], acc[t][u]);
+                }
+            }
         }
     }
 
@@ -236,14 +247,14 @@ bool conv3x3_lat_applies(int dtype, const ConvParams& p) {
 }
 
 namespace {
-template <int TA, int TB>
+template <int TA, int TB, int AHEAD = 1>
 hipError_t launch_form(int dtype, const ConvParams& p, hipStream_t st) {
     const long long totpix = (long long)p.N * p.H * p.W;
     const unsigned grid = (unsigned)(((totpix + 16 * TB - 1) / (16 * TB)) * (p.Cout / (16 * TA)));
-    if (dtype == ALINK_DT_BF16)       hipLaunchKernelGGL((conv3x3_lat_kernel<__bf16, false, 1, TA, TB>), dim3(grid), dim3(64), 0, st, p);
-    else if (dtype == ALINK_DT_F16)   hipLaunchKernelGGL((conv3x3_lat_kernel<_Float16, false, 1, TA, TB>), dim3(grid), dim3(64), 0, st, p);
-    else if (p.nprod == 1)            hipLaunchKernelGGL((conv3x3_lat_kernel<_Float16, true, 1, TA, TB>), dim3(grid), dim3(64), 0, st, p);
-    else                              hipLaunchKernelGGL((conv3x3_lat_kernel<_Float16, true, 3, TA, TB>), dim3(grid), dim3(64), 0, st, p);
+    if (dtype == ALINK_DT_BF16)       hipLaunchKernelGGL((conv3x3_lat_kernel<__bf16, false, 1, TA, TB, AHEAD>), dim3(grid), dim3(64), 0, st, p);
+    else if (dtype == ALINK_DT_F16)   hipLaunchKernelGGL((conv3x3_lat_kernel<_Float16, false, 1, TA, TB, AHEAD>), dim3(grid), dim3(64), 0, st, p);
+    else if (p.nprod == 1)            hipLaunchKernelGGL((conv3x3_lat_kernel<_Float16, true, 1, TA, TB, AHEAD>), dim3(grid), dim3(64), 0, st, p);
+    else                              hipLaunchKernelGGL((conv3x3_lat_kernel<_Float16, true, 3, TA, TB, AHEAD>), dim3(grid), dim3(64), 0, st, p);
     return hipGetLastError();
 }
 }  // namespace
@@ -258,7 +269,8 @@ hipError_t launch_conv3x3_lat(int dtype, const ConvParams& p, hipStream_t st) {
     switch (form) {
         case 1: return launch_form<2, 1>(dtype, p, st);
         case 2: return launch_form<2, 2>(dtype, p, st);
-        default: return launch_form<1, 1>(dtype, p, st);
+        case 4: return launch_form<1, 1, 1>(dtype, p, st);
+        default: return launch_form<1, 1, 2>(dtype, p, st);
     }
 }
 

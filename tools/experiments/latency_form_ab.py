@@ -10,7 +10,7 @@ from a_link_amd.backbone import IRBackbone
 lib = _abi.load()
 params = W.synthetic_ir_params(W.ARCH_UNITS["r100"], seed=1, normalized=True)
 limits = [784]
-forms = [int(a) for a in sys.argv[1:]] or [0, 1, 2]
+forms = [int(a) for a in sys.argv[1:]] or [0, 4, 2]      # 0: 16x16 blocks, 36 sub-steps in flight; 4: the same with 18; 2: 32x32 blocks
 for dt in ("bf16", "f16x2"):
     bb = IRBackbone(params, dtype=dt, max_batch=292)
     for n in (1, 2, 4, 8, 16):
