@@ -62,7 +62,7 @@ def test_no_convolution_kernel_spills_to_scratch():
     kernel 8 %)."""
     obj = os.path.join(ROOT, "a-link_amd", "lib", "obj")
     seen = 0
-    for name in ("conv3x3_linear", "conv3x3_direct", "conv3x3_c64", "conv3x3_s2c64", "front_c64", "conv_igemm", "stem_tail"):
+    for name in ("conv3x3_linear", "conv3x3_lat", "conv3x3_direct", "conv3x3_c64", "conv3x3_s2c64", "front_c64", "conv_igemm", "stem_tail"):
         path = os.path.join(obj, name + ".usage")
         assert os.path.exists(path), "build with the Makefile (it writes %s)" % path
         fn = None
