@@ -20,7 +20,7 @@
 // slices on the same MFMA k positions; a border tap adds the same zeros) and the epilogue is the same sequence of float
 // operations, so the result is bit-identical to the tile kernels' — asserted by every batch-1-equals-in-batch test of the suite.
 // Traffic grows with the batch (each wave re-reads its weight rows and pixels through L2: ~90 MB per image and stage-3 layer),
-// so the form is used for launches of at most g_lat_max_pixels output pixels (four 14 x 14 maps); above, the tile kernels.
+// so the form is used for launches of at most g_lat_max_pixels output pixels (eight 14 x 14 maps); above, the tile kernels.
 // Measured (IR-100, one image): 2.07 -> 1.04 ms in bf16, 6.05 -> 2.28 ms in split precision, embeddings unchanged bit for bit.
 #include "alink_common.h"
 
@@ -228,8 +228,9 @@ __global__ __launch_bounds__(64) void conv3x3_lat_kernel(const ConvParams p) {
     }
 }
 
-// launches of at most this many output pixels take the latency form (0 = never).  784 = four 14 x 14 maps, one 28 x 28 map.
-int g_lat_max_pixels = 784;
+// launches of at most this many output pixels — and at most 448 waves in the 32 x 32 form — take the latency form (0 = never).
+// 1600 = eight 14 x 14 maps, two 28 x 28 maps (sweep: profiles/r04g_small_batch_latency.txt; 3200 loses at 16 images).
+int g_lat_max_pixels = 1600;
 int g_lat_form = -1;              // A/B (alink_debug_set_latency_tiles): -1 = by size (below); 0 = 1 x 1 MFMA tiles per wave; 1 = 2 x 1; 2 = 2 x 2
 
 }  // namespace
@@ -241,6 +242,7 @@ bool conv3x3_lat_applies(int dtype, const ConvParams& p) {
     if (g_lat_max_pixels <= 0 || p.ksz != 3 || p.stride != 1 || p.pad != 1 || p.splitk != 1 || p.dact || p.stamps || p.in2) return false;
     if (p.Cin % 64 || p.Cout % 32 || p.Cin < 128) return false;                 // the 64-channel layers are HBM-shaped, not K walks
     if ((long long)p.N * p.H * p.W > g_lat_max_pixels) return false;
+    if (((long long)p.N * p.H * p.W + 31) / 32 * (p.Cout / 32) > 448) return false;     // more waves than that: the tile kernels' reuse wins
     if ((long long)p.N * p.H * p.W * p.Cin * (dtype == ALINK_DT_F16X2 ? 4 : 2) >= (1ll << 31)) return false;       // byte offsets in 31 bits
     if ((long long)p.Cout * 9 * p.Cin * (dtype == ALINK_DT_F16X2 ? 4 : 2) >= (1ll << 31)) return false;
     return dtype == ALINK_DT_BF16 || dtype == ALINK_DT_F16 || dtype == ALINK_DT_F16X2;

@@ -579,17 +579,17 @@ def test_latency_form_of_small_launches_is_bit_identical_to_the_tile_kernels(gpu
         for name, m in views:
             ref_big = m.embed(x) if name != "exact" else big
             for n in (1, 2, 3, 4, 5):
-                lib.alink_debug_set_latency_form(784)
+                lib.alink_debug_set_latency_form(1600)
                 lat = m.embed(x[:n])
                 lib.alink_debug_set_latency_form(0)
                 tile = m.embed(x[:n])
                 assert np.array_equal(lat, tile), (dtype, name, n, np.abs(lat - tile).max())
                 assert np.array_equal(lat, ref_big[:n]), (dtype, name, n)
             for form in (0, 1, 2):                                 # each block shape alone, 3 images
-                lib.alink_debug_set_latency_form(784)
+                lib.alink_debug_set_latency_form(1600)
                 lib.alink_debug_set_latency_tiles(form)
                 assert np.array_equal(m.embed(x[:3]), ref_big[:3]), (dtype, name, form)
                 lib.alink_debug_set_latency_tiles(-1)
     finally:
-        lib.alink_debug_set_latency_form(784)
+        lib.alink_debug_set_latency_form(1600)
         lib.alink_debug_set_latency_tiles(-1)
