@@ -390,6 +390,24 @@ def main():
                                                   "kernel_ms_per_forward": cms,
                                                   "non_conv_ms_per_forward": float(np.median(other_ms))}}
 
+    def single_image_ms(bbx):
+        """the reference's own call shape (FaceModel.get_feature, code/face_model.py:86-93): ONE image, host array in, host array out"""
+        one = px[:1].numpy() if args.input == "u8" else px[:1].to(torch.float32).numpy()
+        for _ in range(5):
+            bbx.embed(one)
+        ts = []
+        for _ in range(30):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            bbx.embed(one)
+            ts.append(time.perf_counter() - t1)
+        return 1e3 * float(np.median(ts))
+
+    if rank == 0 and not args.no_extras:
+        line["single_image_ms"] = single_image_ms(bb)
+        line["single_image_note"] = ("one image, host in / host out, %s; launches of a handful of images take the latency form of the 3x3 convolution "
+                                     "(csrc/conv3x3_lat.hip), bit-identical to the batched kernels (parity.batch1_rows_bit_equal_to_timed_batch)" % args.dtype)
+
     sel_out = None
     if args.select_dtype != "none" and args.select_dtype != args.dtype:
         # ---- the exact-selection leg (north_star: ">= 10 k embeddings/s ... with selection sets identical to the
@@ -429,6 +447,8 @@ def main():
         if rank == 0 and not args.no_extras and args.select_dtype == "f16x2":
             # the exact mode's own dominant kernel: algorithmic fraction, issued fraction (3 MFMA FLOPs per algorithmic FLOP), traffic
             line["exact_selection"]["roofline"] = roofline_of(bs, "f16x2")
+        if rank == 0 and not args.no_extras:
+            line["exact_selection"]["single_image_ms"] = single_image_ms(bs)
         del bs
     del params
 
