@@ -189,6 +189,8 @@ hipError_t launch_conv3x3_linear(int variant, int dtype, const ConvParams& p, hi
 // conv3x3_lat.hip: the latency form for launches of a handful of images (one wave per 32 x 32 output block, operands straight from L2)
 bool       conv3x3_lat_applies(int dtype, const ConvParams& p);
 hipError_t launch_conv3x3_lat(int dtype, const ConvParams& p, hipStream_t stream);
+bool       conv_gemm_lat_applies(int dtype, const ConvParams& p);     // a lone image's stride-2 3x3 (+ fused shortcut) and 1x1 layers
+hipError_t launch_conv_gemm_lat(int dtype, const ConvParams& p, hipStream_t stream);
 
 // backward.hip (input-gradient pass)
 hipError_t launch_l2norm_bwd(int dtype, const float* g, const float* e, const float* norms, void* dz, int M, int E,

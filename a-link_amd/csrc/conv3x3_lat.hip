@@ -42,6 +42,9 @@ __device__ __forceinline__ f32x4 mfma16<_Float16>(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+template <int A>
+struct IC { static constexpr int a = A; };
+
 // TA x TB MFMA tiles per wave (TA: 16-channel tiles of one 32-channel block of the packed weights, TB: 16-pixel tiles).
 // SP: split precision (T = _Float16): NP product phases per chunk — 3 (hi x W_hi, hi x W_lo, lo x W_hi) or 1 (the screening form).
 //
@@ -228,6 +231,156 @@ __global__ __launch_bounds__(64) void conv3x3_lat_kernel(const ConvParams p) {
     }
 }
 
+// ---- the same form for the implicit-GEMM layers of a lone image: the stride-2 3x3 convolution of a stage's first unit (16-bit
+// modes: with the unit's 1x1 projection shortcut as extra K-steps from a second input) and the stand-alone 1x1 stride-2 shortcut
+// of split precision.  conv_igemm's walk — tap-major, chunk inside the tap, per real step the products X_lo W_hi, X_hi W_hi,
+// X_hi W_lo (split precision), k halves inside; the shortcut's chunks after the last tap — and its epilogue, so the results are
+// bit-identical to conv_igemm_kernel's.  CPT (Cin / 64) is a template parameter: the whole walk unrolls, every offset is an SGPR
+// constant or an immediate.  Weights [cout'][tap][chunk][64] (split precision [tap][chunk][hi 64 | lo 64]), rows permuted per
+// 64-channel block: row 64 b + 16 t + 4 q' + j  <->  channel 64 b + 16 q' + 4 t + j.
+template <typename T, bool SP, int NP, int CPT, int KSZ, int CPT2>
+__global__ __launch_bounds__(64) void conv_gemm_lat_kernel(const ConvParams p) {
+    typedef typename Vec8<T>::type vec8;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    constexpr unsigned RSRC3 = 0x00020000u, OOB = 0x80000000u;
+    constexpr int NTAP = KSZ * KSZ, NPH = SP ? NP : 1;
+    constexpr int XE = SP ? 2 : 1;                             // elements per value (hi | lo)
+    const int lane = threadIdx.x;
+    const int q = lane >> 4, lr = lane & 15;
+    const int H = p.H, W = p.W, Cout = p.Cout;
+    constexpr int Cin = CPT * 64, CinP = XE * Cin, Cin2 = CPT2 * 64;
+    constexpr int K = XE * NTAP * Cin + Cin2;                  // weight row pitch
+    const int ncb = Cout >> 4;
+    const int cb = (int)blockIdx.x % ncb, bp = (int)blockIdx.x / ncb;
+    const int HoWo = p.Ho * p.Wo;
+
+    // this lane's output pixel and the byte offset of its window's first input pixel, biased by PAD rows + PAD pixels so that it is
+    // never negative (the descriptor's base is lowered by the same amount); OOB where a tap leaves the image
+    const int m = bp * 16 + lr;
+    const bool okp = m < p.M;
+    const int mc = okp ? m : 0;
+    const int n = mc / HoWo, rem = mc - n * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+    const long long bias_px = (long long)p.pad * W + p.pad;
+    const unsigned xoff = (unsigned)((((long long)(n * H + iy0) * W + ix0 + bias_px) * CinP + q * 8) * 2);
+    unsigned vox[NTAP];
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+        const int ky = tap / KSZ, kx = tap % KSZ;
+        vox[tap] = (okp && (unsigned)(iy0 + ky) < (unsigned)H && (unsigned)(ix0 + kx) < (unsigned)W) ? xoff : OOB;
+    }
+    const unsigned vox2 = okp ? (unsigned)((((long long)(p.in2_compact ? mc : (n * H + oy * p.stride) * W + ox * p.stride)) * Cin2 + q * 8) * 2) : OOB;
+    const int t16 = cb & 3, b64 = cb >> 2;
+    const unsigned vow = (unsigned)(((b64 * 64 + 16 * t16 + lr) * K + q * 8) * 2);
+
+    const unsigned xbytes = (unsigned)((long long)p.N * H * W * CinP * 2), wbytes = (unsigned)((long long)Cout * K * 2);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, (int)wbytes, RSRC3);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.in - bias_px * CinP * 2), 0,
+                                                                        (int)(xbytes + (unsigned)(bias_px * CinP * 2)), RSRC3);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(CPT2 ? p.in2 : p.in), 0,
+                                                                         CPT2 ? (int)((long long)(p.in2_compact ? p.M : p.N * H * W) * Cin2 * 2) : 0, RSRC3);
+    const int tap_bytes = 0;
+    (void)tap_bytes;
+
+    // the walk, flattened and fully static: S = ((tap * CPT + cc) * NPH + ph) * 2 + ks, then the shortcut's (cc2, ks)
+    constexpr int MAIN = NTAP * CPT * NPH * 2, TOTAL = MAIN + CPT2 * 2;
+    constexpr int DEPTH = TOTAL < 24 ? TOTAL : 24;
+    struct Frag { vec8 a, b; };
+    auto fetch = [&](auto sc) -> Frag {
+        constexpr int S = decltype(sc)::a;
+        Frag f;
+        u32x4 va, vb;
+        if constexpr (S < MAIN) {
+            constexpr int ks = S & 1, r = S >> 1, ph = r % NPH, step = r / NPH, cc = step % CPT, tap = step / CPT;
+            constexpr int ky = tap / KSZ, kx = tap % KSZ;
+            // split precision, conv_igemm's product order: 0 = X_lo W_hi, 1 = X_hi W_hi, 2 = X_hi W_lo; the screening form: X_hi W_hi
+            constexpr int xpart = SP ? ((NP == 3 && ph == 0) ? 1 : 0) : 0, wblk = SP ? ((NP == 3 && ph == 2) ? 1 : 0) : 0;
+            constexpr int wk = SP ? ((tap * CPT + cc) * 2 + wblk) * 128 + ks * 64 : (tap * CPT + cc) * 128 + ks * 64;
+            constexpr int xk = (SP ? (2 * cc + xpart) : cc) * 128 + ks * 64;
+            const int xs = (ky * W + kx) * CinP * 2 + xk;                        // uniform: an SGPR
+            va = __builtin_amdgcn_raw_buffer_load_b128(rw, vow, wk, 0);
+            vb = __builtin_amdgcn_raw_buffer_load_b128(rx, vox[tap], xs, 0);
+        } else {
+            constexpr int S2 = S - MAIN, ks = S2 & 1, cc = S2 >> 1;
+            va = __builtin_amdgcn_raw_buffer_load_b128(rw, vow, (XE * NTAP * Cin + cc * 64) * 2 + ks * 64, 0);
+            vb = __builtin_amdgcn_raw_buffer_load_b128(rx2, vox2, cc * 128 + ks * 64, 0);
+        }
+        __builtin_memcpy(&f.a, &va, 16);
+        __builtin_memcpy(&f.b, &vb, 16);
+        return f;
+    };
+
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    Frag ring[DEPTH];
+    auto prologue = [&](auto self, auto dc) {
+        constexpr int d = decltype(dc)::a;
+        if constexpr (d < DEPTH) {
+            ring[d] = fetch(IC<d>{});
+            self(self, IC<d + 1>{});
+        }
+    };
+    prologue(prologue, IC<0>{});
+    auto body = [&](auto self, auto sc) {
+        constexpr int S = decltype(sc)::a;
+        if constexpr (S < TOTAL) {
+            const Frag f = ring[S % DEPTH];
+            if constexpr (S + DEPTH < TOTAL) ring[S % DEPTH] = fetch(IC<S + DEPTH>{});
+            acc = mfma16<T>(f.a, f.b, acc);
+            self(self, IC<S + 1>{});
+        }
+    };
+    body(body, IC<0>{});
+
+    // ---- conv_igemm's epilogue for the lane's 4 channels of pixel m ------------------------------------------------------------
+    if (!okp) return;
+    const int c0 = b64 * 64 + 16 * q + 4 * t16;
+    int cls = 0;
+    if (p.border_cls) {
+        const int rc = (oy == 0) ? 0 : ((oy == p.Ho - 1) ? 2 : 1);
+        const int cc = (ox == 0) ? 0 : ((ox == p.Wo - 1) ? 2 : 1);
+        cls = rc * 3 + cc;
+    }
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    const size_t off = SP ? (size_t)mc * (2 * Cout) + (size_t)(c0 >> 6) * 128 + (c0 & 63) : (size_t)mc * Cout + c0;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float b = p.bias[cls * Cout + c0 + j];
+        v[j] = SP ? fmaf(acc[j], p.acc_scale, b * p.bias_scale) : acc[j] + b;
+    }
+    if (p.alpha) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * p.alpha[c0 + j];
+    }
+    if (p.resid) {
+        const T* r = (const T*)p.resid;
+        const vec4 rh = *(const vec4*)(r + off);
+        if constexpr (SP) {
+            const vec4 rl = *(const vec4*)(r + off + 64);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaf((float)rh[j] + (float)rl[j], p.res_scale, v[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
+        }
+    }
+    if (p.post_relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = relu_keep_nan(v[j]);
+    }
+    vec4 o4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o4[j] = (T)v[j];
+    *(vec4*)((T*)p.out + off) = o4;
+    if constexpr (SP) {
+        vec4 l4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) l4[j] = (T)(v[j] - (float)o4[j]);
+        *(vec4*)((T*)p.out + off + 64) = l4;
+    }
+}
+
 // launches of at most this many output pixels — and at most 448 waves in the 32 x 32 form — take the latency form (0 = never).
 // 1600 = eight 14 x 14 maps, two 28 x 28 maps (sweep: profiles/r04g_small_batch_latency.txt; 3200 loses at 16 images).
 int g_lat_max_pixels = 1600;
@@ -260,6 +413,62 @@ hipError_t launch_form(int dtype, const ConvParams& p, hipStream_t st) {
     return hipGetLastError();
 }
 }  // namespace
+
+bool conv_gemm_lat_applies(int dtype, const ConvParams& p) {
+    if (g_lat_max_pixels <= 0 || p.splitk != 1 || p.dact || p.stamps) return false;
+    const bool c3 = p.ksz == 3 && p.stride == 2 && p.pad == 1, c1 = p.ksz == 1 && p.pad == 0 && !p.in2;
+    if (!c3 && !c1) return false;
+    const int cpt = p.Cin / 64, cpt2 = p.in2 ? p.Cin2 / 64 : 0;
+    if (p.Cin % 64 || p.Cout % 64 || (cpt != 1 && cpt != 2 && cpt != 4 && cpt != 8)) return false;
+    if (p.in2 && (dtype == ALINK_DT_F16X2 || cpt2 != cpt / 2 || cpt < 2)) return false;        // the fused shortcut of a stage's first unit
+    if (p.M > 784 || (long long)((p.M + 15) / 16) * (p.Cout / 16) > 512) return false;           // a lone image's stride-2 layers
+    const long long two = dtype == ALINK_DT_F16X2 ? 4 : 2;
+    if ((long long)p.N * p.H * p.W * p.Cin * two + ((long long)p.pad * p.W + p.pad) * p.Cin * two >= (1ll << 31)) return false;
+    if ((long long)p.Cout * (p.ksz * p.ksz * p.Cin * (two / 2) + (p.in2 ? p.Cin2 : 0)) * 2 >= (1ll << 31)) return false;
+    return dtype == ALINK_DT_BF16 || dtype == ALINK_DT_F16 || dtype == ALINK_DT_F16X2;
+}
+
+namespace {
+template <int CPT, int KSZ, int CPT2>
+hipError_t launch_gemm_form(int dtype, const ConvParams& p, hipStream_t st) {
+    const unsigned grid = (unsigned)(((p.M + 15) / 16) * (p.Cout / 16));
+    if (dtype == ALINK_DT_BF16)       hipLaunchKernelGGL((conv_gemm_lat_kernel<__bf16, false, 1, CPT, KSZ, CPT2>), dim3(grid), dim3(64), 0, st, p);
+    else if (dtype == ALINK_DT_F16)   hipLaunchKernelGGL((conv_gemm_lat_kernel<_Float16, false, 1, CPT, KSZ, CPT2>), dim3(grid), dim3(64), 0, st, p);
+    else if constexpr (CPT2 == 0) {
+        if (p.nprod == 1)             hipLaunchKernelGGL((conv_gemm_lat_kernel<_Float16, true, 1, CPT, KSZ, 0>), dim3(grid), dim3(64), 0, st, p);
+        else                          hipLaunchKernelGGL((conv_gemm_lat_kernel<_Float16, true, 3, CPT, KSZ, 0>), dim3(grid), dim3(64), 0, st, p);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_conv_gemm_lat(int dtype, const ConvParams& p, hipStream_t st) {
+    const int cpt = p.Cin / 64;
+    if (p.ksz == 3) {
+        if (p.in2) {
+            switch (cpt) {
+                case 2: return launch_gemm_form<2, 3, 1>(dtype, p, st);
+                case 4: return launch_gemm_form<4, 3, 2>(dtype, p, st);
+                case 8: return launch_gemm_form<8, 3, 4>(dtype, p, st);
+            }
+            return hipErrorInvalidValue;
+        }
+        switch (cpt) {
+            case 1: return launch_gemm_form<1, 3, 0>(dtype, p, st);
+            case 2: return launch_gemm_form<2, 3, 0>(dtype, p, st);
+            case 4: return launch_gemm_form<4, 3, 0>(dtype, p, st);
+            case 8: return launch_gemm_form<8, 3, 0>(dtype, p, st);
+        }
+        return hipErrorInvalidValue;
+    }
+    switch (cpt) {
+        case 1: return launch_gemm_form<1, 1, 0>(dtype, p, st);
+        case 2: return launch_gemm_form<2, 1, 0>(dtype, p, st);
+        case 4: return launch_gemm_form<4, 1, 0>(dtype, p, st);
+        case 8: return launch_gemm_form<8, 1, 0>(dtype, p, st);
+    }
+    return hipErrorInvalidValue;
+}
 
 hipError_t launch_conv3x3_lat(int dtype, const ConvParams& p, hipStream_t st) {
     // By size: 16 x 16 blocks (one MFMA per sub-step) while that makes at most 448 waves — a lone 14 x 14 x 256 map is 208 —, 32 x 32

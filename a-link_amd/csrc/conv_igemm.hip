@@ -462,6 +462,8 @@ hipError_t launch_conv_igemm(int dtype, const ConvParams& p, hipStream_t stream)
     const int two = dtype == ALINK_DT_F16X2 ? 2 : 1;
     if ((long long)p.N * p.H * p.W * p.Cin * two >= (1ll << 31)) return hipErrorInvalidValue;
     if ((long long)p.Cout * p.ksz * p.ksz * p.Cin * two >= (1ll << 31)) return hipErrorInvalidValue;
+    // a lone image: the latency form (conv3x3_lat.hip: one wave per 16 x 16 output block, this kernel's walk and epilogue: bit-identical)
+    if (conv_gemm_lat_applies(dtype, p)) return launch_conv_gemm_lat(dtype, p, stream);
     const bool wide = (p.Cout % 128) == 0;
     if (dtype == ALINK_DT_F16X2) {
         // split precision: LDS-DMA staging only; no backward mode; a K split must cut between real K-steps

@@ -565,7 +565,9 @@ def test_latency_form_of_small_launches_is_bit_identical_to_the_tile_kernels(gpu
     code/face_model.py:86-93, is a batch-1 call: 2.07 -> 1.04 ms in bf16, 6.05 -> 2.28 ms in split precision).  Every output is the
     same sum in the same order, and the same epilogue operations, as in the tile kernels: embeddings of 1 / 2 / 3 / 4 / 5 images —
     both block shapes, partial pixel tiles, every border class, PReLU and residual epilogues, 28-, 14- and 7-wide layers — equal
-    the tile kernels' bit for bit, equal their rows of a 292-image batch, and so does the one-product screening form."""
+    the tile kernels' bit for bit, equal their rows of a 292-image batch, and so does the one-product screening form.  The same
+    switch covers the implicit-GEMM layers of a lone image (conv_gemm_lat_kernel: the stride-2 3x3 convolution of a stage's first
+    unit, with its fused 1x1 shortcut in the 16-bit modes, and split precision's stand-alone shortcuts: conv_igemm's walk and epilogue)."""
     from a_link_amd import _abi, weights as W
     from a_link_amd.backbone import IRBackbone
     lib = _abi.load()
