@@ -930,7 +930,13 @@ static int embed_impl(alink_backbone_t* bb, const void* dev_in, int layout, int 
             const int sib = (g_sibling_aware && L.variant != 14) ? bb->siblings : 1;
             p.fine = nwg128 * sib <= g_fine_max ? 1 : 0;
         }
-        const int S = plan_split(bb, L, N);
+        int S = plan_split(bb, L, N);
+        // the opt-in K split (order-changing) gives way where the bit-identical latency form applies: that one is faster
+        if (S > 1) {
+            ConvParams probe = p;
+            probe.splitk = 1;
+            if (L.variant >= 11 ? conv3x3_lat_applies(cfg.dtype, probe) : (L.variant == 0 && conv_gemm_lat_applies(cfg.dtype, probe))) S = 1;
+        }
         if (x2) {
             p.ksteps_per_split *= 3;
             rc = settle(&L.e_out, p.out, (size_t)p.M * L.Cout * 2, [&](int e) -> int {

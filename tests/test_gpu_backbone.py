@@ -283,7 +283,9 @@ def test_small_batch_split_k_matches_fused(gpu):
         # two bf16 computations that round differently: each within ~1.4e-4 of the f32 oracle at this depth
         assert (1.0 - (a * b).sum(1)).max() < 5e-4, n
         assert (1.0 - (a[:2] * ref[:min(n, 2)]).sum(1)).max() < 1e-3, n
-    assert not np.array_equal(split.embed(x[:1]), fused.embed(x[:1]))   # the split path did run
+    # the split path did run (at 16 images; a lone image's layers take the bit-identical latency form instead, which the split
+    # yields to — conv3x3_lat.hip — except the 64-channel front, which is still split)
+    assert not np.array_equal(split.embed(x[:16]), fused.embed(x[:16]))
     # split precision has the same latency mode: slabs of raw accumulators, scales applied by its own finish kernel —
     # both forms at float32 accuracy, different only in summation order
     fused2 = IRBackbone(params, dtype="f16x2", max_batch=32)
@@ -292,7 +294,7 @@ def test_small_batch_split_k_matches_fused(gpu):
         a, b = split2.embed(x[:n]), fused2.embed(x[:n])
         assert np.isfinite(a).all() and np.abs(a - b).max() < 5e-6, (n, np.abs(a - b).max())
         assert np.abs(a[:2] - ref[:min(n, 2)]).max() < 1e-5, n
-    assert not np.array_equal(split2.embed(x[:1]), fused2.embed(x[:1]))
+    assert not np.array_equal(split2.embed(x[:16]), fused2.embed(x[:16]))
 
 
 def _embed_in_launches(bb, xd, streams):
