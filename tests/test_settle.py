@@ -280,3 +280,29 @@ def test_select_queries_settled_non_finite_screened_rows_are_settled_not_trusted
     q, active, labels, _, settled, _ = settle.select_queries_settled(ens, scr, y, settle_fn)
     q0, active0, labels0 = selection.select_queries(ens, dis, y)
     assert q == q0 and active == active0 and np.array_equal(labels, labels0)
+
+
+def test_topk_undetermined_property_based():
+    """hypothesis: for arbitrary intervals and k, every realisation inside the intervals agrees with the items the resolver calls
+    certain, and when nothing is undetermined T is the realisation's exact top-k (ties -> lower index)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.tuples(st.floats(0, 1, width=32), st.floats(0, 0.25, width=32), st.booleans()), min_size=1, max_size=40),
+           st.integers(0, 45), st.booleans(), st.integers(0, 2 ** 31 - 1))
+    def check(items, k, largest, seed):
+        c = np.array([i[0] for i in items], np.float32)
+        w = np.array([0.0 if i[2] else i[1] for i in items], np.float32)
+        lo, hi = (c - w).astype(np.float32), (c + w).astype(np.float32)
+        P = len(c)
+        in_T, need, und, a, b = settle.topk_undetermined(lo, hi, k, largest)
+        assert in_T.sum() == min(k, P) and not (need & (lo == hi)).any()
+        rng = np.random.default_rng(seed)
+        for _ in range(5):
+            v = np.clip((lo + (hi - lo) * rng.random(P).astype(np.float32)).astype(np.float32), lo, hi)
+            top = set(np.lexsort((np.arange(P), -v if largest else v))[:k].tolist())
+            assert set(np.flatnonzero(in_T & ~und).tolist()) <= top
+            assert not (set(np.flatnonzero(~in_T & ~und).tolist()) & top)
+            if not need.any():
+                assert set(np.flatnonzero(in_T).tolist()) == top
+    check()
