@@ -309,7 +309,13 @@ class ArcFace:
             X = np.stack(X)
         if len(X) == 0:
             return np.zeros((0, 512), dtype=np.float32)
-        return self.screen.get_features(X)
+        from ._abi import AlinkError
+        try:
+            return self.screen.get_features(X)
+        except AlinkError:
+            # a batch the 16-bit screening form cannot hold (plain f16 left its range): the exact mode's own embeddings are a
+            # perfectly good "screening" of themselves — nothing near a cut will move when it is settled
+            return self.model.get_features(X)
 
     def process(self, X):
         """(N,H,W,3) float RGB 0..255 -> (N,512).  The reference loops get_input/get_feature per
