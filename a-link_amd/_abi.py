@@ -118,11 +118,12 @@ PROTOTYPES = {
     "alink_smallres_mask_sizes": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "alink_noise_gaussian": (_i, [_vp, _vp, _i64, _f, _f, _u64, _u64, _vp]),
     "alink_noise_speckle": (_i, [_vp, _vp, _i64, _f, _u64, _u64, _vp]),
-    "alink_noise_saltpepper": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _u64, _vp]),
+    "alink_noise_uniform": (_i, [_vp, _vp, _i64, _f, _f, _u64, _u64, _vp]),
+    "alink_noise_saltpepper": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u64, _vp]),
     "alink_noise_poisson_scratch_bytes": (_sz, [_i, _i64]),
-    "alink_noise_poisson": (_i, [_vp, _vp, _i, _i64, _u64, _vp, _sz, _vp, _vp]),
+    "alink_noise_poisson": (_i, [_vp, _vp, _i, _i64, _u64, _u64, _vp, _sz, _vp, _vp]),
     "alink_perlin_nodes": (_i, [_i, C.POINTER(_i)]),
-    "alink_perlin_vectors": (_i, [_i, _i, _u64, _vp, _vp]),
+    "alink_perlin_vectors": (_i, [_i, _i, _u64, _u64, _vp, _vp]),
     "alink_noise_perlin": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i), _vp, _vp]),
     "alink_resize_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "alink_pgd_step": (_i, [_vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _vp]),

@@ -53,6 +53,8 @@ class Flags(object):
     # work) in the feature model's 16-bit SCREENING mode and re-embed in the exact mode only the pairs whose side of a
     # cut is uncertain (settle.py) — same query set, same fine-tune data; needs a feature model with `process_screen`
     screen_settle = True
+    # not a flag of the reference: keyword options for settle.select_queries_settled (safety, delta0, min_sample, audit, ...)
+    settle_options = None
 
     def __init__(self, **kw):
         for k, v in kw.items():
@@ -65,6 +67,8 @@ def add_flags(parser):
     """Register the reference's flags on an argparse parser (tf.flags is not a dependency here)."""
     for name in sorted(n for n in vars(Flags) if not n.startswith("_")):
         default = getattr(Flags, name)
+        if default is None:                     # structured options: set on the Flags object, not on the command line
+            continue
         if isinstance(default, bool):
             parser.add_argument("--" + name, action="store_true", default=default)
         else:
@@ -112,9 +116,21 @@ def _set_rows(a, idx, v):
         a[np.asarray(idx, np.int64)] = _np(v)
 
 
+def sync_host_randomness(ensembleNoise, shards):
+    """Make rank 0's host-side random state every rank's: NumPy's global stream (the balanced generator's sampling,
+    fit()'s shuffles and SmallRes' dropout masks draw from it, as the reference's do: SURVEY.md §5) and the stream
+    state of every noise object.  After it, ranks that run the same host code stay in step by themselves."""
+    states = [z.stream_state() if hasattr(z, "stream_state") else None for z in ensembleNoise]
+    rng, states = shards.bcast((np.random.get_state(), states))
+    np.random.set_state(rng)
+    for z, st in zip(ensembleNoise, states):
+        if st is not None and hasattr(z, "set_stream_state"):
+            z.set_stream_state(st)
+
+
 def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensembleNoise, student, dataGen,
                     noisy_for_student, clean_for_student, image_res, col=0, verbose=1, labels_one_hot=False,
-                    noisy_for_student_screen=None):
+                    noisy_for_student_screen=None, group=None, batch_x_rows=None, calibration_of=None):
     """One pass of the loop body (code/ALINK_arc.py:150-254) over an already-built mini-batch.
 
     batch_x            [left, right] pair images (P, H, W, 3)
@@ -127,61 +143,146 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
                        flags.screen_settle), every noisy copy is converted by it first and only the pairs whose side of
                        a cut of the selection rule is uncertain — plus the pairs that end up selected — are converted
                        again by `noisy_for_student` (settle.select_queries_settled): query set, oracle count, labels and
-                       the rows that reach the fine-tune set equal the all-exact run's.
+                       the rows that reach the fine-tune set equal the all-exact run's on every workload measured, with a
+                       sampled audit behind the error bound (settle.py).
+    group              one process per GPU (not in the reference, which is one process on one GPU): a torch.distributed
+                       ProcessGroup (torch.distributed.group.WORLD, or True, for all ranks).  The P pair rows — 2 P n_noise
+                       noisy embeddings, the bulk of an iteration — are split contiguously over the ranks
+                       (distributed.RowShards): every rank perturbs ITS rows (noise keyed by the global row: what a row
+                       receives does not depend on the number of ranks), converts and scores them; ONE all-gather carries
+                       the (P, 2) student predictions of all noises (8 B per row and noise — never the features); the
+                       selection rule runs replicated on every rank (it is deterministic); a settle request is served by
+                       the rank that owns the row; the rows the fine-tune set takes from the noisy passes are gathered
+                       from their owners (a few hundred feature vectors); the fine-tune itself runs on every rank through
+                       distributed.dp_train_on_batch (replicated at the reference's batch of 16, gradient all-reduce
+                       above DP_SHARD_MIN_ROWS rows) with rank 0's shuffles.  Everything else (the clean pass: a few dozen
+                       unique images; committee predictions; bookkeeping) is replicated.  Query list, oracle count,
+                       fine-tune set and the student's weights afterwards equal the single-process iteration's bit for
+                       bit (tests/test_alink_multirank.py over gloo at world sizes 2 and 3; tests/test_gpu_distributed.py
+                       with two processes on one card).
+    batch_x_rows       (lo, hi) when batch_x holds only THIS rank's rows lo : hi of the P pairs (run_alink_dfw gathers
+                       just those: 150 KB of pixels per row and side); None: batch_x holds all P rows.
+    calibration_of     optional f() -> a picklable calibration state of the feature model (ArcFace: the split-precision
+                       scales): checked equal on all ranks before and after the iteration — a rank that re-calibrated on
+                       its own rows would embed to different last bits than its peers.
     Returns the number of examples added to the pending fine-tune set, or -1 when the reference
     `continue`s (no query survived: code/ALINK_arc.py:203-205 — the stop check is skipped too).
     """
     log = print if verbose else (lambda *a, **k: None)
+    P = len(batch_y)
+    shards = None
+    lo, hi = 0, P
+    if group is not None:
+        from . import distributed as _D
+        group = _D.resolve_group(group)
+        shards = _D.RowShards(P, group)
+        lo, hi = shards.lo, shards.hi
+        sync_host_randomness(ensembleNoise, shards)
+        cal0 = calibration_of() if calibration_of is not None else None
+        if calibration_of is not None and not shards.same_everywhere(cal0):
+            raise RuntimeError("alink_iteration: the feature model's calibration state differs between ranks: calibrate on one rank "
+                               "(or on a sample every rank draws identically) and distributed.broadcast_calibration() it")
+    if batch_x_rows is not None:
+        assert tuple(batch_x_rows) == (lo, hi), "batch_x_rows %s is not this rank's shard %s" % (tuple(batch_x_rows), (lo, hi))
+        local_x = batch_x
+    elif shards is not None:
+        local_x = [batch_x[0][lo:hi], batch_x[1][lo:hi]]
+    else:
+        local_x = batch_x
     state.iterations += 1
-    state.un_size += len(batch_x[0])
+    state.un_size += P
     ensemblePredictions = _np(bag.predict(batch_x_features))
     m1_labels = np.argmax(ensemblePredictions, axis=1)
     if labels_one_hot:                      # ALINK_MTP.py:174 passes keras.utils.to_categorical(..., 2)
         m1_labels = helpers.one_hot(m1_labels, 2)
-    noisy_data = bag.attackModel(batch_x, image_res, m1_labels)
+    if shards is not None:
+        noisy_data = bag.attackModel(local_x, image_res, m1_labels[lo:hi], rows=(lo, P))
+    else:
+        noisy_data = bag.attackModel(local_x, image_res, m1_labels)
     n_noise = len(ensembleNoise)
+    pred_shape = ensemblePredictions.shape[1:]
+
+    def predict_rows(sides):
+        """the student's predictions for rows this rank holds (an empty shard predicts nothing)"""
+        if len(sides[0]) == 0:
+            return np.zeros((0,) + tuple(pred_shape), np.float32)
+        return np.asarray(_np(student.predict(sides)), np.float32)
+
+    def all_noises(local_preds):
+        """[per noise (rows of this rank, C)] -> [per noise (P, C)]: one all-gather for all noises"""
+        if shards is None:
+            return local_preds
+        full = shards.all_rows(np.stack(local_preds, axis=1))             # (P, n_noise, C)
+        return [np.ascontiguousarray(full[:, jj]) for jj in range(n_noise)]
+
     if noisy_for_student_screen is not None and getattr(flags, "screen_settle", True):
         from . import settle
         pixels = noisy_data
         noisy_data = [[noisy_for_student_screen(p) for p in part] for part in pixels]
         noisy_data = [[f.clone() if hasattr(f, "detach") else np.array(f, copy=True) for f in part] for part in noisy_data]
-        screened = [_np(student.predict([noisy_data[0][jj], noisy_data[1][jj]])) for jj in range(n_noise)]
+        screened = all_noises([predict_rows([noisy_data[0][jj], noisy_data[1][jj]]) for jj in range(n_noise)])
 
         def settle_many(requests):
-            """a round's requests [(noise, pairs)]: both sides of every request converted in ONE exact call"""
-            parts = [_rows(pixels[s][jj], idx) for jj, idx in requests for s in (0, 1)]
-            if hasattr(parts[0], "detach"):
-                import torch
-                conv = noisy_for_student(torch.cat(parts))
-            else:
-                conv = noisy_for_student(np.concatenate([np.asarray(p) for p in parts]))
+            """a round's requests [(noise, pairs)]: both sides of every request converted in ONE exact call — by the
+            rank that owns the rows; the exact predictions of all requests then travel in one all-gather"""
+            mine = [(jj, np.asarray(idx, np.int64) - lo if shards is None else shards.owned(idx)) for jj, idx in requests]
+            parts = [_rows(pixels[s][jj], own) for jj, own in mine for s in (0, 1) if len(own)]
+            conv = None
+            if parts:
+                if hasattr(parts[0], "detach"):
+                    import torch
+                    conv = noisy_for_student(torch.cat(parts))
+                else:
+                    conv = noisy_for_student(np.concatenate([np.asarray(p) for p in parts]))
             out, o = [], 0
-            for jj, idx in requests:
+            for jj, own in mine:
                 sides = []
                 for s in (0, 1):
-                    sides.append(conv[o:o + len(idx)])
-                    _set_rows(noisy_data[s][jj], idx, sides[-1])     # the exact rows replace the screened ones
-                    o += len(idx)
-                out.append(_np(student.predict(sides)))
+                    if len(own):
+                        sides.append(conv[o:o + len(own)])
+                        _set_rows(noisy_data[s][jj], own, sides[-1])     # the exact rows replace the screened ones
+                        o += len(own)
+                out.append(predict_rows(sides) if len(own) else np.zeros((0,) + tuple(pred_shape), np.float32))
+            if shards is not None:
+                out = shards.subsets([idx for _, idx in requests], out, pred_shape)
             return out
         queryIndices, active, labels, disguisedPredictions, _, info = settle.select_queries_settled(
             ensemblePredictions, screened, batch_y, None, col=col, disparity_ratio=flags.disparity_ratio,
-            eps=flags.eps, blind_strategy=flags.blind_strategy, settle_many=settle_many)
+            eps=flags.eps, blind_strategy=flags.blind_strategy, settle_many=settle_many,
+            **dict(getattr(flags, "settle_options", None) or {}))
+        if shards is not None:
+            info = dict(info, rank=shards.rank, world=shards.world, rows_of_this_rank=hi - lo)
         state.settle_info.append(info)
     else:
         noisy_data = [[noisy_for_student(p) for p in part] for part in noisy_data]
-        disguisedPredictions = [_np(student.predict([noisy_data[0][jj], noisy_data[1][jj]])) for jj in range(n_noise)]
+        disguisedPredictions = all_noises([predict_rows([noisy_data[0][jj], noisy_data[1][jj]]) for jj in range(n_noise)])
         queryIndices, active, labels = selection.select_queries(
             ensemblePredictions, disguisedPredictions, batch_y, col=col, disparity_ratio=flags.disparity_ratio,
             eps=flags.eps, blind_strategy=flags.blind_strategy)
+    if shards is not None and calibration_of is not None:
+        if not shards.all_true(calibration_of() == cal0):
+            raise RuntimeError("alink_iteration: a rank's feature model re-calibrated itself during the iteration (a batch left the "
+                               "split-precision range): ranks no longer embed to the same bits.  Calibrate on noisy images like "
+                               "these first, then distributed.broadcast_calibration()")
     state.active_count += active
     log("Active Count so far : %d" % state.active_count)
     if len(queryIndices) == 0:
         return -1
     q = np.asarray(queryIndices)
     mp = int(len(q) / float(n_noise))
-    state.left = _concat(state.left, [_np(noisy_data[0][i])[q[i * mp:(i + 1) * mp]] for i in range(n_noise)])
-    state.right = _concat(state.right, [_np(noisy_data[1][i])[q[i * mp:(i + 1) * mp]] for i in range(n_noise)])
+    chunks = [q[i * mp:(i + 1) * mp] for i in range(n_noise)]
+    if shards is None:
+        noisy_left = [_np(noisy_data[0][i])[chunks[i]] for i in range(n_noise)]
+        noisy_right = [_np(noisy_data[1][i])[chunks[i]] for i in range(n_noise)]
+    else:
+        # chunk i of the query list takes noise i's rows (code/ALINK_arc.py:213-222): gathered from the ranks that own them
+        row_shape = tuple(_np(clean_for_student[0][:1]).shape[1:])
+        got = shards.subsets(chunks + chunks,
+                             [_np(_rows(noisy_data[s][i], shards.owned(chunks[i]))) for s in (0, 1) for i in range(n_noise)],
+                             row_shape, _np(clean_for_student[0][:1]).dtype)
+        noisy_left, noisy_right = got[:n_noise], got[n_noise:]
+    state.left = _concat(state.left, noisy_left)
+    state.right = _concat(state.right, noisy_right)
     state.y = _concat(state.y, [labels[i * mp:(i + 1) * mp] for i in range(n_noise)])
     added = n_noise * mp
     if state.y.shape[0] >= flags.batch_send:
@@ -197,7 +298,14 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
         left = np.concatenate((state.left, _np(clean_for_student[0])[q], X_old_left))
         right = np.concatenate((state.right, _np(clean_for_student[1])[q], X_old_right))
         y = np.concatenate((state.y, labels, Y_old))
-        hist = student.finetune([left, right], y, flags.ft_epochs, 16, 1 if verbose else 0)
+        net = getattr(student, "siamese_net", None)
+        if shards is not None and net is not None and hasattr(net, "dp_group"):
+            net.dp_group = group              # fit() -> distributed.dp_train_on_batch, rank 0's shuffles
+        try:
+            hist = student.finetune([left, right], y, flags.ft_epochs, 16, 1 if verbose else 0)
+        finally:
+            if shards is not None and net is not None and hasattr(net, "dp_group"):
+                net.dp_group = None
         state.history.append(hist)
         state.finetunes += 1
         state.left, state.right, state.y = np.array([]), np.array([]), np.array([])
@@ -207,7 +315,8 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
 def _embed_pairs_unique(conversionModel, plain_part, disguise_part, on_device):
     """Teacher features of createMiniBatch(plain_part, disguise_part) with every image embedded once.
     on_device: keep pixels, pair gathers and features as CUDA tensors, so that the P pair occurrences
-    (hundreds of MB of pixels per side) never cross PCIe — noise, resize and embedding all take tensors."""
+    (hundreds of MB of pixels per side) never cross PCIe — noise, resize and embedding all take tensors.
+    Replicated on every rank of a multi-rank loop (a few dozen unique images: 80 of an iteration's 30,800 embeddings)."""
     n_plain = [len(p) for p in plain_part]
     n_dig = [len(d) for d in disguise_part]
     li, ri, y = pairs.createMiniBatchIndices(n_plain, n_dig)
@@ -220,32 +329,55 @@ def _embed_pairs_unique(conversionModel, plain_part, disguise_part, on_device):
     return unique, li, ri, y, feats
 
 
+def _calibration_probe(conversionModel):
+    """f() -> the feature model's calibration state (split-precision scales), or None when it has none to keep in step"""
+    bb = getattr(getattr(conversionModel, "model", None), "model", None)
+    if bb is not None and hasattr(bb, "state") and getattr(bb, "dtype", None) == "f16x2":
+        return bb.state
+    return None
+
+
 def run_alink_dfw(flags, conversionModel, bag, ensembleNoise, disguisedFacesModel, X_plain_raw, X_dig_post, dataGen,
-                  image_res, col=0, verbose=1, state=None, on_device=True):
+                  image_res, col=0, verbose=1, state=None, on_device=True, group=None):
     """The framework loop of ALINK_arc.py (col = 0) / ALINK.py (col = 1): code/ALINK_arc.py:139-260.
-    X_plain_raw / X_dig_post: per-person lists of raw images (k_i, H, W, 3).  Returns LoopState."""
+    X_plain_raw / X_dig_post: per-person lists of raw images (k_i, H, W, 3).  Returns LoopState.
+    group (one process per GPU; see alink_iteration): every rank is handed the SAME data and models (same weights, same
+    calibration) and calls this together; each materialises only its own rows of an iteration's pair batch, the state
+    returned — and the student's weights — are the same on every rank and equal the single-process loop's.  Rank 0
+    alone writes `flags.out_model`."""
     log = print if verbose else (lambda *a, **k: None)
     assert 0 <= flags.disparity_ratio <= 1 and 0 <= flags.eps < 0.5
     state = state or LoopState()
+    rank = 0
+    if group is not None:
+        from . import distributed as _D
+        group = _D.resolve_group(group)
+        rank = _D._dist().get_rank(group)
     log("== Framework beginning with a pool of %d" % (len(X_dig_post)))
     for ii in range(0, len(X_dig_post), flags.alink_bs):
         log("\nIteration #%d" % ((ii // flags.alink_bs) + 1))
         plain_part = X_plain_raw[ii: ii + flags.alink_bs]
         disguise_part = X_dig_post[ii: ii + flags.alink_bs]
         unique, li, ri, batch_y, feats = _embed_pairs_unique(conversionModel, plain_part, disguise_part, on_device)
-        batch_x = [unique[li], unique[ri]]
+        rows = None
+        if group is not None:                   # only this rank's rows of the pair batch are gathered (150 KB per row and side)
+            rows = _D.shard_range(len(batch_y), rank, _D._dist().get_world_size(group))
+            batch_x = [unique[li[rows[0]:rows[1]]], unique[ri[rows[0]:rows[1]]]]
+        else:
+            batch_x = [unique[li], unique[ri]]
         batch_x_features = [feats[li], feats[ri]]
         added = alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensembleNoise,
                                 disguisedFacesModel, dataGen, noisy_for_student=conversionModel.process,
                                 clean_for_student=batch_x_features, image_res=image_res, col=col, verbose=verbose,
-                                noisy_for_student_screen=getattr(conversionModel, "process_screen", None))
+                                noisy_for_student_screen=getattr(conversionModel, "process_screen", None),
+                                group=group, batch_x_rows=rows, calibration_of=_calibration_probe(conversionModel) if group is not None else None)
         if added < 0:
             continue
         if int(flags.active_ratio * state.un_size) <= state.active_count:
             log("Specified limit reached! Stopping algorithm")
             break
     log("Active Count: %d out of %d" % (state.active_count, state.un_size))
-    if flags.out_model:
+    if flags.out_model and rank == 0:
         disguisedFacesModel.save(flags.out_model)
     return state
 
@@ -264,12 +396,18 @@ def createMiniBatchMTP(X_dig):
 
 
 def run_alink_mtp(flags, conversionModel, bag, ensembleNoise, lowResModel, X_dig_post, dataGen, image_res, low_res,
-                  verbose=1, state=None):
+                  verbose=1, state=None, group=None):
     """The framework loop of ALINK_MTP.py (code/ALINK_MTP.py:150-266): the teacher committee scores
-    high-res features, the student (SmallRes) sees noisy LOW-res pixels and is fine-tuned on them."""
+    high-res features, the student (SmallRes) sees noisy LOW-res pixels and is fine-tuned on them.
+    group: as in run_alink_dfw (the student's train steps run replicated: every rank holds the same SmallRes)."""
     from . import noise as _noise
     log = print if verbose else (lambda *a, **k: None)
     state = state or LoopState()
+    rank = 0
+    if group is not None:
+        from . import distributed as _D
+        group = _D.resolve_group(group)
+        rank = _D._dist().get_rank(group)
     log("== Framework beginning with a pool of %d ==" % (len(X_dig_post)))
     for ii in range(0, len(X_dig_post), flags.alink_bs):
         log("\nIteration #%d" % ((ii // flags.alink_bs) + 1))
@@ -284,10 +422,15 @@ def run_alink_mtp(flags, conversionModel, bag, ensembleNoise, lowResModel, X_dig
         high = np.asarray(_noise.resize_images(unique, image_res))           # readMTP.resizeImages (:164-165)
         low = np.asarray(_noise.resize_images(unique, low_res))
         feats = np.asarray(conversionModel.process(high))
-        batch_x = [unique[li], unique[ri]]
+        rows = None
+        if group is not None:
+            rows = _D.shard_range(len(batch_y), rank, _D._dist().get_world_size(group))
+            batch_x = [unique[li[rows[0]:rows[1]]], unique[ri[rows[0]:rows[1]]]]
+        else:
+            batch_x = [unique[li], unique[ri]]
         added = alink_iteration(state, flags, batch_x, batch_y, [feats[li], feats[ri]], bag, ensembleNoise, lowResModel,
                                 dataGen, noisy_for_student=lambda p: np.asarray(p), clean_for_student=[low[li], low[ri]],
-                                image_res=low_res, col=0, verbose=verbose, labels_one_hot=True)
+                                image_res=low_res, col=0, verbose=verbose, labels_one_hot=True, group=group, batch_x_rows=rows)
         if added < 0:
             log("== Nothing in this set. Skipping batch ==")
             continue
@@ -295,7 +438,7 @@ def run_alink_mtp(flags, conversionModel, bag, ensembleNoise, lowResModel, X_dig
             log("== Specified limit reached! Stopping algorithm ==")
             break
     log("== Active Count: %d out of %d ==" % (state.active_count, state.un_size))
-    if flags.out_model:
+    if flags.out_model and rank == 0:
         lowResModel.save(flags.out_model)
     return state
 

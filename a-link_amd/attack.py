@@ -124,7 +124,11 @@ class PixelAttacker:
                 (not targeted_attack and predicted_class != target_class)):
             return True
 
-    def attack(self, image, actual_class, target, pixel_count, dimensions, maxiter=75, popsize=400, verbose=False):
+    def attack(self, image, actual_class, target, pixel_count, dimensions, maxiter=75, popsize=400, verbose=False,
+               seed=None):
+        """seed (not in the reference, which seeds nothing: code/attack.py:81-83): this search's own random stream,
+        instead of the attacker's `self.seed` — what makes a pair's search independent of the pairs attacked before it"""
+        seed = self.seed if seed is None else seed
         targeted_attack = target is not None
         target_class = target if targeted_attack else actual_class
         dim_x, dim_y = dimensions
@@ -139,17 +143,20 @@ class PixelAttacker:
             return self.attack_success(x, image, target_class, targeted_attack, verbose, _scorer=scorer)
 
         attack_result = differential_evolution(predict_fn, bounds, maxiter=maxiter, popsize=popmul, recombination=1,
-                                               atol=-1, callback=callback_fn, polish=False, seed=self.seed,
+                                               atol=-1, callback=callback_fn, polish=False, seed=seed,
                                                rng_compat=self.rng_compat)
         self.last_result = attack_result
         attack_image = perturb_image(attack_result.x, image)[0]
         return attack_image
 
-    def attack_all(self, input_data, targets, dimensions, pixel_count=40, maxiter=50, popsize=250, verbose=False):
+    def attack_all(self, input_data, targets, dimensions, pixel_count=40, maxiter=50, popsize=250, verbose=False,
+                   seeds=None):
+        """seeds (optional, one per image): see attack() — a rank that attacks rows lo : hi of a pair batch with the
+        seeds of those rows finds what the whole-batch call finds for them"""
         X = []
         for i, img in enumerate(input_data):
             target_class = np.argmax(targets[i])
             result = self.attack(img, 1 - target_class, target_class, pixel_count, dimensions, maxiter=maxiter,
-                                 popsize=popsize, verbose=verbose)
+                                 popsize=popsize, verbose=verbose, seed=None if seeds is None else seeds[i])
             X.append(result)
         return X

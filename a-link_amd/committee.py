@@ -51,12 +51,19 @@ class Bagging:
         out = _noise.resize_images(images, new_size)
         return out if hasattr(out, "detach") else np.array(out)      # CUDA tensors stay on the device
 
-    def attackModel(self, image_pairs, target_size, target_labels=None):
+    def attackModel(self, image_pairs, target_size, target_labels=None, rows=None):
         """code/committee.py:28-37: every noise perturbs the pair batch, both sides are resized to
-        target_size; returns [[left per noise], [right per noise]]."""
+        target_size; returns [[left per noise], [right per noise]].
+        rows=(lo, total) (not in the reference): image_pairs / target_labels hold rows lo : lo + len of a batch of
+        `total` pairs — one rank's shard; noise objects that take row ranges (noise.py: every one of this package)
+        then draw for those rows what the whole-batch call would have drawn, any other duck-typed noise is called the
+        reference's way on the rows it is given."""
         sides = ([], [])
         for attack in self.attacks:
-            noisy = attack.addPairNoise(image_pairs, target_labels)
+            if rows is not None and getattr(attack, "supports_rows", False):
+                noisy = attack.addPairNoise(image_pairs, target_labels, rows=rows)
+            else:
+                noisy = attack.addPairNoise(image_pairs, target_labels)
             for side, images in zip(sides, noisy):
                 side.append(self.resize(images, target_size))
         return [sides[0], sides[1]]

@@ -62,7 +62,9 @@ __device__ __forceinline__ void box_muller(unsigned int a, unsigned int b, float
 // ---- Gaussian / Speckle ---------------------------------------------------------------------------
 // mode 0 (code/noise.py:40-44):  out = x + (mean + sigma * z)
 // mode 1 (code/noise.py:84-87):  out = x + x * (z / div)
-// Element e (= offset + i) takes normal number (e & 3) of Philox block e >> 2.
+// mode 2 (PGD's random start, an extension): out = x + (lo + (hi - lo) * u), u the element's 24-bit uniform
+// Element e (= offset + i) takes normal number (e & 3) of Philox block e >> 2: a row range of a logical array (a rank's
+// shard of the pair batch) draws what the whole array would have drawn there, whatever the offset's alignment.
 struct AffineNoise {
     const float* in;
     float* out;
@@ -70,28 +72,34 @@ struct AffineNoise {
     unsigned long long seed, offset;
     float p0, p1;
     int mode;
+    int vec;              // offset % 4 == 0 and both pointers 16-byte aligned: 16-byte lane accesses
 };
 
 __device__ __forceinline__ float apply_noise(const AffineNoise& p, float x, float z) {
-    return p.mode == 0 ? x + (p.p0 + p.p1 * z) : x + x * (z / p.p0);
+    return p.mode == 0 ? x + (p.p0 + p.p1 * z) : (p.mode == 1 ? x + x * (z / p.p0) : x + (p.p0 + (p.p1 - p.p0) * z));
 }
 
 __global__ __launch_bounds__(256) void affine_noise_kernel(const AffineNoise p) {
-    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;     // group of 4 elements
-    const long long i0 = g * 4;
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;     // Philox block (offset >> 2) + g: 4 elements
+    const long long i0 = g * 4 - (long long)(p.offset & 3);           // local index of the block's first element
     if (i0 >= p.count) return;
     const U4 r = draw(p.seed, (p.offset >> 2) + (unsigned long long)g, 0, ST_NORMAL);
     float z[4];
-    box_muller(r.x, r.y, z[0], z[1]);
-    box_muller(r.z, r.w, z[2], z[3]);
-    if (i0 + 4 <= p.count) {
+    if (p.mode == 2) {
+        z[0] = u01(r.x); z[1] = u01(r.y); z[2] = u01(r.z); z[3] = u01(r.w);
+    } else {
+        box_muller(r.x, r.y, z[0], z[1]);
+        box_muller(r.z, r.w, z[2], z[3]);
+    }
+    if (p.vec && i0 + 4 <= p.count) {
         const f32x4 x = *(const f32x4*)(p.in + i0);
         f32x4 y;
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = apply_noise(p, x[j], z[j]);
         *(f32x4*)(p.out + i0) = y;
     } else {
-        for (int j = 0; i0 + j < p.count; ++j) p.out[i0 + j] = apply_noise(p, p.in[i0 + j], z[j]);
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j >= 0 && i0 + j < p.count) p.out[i0 + j] = apply_noise(p, p.in[i0 + j], z[j]);
     }
 }
 
@@ -103,7 +111,7 @@ struct SaltPepperP {
     const float* in;
     float* out;
     int H, W, C, n_salt, n_pepper;
-    unsigned long long seed;
+    unsigned long long seed, first_image;
 };
 
 __device__ __forceinline__ int bounded(unsigned int x, int range) {
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256) void saltpepper_kernel(const SaltPepperP p) {
     for (int phase = 0; phase < 2; ++phase) {
         const int n = phase == 0 ? p.n_salt : p.n_pepper;
         for (int k = tid; k < n; k += 256) {
-            const U4 r = draw(p.seed, ((unsigned long long)img << 32) | (unsigned int)k, (unsigned int)phase, ST_SALTPEPPER);
+            const U4 r = draw(p.seed, ((p.first_image + (unsigned long long)img) << 32) | (unsigned int)k, (unsigned int)phase, ST_SALTPEPPER);
             const int rr = bounded(r.x, p.H - 1), cc = bounded(r.y, p.W - 1), ch = bounded(r.z, p.C - 1);
             dst[((long long)rr * p.W + cc) * p.C + ch] = phase == 0 ? 1.f : 0.f;
         }
@@ -172,15 +180,18 @@ __global__ __launch_bounds__(256) void perlin_kernel(const PerlinP p) {
     for (int c = 0; c < p.C; ++c) p.out[base + c] = p.in[base + c] + noise;
 }
 
-__global__ void perlin_vectors_kernel(float* __restrict__ vec, long long n, unsigned long long seed) {
+// node e = first + i of the logical [all images][nodes] array takes word (e & 3) of Philox block e >> 2
+__global__ void perlin_vectors_kernel(float* __restrict__ vec, long long n, unsigned long long seed, unsigned long long first) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;      // 4 nodes per Philox block
-    if (g * 4 >= n) return;
-    const U4 r = draw(seed, (unsigned long long)g, 0, ST_PERLIN);
+    const long long i0 = g * 4 - (long long)(first & 3);
+    if (i0 >= n) return;
+    const U4 r = draw(seed, (first >> 2) + (unsigned long long)g, 0, ST_PERLIN);
     const unsigned int w[4] = {r.x, r.y, r.z, r.w};
-    for (int j = 0; j < 4 && g * 4 + j < n; ++j) {
+    for (int j = 0; j < 4; ++j) {
+        if (i0 + j < 0 || i0 + j >= n) continue;
         const float phi = 6.283185307179586f * u01(w[j]);       // np.random.uniform(0, 2 pi) (:102)
-        vec[(g * 4 + j) * 2 + 0] = cosf(phi);
-        vec[(g * 4 + j) * 2 + 1] = sinf(phi);
+        vec[(i0 + j) * 2 + 0] = cosf(phi);
+        vec[(i0 + j) * 2 + 1] = sinf(phi);
     }
 }
 
@@ -225,7 +236,7 @@ struct PoissonP {
     const unsigned int* count;   // unique values per image
     float* vals_out;             // optional [n_images]
     long long per;
-    unsigned long long seed;
+    unsigned long long seed, first_image;
 };
 
 __device__ double poisson_sample(double lam, unsigned long long seed, unsigned long long elem) {
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(256) void poisson_kernel(const PoissonP p) {
     if (i == 0 && p.vals_out) p.vals_out[img] = (float)vals;
     const long long e = img * p.per + i;
     const double lam = (double)p.in[e] * vals;
-    p.out[e] = (float)(poisson_sample(lam, p.seed, (unsigned long long)e) / vals);
+    p.out[e] = (float)(poisson_sample(lam, p.seed, p.first_image * (unsigned long long)p.per + (unsigned long long)e) / vals);
 }
 
 // ---- bilinear resize (cv2.resize INTER_LINEAR, code/committee.py:22-26) -------------------------------
@@ -353,6 +364,9 @@ __global__ __launch_bounds__(256) void perturb_kernel(const PerturbP p) {
 }
 
 inline dim3 g1(long long n) { return dim3((unsigned)((n + 255) / 256), 1, 1); }
+inline int affine_vec_ok(const float* in, const float* out, unsigned long long offset) {
+    return ((offset & 3) == 0 && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0) ? 1 : 0;
+}
 
 }  // namespace
 }  // namespace alink
@@ -365,10 +379,9 @@ int alink_noise_gaussian(const float* dev_in, float* dev_out, int64_t count, flo
                          uint64_t seed, uint64_t offset, void* stream) {
     ALINK_REQUIRE(dev_in && dev_out && count >= 0, ALINK_EINVAL, "bad argument");
     DeviceGuard dg(device_of_pointer(dev_out));
-    ALINK_REQUIRE((offset & 3) == 0, ALINK_EINVAL, "offset must be a multiple of 4");
     if (count == 0) return ALINK_OK;
-    AffineNoise p{dev_in, dev_out, count, seed, offset, mean, sigma, 0};
-    hipLaunchKernelGGL(affine_noise_kernel, g1((count + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    AffineNoise p{dev_in, dev_out, count, seed, offset, mean, sigma, 0, affine_vec_ok(dev_in, dev_out, offset)};
+    hipLaunchKernelGGL(affine_noise_kernel, g1(((long long)(offset & 3) + count + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
 }
@@ -377,23 +390,34 @@ int alink_noise_speckle(const float* dev_in, float* dev_out, int64_t count, floa
                         uint64_t offset, void* stream) {
     ALINK_REQUIRE(dev_in && dev_out && count >= 0 && divisor != 0.f, ALINK_EINVAL, "bad argument");
     DeviceGuard dg(device_of_pointer(dev_out));
-    ALINK_REQUIRE((offset & 3) == 0, ALINK_EINVAL, "offset must be a multiple of 4");
     if (count == 0) return ALINK_OK;
-    AffineNoise p{dev_in, dev_out, count, seed, offset, divisor, 0.f, 1};
-    hipLaunchKernelGGL(affine_noise_kernel, g1((count + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    AffineNoise p{dev_in, dev_out, count, seed, offset, divisor, 0.f, 1, affine_vec_ok(dev_in, dev_out, offset)};
+    hipLaunchKernelGGL(affine_noise_kernel, g1(((long long)(offset & 3) + count + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+int alink_noise_uniform(const float* dev_in, float* dev_out, int64_t count, float lo, float hi, uint64_t seed,
+                        uint64_t offset, void* stream) {
+    ALINK_REQUIRE(dev_in && dev_out && count >= 0 && lo <= hi, ALINK_EINVAL, "bad argument");
+    DeviceGuard dg(device_of_pointer(dev_out));
+    if (count == 0) return ALINK_OK;
+    AffineNoise p{dev_in, dev_out, count, seed, offset, lo, hi, 2, affine_vec_ok(dev_in, dev_out, offset)};
+    hipLaunchKernelGGL(affine_noise_kernel, g1(((long long)(offset & 3) + count + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
 }
 
 int alink_noise_saltpepper(const float* dev_in, float* dev_out, int n_images, int H, int W, int C, int n_salt,
-                           int n_pepper, uint64_t seed, void* stream) {
+                           int n_pepper, uint64_t seed, uint64_t first_image, void* stream) {
     ALINK_REQUIRE(dev_in && dev_out && n_images >= 0, ALINK_EINVAL, "bad argument");
     DeviceGuard dg(device_of_pointer(dev_out));
     // np.random.randint(0, i - 1) needs i - 1 > 0 for every axis (code/noise.py:59,63)
     ALINK_REQUIRE(H >= 2 && W >= 2 && C >= 2, ALINK_EINVAL, "low >= high: image %dx%dx%d has an axis shorter than 2", H, W, C);
     ALINK_REQUIRE(n_salt >= 0 && n_pepper >= 0, ALINK_EINVAL, "negative counts");
     if (n_images == 0) return ALINK_OK;
-    SaltPepperP p{dev_in, dev_out, H, W, C, n_salt, n_pepper, seed};
+    ALINK_REQUIRE(first_image + (uint64_t)n_images <= (1ull << 32), ALINK_EINVAL, "image index beyond 2^32");
+    SaltPepperP p{dev_in, dev_out, H, W, C, n_salt, n_pepper, seed, first_image};
     hipLaunchKernelGGL(saltpepper_kernel, dim3(n_images), dim3(256), 0, (hipStream_t)stream, p);
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
@@ -411,12 +435,13 @@ int alink_perlin_nodes(int size, const int* ns3) {
     return t;
 }
 
-int alink_perlin_vectors(int n_images, int nodes_total, uint64_t seed, float* dev_vec, void* stream) {
+int alink_perlin_vectors(int n_images, int nodes_total, uint64_t seed, uint64_t first_image, float* dev_vec, void* stream) {
     ALINK_REQUIRE(dev_vec && n_images >= 0 && nodes_total > 0, ALINK_EINVAL, "bad argument");
     DeviceGuard dg(device_of_pointer(dev_vec));
     const long long n = (long long)n_images * nodes_total;
     if (n == 0) return ALINK_OK;
-    hipLaunchKernelGGL(perlin_vectors_kernel, g1((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dev_vec, n, seed);
+    const unsigned long long first = first_image * (unsigned long long)nodes_total;
+    hipLaunchKernelGGL(perlin_vectors_kernel, g1(((long long)(first & 3) + n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dev_vec, n, seed, first);
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
 }
@@ -453,7 +478,7 @@ size_t alink_noise_poisson_scratch_bytes(int n_images, int64_t per_image) {
 }
 
 int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64_t per_image, uint64_t seed,
-                        void* dev_scratch, size_t scratch_bytes, float* dev_vals, void* stream) {
+                        uint64_t first_image, void* dev_scratch, size_t scratch_bytes, float* dev_vals, void* stream) {
     ALINK_REQUIRE(dev_in && dev_out && n_images >= 0 && per_image > 0, ALINK_EINVAL, "bad argument");
     DeviceGuard dg(device_of_pointer(dev_out));
     ALINK_REQUIRE(per_image < (1ll << 30), ALINK_EINVAL, "image of %lld elements too large", (long long)per_image);
@@ -470,7 +495,7 @@ int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64
     const dim3 grid((unsigned)((per_image + 255) / 256), n_images);
     UniqueP u{dev_in, table, count, per_image, slots};
     hipLaunchKernelGGL(unique_count_kernel, grid, dim3(256), 0, st, u);
-    PoissonP p{dev_in, dev_out, count, dev_vals, per_image, seed};
+    PoissonP p{dev_in, dev_out, count, dev_vals, per_image, seed, first_image};
     hipLaunchKernelGGL(poisson_kernel, grid, dim3(256), 0, st, p);
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;

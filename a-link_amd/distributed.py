@@ -12,6 +12,10 @@ this is new work shaped by SURVEY.md §8e:
   * `committee_pool_topk`: the whole config-3 shape on one rank (shard -> committee of backbones + heads ->
     uncertainty -> local top-k -> merge); `committee_pool_topk_settled`: the same result from a 16-bit screening pass
     plus exact re-embedding of only the images that own a pair near the cut (settle.py).
+  * `RowShards`: the rows of ONE pair batch split contiguously over the ranks — what the multi-rank A-LINK iteration
+    (alink_loop.alink_iteration(group=...), BASELINE configs[3] / configs[4]) is built from: every rank perturbs, embeds
+    and scores its rows, ONE all-gather carries the (P, 2) student predictions (not the features), selection is
+    replicated, settle requests and the fine-tune set's rows are served by the rank that owns them.
 All functions work on CPU tensors too (that is how the world-size-2 gloo tests exercise them).
 """
 import numpy as np
@@ -27,6 +31,17 @@ def shard_range(n, rank, world):
 def _dist():
     import torch.distributed as dist
     return dist
+
+
+def resolve_group(group):
+    """The loop-level functions (alink_loop, DenseHead.dp_group) use None for "one process, no collective"; the ranks of
+    a job are named by a ProcessGroup object — torch.distributed.group.WORLD for all of them, which True / "world"
+    abbreviate here."""
+    if group is None or group is False:
+        return None
+    if group is True or group == "world":
+        return _dist().group.WORLD
+    return group
 
 
 def merge_topk(local_vals, local_global_idx, k, largest=True, group=None):
@@ -250,6 +265,92 @@ def committee_pool_topk_settled(screen_backbones, exact_backbones, heads, pool_s
         info.update(inf)
     out_dev = Eg[0].device
     return torch.from_numpy(np.ascontiguousarray(vals)).to(out_dev), torch.from_numpy(np.ascontiguousarray(gidx)).to(out_dev)
+
+
+class RowShards(object):
+    """P rows (the pairs of one A-LINK mini-batch) split contiguously over the ranks of `group` (shard_range).  Every
+    method is a collective: all ranks call it with the same global arguments.  Payloads are small (predictions: 8 B per
+    row; fine-tune rows: a few hundred feature vectors), so they travel as ONE padded all-gather each — staged on the
+    device under "nccl" (RCCL moves device buffers), on the host under "gloo"."""
+
+    def __init__(self, P, group=None):
+        import torch
+        dist = _dist()
+        self.torch, self.dist, self.group = torch, dist, group
+        self.P = int(P)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.ranges = [shard_range(self.P, r, self.world) for r in range(self.world)]
+        self.lo, self.hi = self.ranges[self.rank]
+        self.device = "cuda:%d" % torch.cuda.current_device() if dist.get_backend(group) == "nccl" else "cpu"
+
+    def _gather(self, local, counts):
+        """local: (counts[rank], ...) host array -> [(counts[r], ...) host array for every rank r]"""
+        torch = self.torch
+        local = np.ascontiguousarray(local)
+        assert local.shape[0] == counts[self.rank], (local.shape, counts, self.rank)
+        m = max(counts)
+        if m == 0:
+            return [local[:0] for _ in counts]
+        pad = np.zeros((m,) + local.shape[1:], local.dtype)
+        pad[:local.shape[0]] = local
+        mine = torch.from_numpy(pad).to(self.device)
+        if self.device != "cpu":
+            every = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=self.device)
+            self.dist.all_gather_into_tensor(every, mine, group=self.group)
+            every = every.cpu().numpy()
+        else:
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine, group=self.group)
+            every = np.stack([p.numpy() for p in parts])
+        return [every[r, :counts[r]] for r in range(self.world)]
+
+    def all_rows(self, local):
+        """this rank's rows (hi - lo, ...) -> all P rows, in row order, on every rank"""
+        return np.concatenate(self._gather(local, [h - l for l, h in self.ranges]))
+
+    def owned(self, gidx):
+        """positions (into this rank's rows) of the members of the ascending global index list `gidx` this rank owns"""
+        gidx = np.asarray(gidx, np.int64)
+        return gidx[(gidx >= self.lo) & (gidx < self.hi)] - self.lo
+
+    def subsets(self, gidx_lists, local_values, row_shape, dtype=np.float32):
+        """For every ascending global index list in `gidx_lists`: the rows' values (each of shape `row_shape`), in list
+        order, on every rank.  local_values[i] holds the values of the members of gidx_lists[i] this rank owns (owned()
+        order); all lists travel in ONE all-gather."""
+        gidx_lists = [np.asarray(g, np.int64) for g in gidx_lists]
+        row_shape = tuple(int(v) for v in row_shape)
+        counts = [[int(((g >= l) & (g < h)).sum()) for g in gidx_lists] for l, h in self.ranges]
+        flat = [np.asarray(v, dtype).reshape((-1,) + row_shape) for v in local_values]
+        local = np.concatenate(flat) if flat else np.zeros((0,) + row_shape, dtype)
+        per_rank = self._gather(local, [sum(c) for c in counts])
+        out = []
+        offs = [0] * self.world
+        for i in range(len(gidx_lists)):
+            parts = []
+            for r in range(self.world):
+                parts.append(per_rank[r][offs[r]:offs[r] + counts[r][i]])
+                offs[r] += counts[r][i]
+            out.append(np.concatenate(parts))                 # ranks own ascending ranges: rank order is list order
+        return out
+
+    def bcast(self, obj, src=0):
+        """rank `src` (of the group)'s object on every rank"""
+        box = [obj if self.rank == src else None]
+        self.dist.broadcast_object_list(box, src=self.dist.get_global_rank(self.group, src) if self.group is not None else src,
+                                        group=self.group)
+        return box[0]
+
+    def all_true(self, flag):
+        """True on every rank iff `flag` is true on all ranks"""
+        every = [None] * self.world
+        self.dist.all_gather_object(every, bool(flag), group=self.group)
+        return all(every)
+
+    def same_everywhere(self, obj):
+        """True on every rank iff `obj` (small, picklable) is equal on all ranks"""
+        every = [None] * self.world
+        self.dist.all_gather_object(every, obj, group=self.group)
+        return all(e == every[0] for e in every)
 
 
 def broadcast_calibration(backbones, src=0, group=None):

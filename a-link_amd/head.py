@@ -82,6 +82,13 @@ class KerasFitMixin(object):
     (reference code/siamese.py:57).  validation_split holds out the LAST fraction before shuffling;
     np.random.shuffle(index_array) per epoch; epoch logs are batch-size-weighted means."""
     stop_training = False
+    # One process per GPU (not in the reference, which is one process on one GPU): with dp_group set, fit() runs its
+    # steps through distributed.dp_train_on_batch (replicated below distributed.DP_SHARD_MIN_ROWS rows, sharded with a
+    # gradient all-reduce above: dp_mode / dp_exchange) and every epoch's shuffle is rank 0's, so that all ranks hold
+    # the same weights afterwards.  alink_loop sets it for the student's fine-tune when the loop runs with `group`.
+    dp_group = None          # a torch.distributed ProcessGroup (torch.distributed.group.WORLD for all ranks); None: one process
+    dp_mode = "auto"
+    dp_exchange = "gather"
 
     def fit(self, x, y, batch_size=32, epochs=1, verbose=1, callbacks=None, validation_split=0.0, shuffle=True):
         L = np.asarray(x[0], dtype=np.float32)
@@ -98,13 +105,24 @@ class KerasFitMixin(object):
         history = {}
         self.stop_training = False
         index_array = np.arange(n)
+        step = self.train_on_batch
+        group = self.dp_group
+        if group is not None:
+            import torch.distributed as dist
+            if hasattr(self, "grads_tensor"):
+                from . import distributed as _D
+                step = lambda xb, yb: _D.dp_train_on_batch(self, xb, yb, group=group, mode=self.dp_mode, exchange=self.dp_exchange)
         for epoch in range(epochs):
             if shuffle:
                 np.random.shuffle(index_array)
+                if group is not None:
+                    box = [index_array if dist.get_rank(group) == 0 else None]
+                    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0), group=group)
+                    index_array = np.array(box[0])
             tot, seen = np.zeros(2), 0
             for s in range(0, n, batch_size):
                 ids = index_array[s:s + batch_size]
-                out = self.train_on_batch([L[ids], R[ids]], y[ids])
+                out = step([L[ids], R[ids]], y[ids])
                 tot += np.asarray(out) * len(ids)
                 seen += len(ids)
             logs = {"loss": tot[0] / seen, "acc": tot[1] / seen}

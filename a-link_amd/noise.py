@@ -17,6 +17,11 @@ Differences, all deliberate:
     (SURVEY.md §0); Perlin raises the reference's ValueError for sizes its reshape cannot take
     (112 x 112: code/noise.py:96,130).
 NumPy in -> NumPy out; CUDA tensor in -> CUDA tensor out.
+
+Row ranges (one process per GPU, alink_loop with `group`): `addPairNoise(pairs, labels, rows=(lo, total))` /
+`addNoise(images, labels, first_row=lo)` perturb rows lo : lo + len of a logical batch and return exactly what rows
+lo : lo + len of the whole-batch call would have held — every draw is keyed by (stream seed, GLOBAL element / image
+index), so the noise a pair receives does not depend on how many ranks share the batch.
 """
 import ctypes as C
 
@@ -51,8 +56,21 @@ class Noise(object):
         self._calls += 1
         return s
 
-    # batch hook: subclasses implement _apply(dev_images (n,H,W,C) f32) -> dev tensor
-    def _apply(self, x):
+    # what alink_loop's multi-rank iteration needs from a noise object: row-range calls (above) and a stream state
+    # that can be made rank 0's on every rank
+    supports_rows = True
+
+    def stream_state(self):
+        return (self._seed, self._calls)
+
+    def set_stream_state(self, st):
+        self._seed, self._calls = int(st[0]), int(st[1])
+
+    def _stream(self):
+        return _abi.current_stream(self.device)
+
+    # batch hook: subclasses implement _apply(dev_images (n,H,W,C) f32, first = global index of image 0) -> dev tensor
+    def _apply(self, x, first=0):
         return x.clone()
 
     def addIndividualNoise(self, image, target_labels=None):
@@ -61,17 +79,19 @@ class Noise(object):
             return self.addNoise(image[None], None)[0]
         return self.addNoise(np.asarray(image)[None], None)[0]
 
-    def addNoise(self, images, target_labels):
+    def addNoise(self, images, target_labels, first_row=0):
         if len(images) == 0:
-            return np.array(images)
+            self._next_seed()                    # an empty shard still consumes the call's stream: ranks stay in step
+            return images if hasattr(images, "detach") else np.array(images)
         x, as_torch = _as_device(images if not isinstance(images, (list, tuple)) else np.stack(images), self.device)
         if x.ndim != 4:
             raise ValueError("expected images of shape (n, H, W, C), got %s" % (tuple(x.shape),))
-        return _ret(self._apply(x), as_torch)
+        return _ret(self._apply(x, int(first_row)), as_torch)
 
-    def addPairNoise(self, image_pairs, target_labels):
-        left_half = self.addNoise(image_pairs[0], target_labels)
-        right_half = self.addNoise(image_pairs[1], target_labels)
+    def addPairNoise(self, image_pairs, target_labels, rows=None):
+        first = 0 if rows is None else int(rows[0])
+        left_half = self.addNoise(image_pairs[0], target_labels, first)
+        right_half = self.addNoise(image_pairs[1], target_labels, first)
         return [left_half, right_half]
 
 
@@ -82,12 +102,12 @@ class Gaussian(Noise):
         self.var = var
         self.sigma = self.var ** 0.5
 
-    def _apply(self, x):
+    def _apply(self, x, first=0):
         import torch
         lib = _abi.init(self.device)
         out = torch.empty_like(x)
         _abi.check(lib.alink_noise_gaussian(_abi.ptr(x), _abi.ptr(out), x.numel(), float(self.mean), float(self.sigma),
-                                            self._next_seed(), 0, _abi.current_stream()), "alink_noise_gaussian")
+                                            self._next_seed(), first * x[0].numel(), self._stream()), "alink_noise_gaussian")
         return out
 
 
@@ -95,12 +115,12 @@ class Speckle(Noise):
     def __init__(self, model=None, sess=None, feature_model=None, seed=None, device=None):
         super(Speckle, self).__init__(seed=seed, device=device)
 
-    def _apply(self, x):
+    def _apply(self, x, first=0):
         import torch
         lib = _abi.init(self.device)
         out = torch.empty_like(x)
-        _abi.check(lib.alink_noise_speckle(_abi.ptr(x), _abi.ptr(out), x.numel(), 15.0, self._next_seed(), 0,
-                                           _abi.current_stream()), "alink_noise_speckle")
+        _abi.check(lib.alink_noise_speckle(_abi.ptr(x), _abi.ptr(out), x.numel(), 15.0, self._next_seed(),
+                                           first * x[0].numel(), self._stream()), "alink_noise_speckle")
         return out
 
 
@@ -114,7 +134,7 @@ class SaltPepper(Noise):
         size = int(np.prod(shape))
         return (int(np.ceil(self.amount * size * self.s_vs_p)), int(np.ceil(self.amount * size * (1. - self.s_vs_p))))
 
-    def _apply(self, x):
+    def _apply(self, x, first=0):
         import torch
         lib = _abi.init(self.device)
         n, H, W, Cc = x.shape
@@ -123,7 +143,7 @@ class SaltPepper(Noise):
         n_salt, n_pepper = self.counts((H, W, Cc))
         out = torch.empty_like(x)
         _abi.check(lib.alink_noise_saltpepper(_abi.ptr(x), _abi.ptr(out), n, H, W, Cc, n_salt, n_pepper,
-                                              self._next_seed(), _abi.current_stream()), "alink_noise_saltpepper")
+                                              self._next_seed(), first, self._stream()), "alink_noise_saltpepper")
         return out
 
 
@@ -132,7 +152,7 @@ class Poisson(Noise):
         super(Poisson, self).__init__(seed=seed, device=device)
         self.last_vals = None
 
-    def _apply(self, x):
+    def _apply(self, x, first=0):
         import torch
         lib = _abi.init(self.device)
         n = x.shape[0]
@@ -143,8 +163,8 @@ class Poisson(Noise):
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         vals = torch.empty(n, dtype=torch.float32, device=x.device)
         out = torch.empty_like(x)
-        _abi.check(lib.alink_noise_poisson(_abi.ptr(x), _abi.ptr(out), n, per, self._next_seed(), _abi.ptr(scratch),
-                                           nbytes, _abi.ptr(vals), _abi.current_stream()), "alink_noise_poisson")
+        _abi.check(lib.alink_noise_poisson(_abi.ptr(x), _abi.ptr(out), n, per, self._next_seed(), first, _abi.ptr(scratch),
+                                           nbytes, _abi.ptr(vals), self._stream()), "alink_noise_poisson")
         self.last_vals = vals
         return out
 
@@ -157,7 +177,7 @@ class Perlin(Noise):
     def octaves(row):
         return [56, 32, 16] if row % 56 == 0 else [50, 30, 15]  # code/noise.py:144-147
 
-    def _apply(self, x, vectors=None):
+    def _apply(self, x, first=0, vectors=None):
         import torch
         lib = _abi.init(self.device)
         n, row, col, Cc = x.shape
@@ -171,14 +191,14 @@ class Perlin(Noise):
         nodes = lib.alink_perlin_nodes(row, ns3)
         if vectors is None:
             vectors = torch.empty((n, nodes, 2), dtype=torch.float32, device=x.device)
-            _abi.check(lib.alink_perlin_vectors(n, nodes, self._next_seed(), _abi.ptr(vectors), _abi.current_stream()),
+            _abi.check(lib.alink_perlin_vectors(n, nodes, self._next_seed(), first, _abi.ptr(vectors), self._stream()),
                        "alink_perlin_vectors")
         else:
             vectors = vectors.to(x.device, torch.float32).contiguous()
             assert tuple(vectors.shape) == (n, nodes, 2)
         out = torch.empty_like(x)
         _abi.check(lib.alink_noise_perlin(_abi.ptr(x), _abi.ptr(out), n, row, Cc, ns3, _abi.ptr(vectors),
-                                          _abi.current_stream()), "alink_noise_perlin")
+                                          self._stream()), "alink_noise_perlin")
         return out
 
 
@@ -222,18 +242,37 @@ class PredictionWrappedModel:
 
 
 class AdversarialNoise(Noise):
-    def __init__(self, model, sess, feature_model, seed=None, device=None):
+    """code/noise.py:171-188.  pixel_count / maxiter / popsize: the reference's attack_all defaults (code/attack.py:91),
+    exposed so that a test can run a short search.  Every pair's search has its own random stream, seeded by (this
+    object's stream, the pair's GLOBAL row): the reference seeds nothing (only distributions are contractual), and a
+    rank that attacks rows lo : hi of the batch (rows=(lo, total)) finds what the whole-batch call finds for them —
+    the search is 0.5 s per pair at the defaults, the part of an A2-LINK iteration that most needs every GPU."""
+
+    def __init__(self, model, sess, feature_model, seed=None, device=None, pixel_count=40, maxiter=50, popsize=250):
         super(AdversarialNoise, self).__init__(model, sess, feature_model, seed=seed, device=device)
         from . import attack
         self.e2e_model = PredictionWrappedModel(model, feature_model)
         self.attacker = attack.PixelAttacker(self.e2e_model)
+        self.search = dict(pixel_count=pixel_count, maxiter=maxiter, popsize=popsize)
 
-    def addPairNoise(self, image_pairs, target_labels):
+    def addPairNoise(self, image_pairs, target_labels, rows=None):
+        first = 0 if rows is None else int(rows[0])
+        base = self._next_seed()
+        n = len(image_pairs[0])
+        if n == 0:
+            return [[], []]
         image_pairs = [p.detach().cpu().numpy() if hasattr(p, "detach") else p for p in image_pairs]
-        concat_data = [np.concatenate((image_pairs[0][i], image_pairs[1][i]), axis=0)
-                       for i in range(len(image_pairs[0]))]
+        concat_data = [np.concatenate((image_pairs[0][i], image_pairs[1][i]), axis=0) for i in range(n)]
         img_shape = image_pairs[0][0].shape
-        perturbed = self.attacker.attack_all(concat_data, target_labels, dimensions=(2 * img_shape[0], img_shape[1]))
+        # splitmix64 of (stream, global row) -> a 32-bit RandomState seed per pair
+        seeds = []
+        for i in range(n):
+            z = (base + 0x9E3779B97F4A7C15 * (first + i + 1)) & 0xFFFFFFFFFFFFFFFF
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+            seeds.append(int((z ^ (z >> 31)) & 0xFFFFFFFF))
+        perturbed = self.attacker.attack_all(concat_data, target_labels, dimensions=(2 * img_shape[0], img_shape[1]),
+                                             seeds=seeds, **self.search)
         left_half = [p[:p.shape[0] // 2] for p in perturbed]
         right_half = [p[p.shape[0] // 2:] for p in perturbed]
         return [left_half, right_half]
@@ -272,8 +311,13 @@ class FGSM(Noise):
         y[np.arange(n), cls] = 1.0
         return y
 
-    def addPairNoise(self, image_pairs, target_labels):
+    def addPairNoise(self, image_pairs, target_labels, rows=None):
         import torch
+        first = 0 if rows is None else int(rows[0])
+        if len(image_pairs[0]) == 0:                # an empty shard consumes the call's streams like any other
+            if self.random_start:
+                self._next_seed(), self._next_seed()
+            return [image_pairs[0], image_pairs[1]]
         bb, head = self._parts()
         xl, as_torch = _as_device(image_pairs[0] if not isinstance(image_pairs[0], (list, tuple)) else np.stack(image_pairs[0]), self.device)
         xr, _ = _as_device(image_pairs[1] if not isinstance(image_pairs[1], (list, tuple)) else np.stack(image_pairs[1]), self.device)
@@ -282,13 +326,14 @@ class FGSM(Noise):
         step = self.eps if self.alpha is None else float(self.alpha)
         sign = -1.0 if self.targeted else 1.0
         al, ar = xl.clone(), xr.clone()
-        if self.random_start:
-            g = torch.Generator(device=xl.device).manual_seed(self._next_seed() & 0x7FFFFFFF)
-            al += (torch.rand(al.shape, generator=g, device=al.device) * 2 - 1) * self.eps
-            ar += (torch.rand(ar.shape, generator=g, device=ar.device) * 2 - 1) * self.eps
-        mb = bb.max_batch
         lib = _abi.init(self.device)
         al, ar = al.float().contiguous(), ar.float().contiguous()
+        if self.random_start:
+            # U(-eps, eps) keyed by (stream, GLOBAL element): a row's start does not depend on the batch it arrives in
+            for t in (al, ar):
+                _abi.check(lib.alink_noise_uniform(_abi.ptr(t), _abi.ptr(t), t.numel(), -self.eps, self.eps, self._next_seed(),
+                                                   first * t[0].numel(), self._stream()), "alink_noise_uniform")
+        mb = bb.max_batch
         for _ in range(self.steps):
             for s in range(0, n, mb):
                 sl = slice(s, min(n, s + mb))
@@ -304,10 +349,10 @@ class FGSM(Noise):
                 for adv, clean, grad in ((al, xl, gl), (ar, xr, gr)):
                     a_, c_, g_ = adv[sl], clean[sl].contiguous(), grad.contiguous()
                     _abi.check(lib.alink_pgd_step(_abi.ptr(a_), _abi.ptr(c_), _abi.ptr(g_), a_.numel(), sign * step, self.eps,
-                                                  float(lo), float(hi), _abi.current_stream()), "alink_pgd_step")
+                                                  float(lo), float(hi), self._stream()), "alink_pgd_step")
         return [_ret(al, as_torch), _ret(ar, as_torch)]
 
-    def addNoise(self, images, target_labels):
+    def addNoise(self, images, target_labels, first_row=0):
         raise TypeError("gradient attacks perturb pairs: use addPairNoise")
 
 

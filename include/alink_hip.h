@@ -396,7 +396,9 @@ int alink_roc_counts(const float* dev_scores, const uint8_t* dev_mask, int n,
  * A2-LINK perturbation stage (code/noise.py, code/attack.py:5-29, code/committee.py:22-37).
  * Images are float32 (n, H, W, C) as everywhere upstream of the models.  Random draws come from a
  * counter-based Philox4x32-10 keyed by (seed, element index): results do not depend on the launch
- * shape, and `offset` (multiple of 4 elements) lets a caller process one logical array in chunks.
+ * shape, and `offset` (elements; any value) / `first_image` (images) let a caller process a row range of one
+ * logical array — a chunk, or one rank's shard of the pair batch (a-link_amd/alink_loop.py with `group`) —
+ * and get exactly what the whole array would have drawn there.
  * The reference draws from the unseeded np.random global stream, so only the distributions are
  * contractual.  In-place (dev_out == dev_in) is allowed for every call except alink_resize_bilinear.
  * ---------------------------------------------------------------------------------------------- */
@@ -406,22 +408,27 @@ int alink_noise_gaussian(const float* dev_in, float* dev_out, int64_t count, flo
 /* noise.Speckle.addIndividualNoise (code/noise.py:83-88): out = x + x * N(0,1) / divisor (15) */
 int alink_noise_speckle(const float* dev_in, float* dev_out, int64_t count, float divisor,
                         uint64_t seed, uint64_t offset, void* stream);
+/* EXTENSION (the random start of noise.PGD; no counterpart in code/noise.py): out = x + U(lo, hi), the element's
+ * 24-bit uniform from the same (seed, element) keying */
+int alink_noise_uniform(const float* dev_in, float* dev_out, int64_t count, float lo, float hi,
+                        uint64_t seed, uint64_t offset, void* stream);
 /* noise.SaltPepper.addIndividualNoise (code/noise.py:54-65), tuple-index semantics: per image n_salt
  * elements (r,c,ch) <- 1 then n_pepper elements <- 0, r in [0,H-2], c in [0,W-2], ch in [0,C-2]. */
 int alink_noise_saltpepper(const float* dev_in, float* dev_out, int n_images, int H, int W, int C,
-                           int n_salt, int n_pepper, uint64_t seed, void* stream);
+                           int n_salt, int n_pepper, uint64_t seed, uint64_t first_image, void* stream);
 /* noise.Poisson.addIndividualNoise (code/noise.py:72-76): per image vals = 2^ceil(log2(#unique)),
  * out = Poisson(x * vals) / vals.  dev_vals (optional, n_images) receives vals. */
 size_t alink_noise_poisson_scratch_bytes(int n_images, int64_t per_image);
 int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64_t per_image,
-                        uint64_t seed, void* dev_scratch, size_t scratch_bytes, float* dev_vals,
-                        void* stream);
+                        uint64_t seed, uint64_t first_image, void* dev_scratch, size_t scratch_bytes,
+                        float* dev_vals, void* stream);
 /* noise.Perlin (code/noise.py:95-150): three octaves ns3[0..2] of gradient noise on square
  * size x size images, the same noise added to every channel.  dev_vec holds the unit gradient
  * vectors [n_images][alink_perlin_nodes(size, ns3)][2], octave after octave, row-major grids of
  * (size/ns + 1)^2 nodes (code/noise.py:100-107); alink_perlin_vectors fills it with random ones. */
 int alink_perlin_nodes(int size, const int* ns3);
-int alink_perlin_vectors(int n_images, int nodes_total, uint64_t seed, float* dev_vec, void* stream);
+int alink_perlin_vectors(int n_images, int nodes_total, uint64_t seed, uint64_t first_image, float* dev_vec,
+                         void* stream);
 int alink_noise_perlin(const float* dev_in, float* dev_out, int n_images, int size, int C,
                        const int* ns3, const float* dev_vec, void* stream);
 /* committee.Bagging.resize (code/committee.py:22-26): cv2.resize(image, (Wo, Ho)), INTER_LINEAR */
