@@ -525,15 +525,34 @@ __global__ __launch_bounds__(256) void pgd_step_kernel(float* __restrict__ adv, 
         for (long long k = 4 * n4; k < n; ++k) adv[k] = one(adv[k], clean[k], grad[k]);
     }
 }
+__global__ __launch_bounds__(256) void pgd_step_scalar_kernel(float* __restrict__ adv, const float* __restrict__ clean,
+                                                              const float* __restrict__ grad, long long n,
+                                                              float step, float eps, float lo, float hi) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = grad[i], c = clean[i];
+    const float s = (g > 0.f ? 1.f : 0.f) - (g < 0.f ? 1.f : 0.f);
+    float a = fmaf(step, s, adv[i]);
+    a = fminf(fmaxf(a, c - eps), c + eps);
+    adv[i] = fminf(fmaxf(a, lo), hi);
+}
 }  // namespace
 }  // namespace alink
 
 int alink_pgd_step(float* dev_adv, const float* dev_clean, const float* dev_grad, int64_t n, float step, float eps,
                    float lo, float hi, void* stream) {
     ALINK_REQUIRE(dev_adv && dev_clean && dev_grad && n >= 0, ALINK_EINVAL, "bad argument");
-    ALINK_REQUIRE((((uintptr_t)dev_adv | (uintptr_t)dev_clean | (uintptr_t)dev_grad) & 15) == 0, ALINK_EINVAL, "buffers must be 16-byte aligned");
     if (n == 0) return ALINK_OK;
     DeviceGuard dg(device_of_pointer(dev_adv));
+    // 16-byte lane accesses when all three buffers are 16-byte aligned; a chunk of an odd-sized batch is not (its start
+    // is s * H * W * C * 4 bytes): the same kernel then takes every element in its scalar tail — one block per 256 elements
+    const bool aligned = (((uintptr_t)dev_adv | (uintptr_t)dev_clean | (uintptr_t)dev_grad) & 15) == 0;
+    if (!aligned) {
+        hipLaunchKernelGGL(alink::pgd_step_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           dev_adv, dev_clean, dev_grad, (long long)n, step, eps, lo, hi);
+        ALINK_HIP(hipGetLastError());
+        return ALINK_OK;
+    }
     const long long n4 = n / 4;
     hipLaunchKernelGGL(alink::pgd_step_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        dev_adv, dev_clean, dev_grad, n4, (long long)n, step, eps, lo, hi);

@@ -640,14 +640,19 @@ def main():
         line["pool_from_host_note"] = "IRBackbone.embed on a (%d,112,112,3) uint8 host array -> (N,512) host array, %s; PCIe-inclusive, not `value`" % (B, args.dtype)
         assert np.isfinite(eh).all()
 
-    if rank == 0 and world == 1 and not args.no_config4 and not args.no_extras:
-        # ---- BASELINE configs[3] shape on one GPU: ONE A-LINK iteration (reference code/ALINK_arc.py:142-254) with an IR-100
+    if not args.no_config4 and not args.no_extras:
+        # ---- BASELINE configs[3] shape: ONE A-LINK iteration (reference code/ALINK_arc.py:142-254) with an IR-100
         # teacher — 16 persons x (2 plain + 3 disguised) = 80 unique images, P = 3,840 pairs, four noises drawn per pair
         # occurrence = 30,720 noisy embeddings (the bulk of an iteration), selection, fine-tune —
         # twice from identical seeds: every embedding exact, and screen-then-settle (noisy copies in the 16-bit mode, only
         # the pairs near a cut of the rule and the selected ones again in the exact mode).  Must agree on the oracle-query
-        # count, the number of fine-tunes and the student's weights afterwards, bit for bit (asserted).
+        # count, the number of fine-tunes and the student's weights afterwards, bit for bit (compared here).
+        # With N ranks (a-link_amd/alink_loop.py, `group`): ONE iteration of the same size shared by all ranks — the pair
+        # rows split contiguously, every rank perturbs / embeds / scores its rows, one all-gather of the predictions,
+        # selection replicated, settle requests and fine-tune rows served by their owners (STRONG scaling of this leg: the
+        # job is fixed); every rank must end with the same student weights (hash compared across ranks here).
         from a_link_amd import alink_loop as AL, committee, noise as NZ, pairs as PR, siamese
+        import hashlib
         import tempfile
         names = ("gaussian", "saltpepper", "poisson", "speckle")
         ppl, _ = _identity_pool(16 * 5, 4242, per_person=5)
@@ -655,10 +660,11 @@ def main():
         X_plain, X_dig = [q[:2] for q in ppl], [q[2:] for q in ppl]
         res4 = {}
         tmpd = tempfile.mkdtemp()
+        grp4 = dist.group.WORLD if dist is not None else None        # under a launcher the multi-rank form runs even with one rank
         for mode in ("exact_all", "screen_settle"):
             conv = siamese.ArcFace((112, 112), "synthetic:r100:1:normalized", dtype="f16x2",
                                    screen_dtype="auto" if mode == "screen_settle" else None)
-            conv.model.model.calibrate(torch.from_numpy(ppl.reshape(-1, 112, 112, 3)).cuda())
+            conv.model.model.calibrate(torch.from_numpy(ppl.reshape(-1, 112, 112, 3)).cuda())     # the same images on every rank
             student = siamese.SiameseNetwork((512,), os.path.join(tmpd, "student"), 0.1, seed=1)
             ens = [siamese.SiameseNetwork((512,), "e%d" % i, 0.1, seed=2 + i) for i in range(2)]
             nzs = [NZ.get_relevant_noise(n_)(model=student, sess=None, feature_model=conv) for n_ in names]
@@ -680,33 +686,60 @@ def main():
                 gen = PR.getGenerator(PR.getNormalGenerator(feats, 16), PR.getNormalGenerator(feats, 16),
                                       PR.getImposterGenerator(feats, feats, 16), 16)
                 torch.cuda.synchronize()
+                barrier()
                 t1 = time.perf_counter()
-                st4 = AL.run_alink_dfw(flags, conv, bag, nzs, student, X_plain, X_dig, gen, (112, 112), col=0, verbose=0)
+                st4 = AL.run_alink_dfw(flags, conv, bag, nzs, student, X_plain, X_dig, gen, (112, 112), col=0, verbose=0, group=grp4)
                 torch.cuda.synchronize()
-                ts4.append(time.perf_counter() - t1)
+                barrier()
+                t4 = time.perf_counter() - t1
+                if dist is not None:
+                    tt = torch.tensor([t4], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    t4 = float(tt.item())
+                ts4.append(t4)
             res4[mode] = (ts4[-1], st4, student.siamese_net.get_weights(), conv.screen.model.dtype if conv.screen else None)
             del conv, student, ens, bag, nzs
         (t_e, st_e, w_e, _), (t_q, st_q, w_q, sdt) = res4["exact_all"], res4["screen_settle"]
         same4 = (st_e.active_count == st_q.active_count and st_e.finetunes == st_q.finetunes and st_e.un_size == st_q.un_size
                  and all(np.array_equal(a_, b_) for a_, b_ in zip(w_e, w_q)))
         assert same4 or not args.strict, "screen-then-settle A-LINK iteration differs from the all-exact one"
+        # every rank's student after the iteration: one hash per rank and mode, gathered
+        digest = [hashlib.sha256(b"".join(np.ascontiguousarray(w_).tobytes() for w_ in ws_)).hexdigest()[:16] for ws_ in (w_e, w_q)]
+        digests = [digest]
+        if dist is not None:
+            digests = [None] * world
+            dist.all_gather_object(digests, digest)
+        ranks_agree = all(d_ == digests[0] for d_ in digests)
+        assert ranks_agree or not args.strict, "ranks ended the A-LINK iteration with different student weights: %s" % digests
         P4 = st_e.un_size
         n_emb = 80 + 2 * P4 * len(names)
         g100 = ir_resnet.flops_per_image(W.ARCH_UNITS["r100"]) / 1e9
         inf4 = st_q.settle_info[-1]
-        line["config4"] = {
-            "workload": "one A-LINK iteration, IR-100 teacher (BatchNorm statistics matching the activations), 16 persons, 80 unique "
-                        "images, %d pairs, noises %s per pair occurrence = %d embeddings, heads' last layers rescaled (probabilities "
-                        "spread), selection + fine-tune" % (P4, "/".join(names), n_emb),
-            "exact_all": {"s_per_iteration": t_e, "embeddings_per_s": n_emb / t_e},
-            "screen_settle": {"s_per_iteration": t_q, "embeddings_per_s": n_emb / t_q, "screening_dtype": sdt,
-                              "fraction_pair_noise_rows_settled": inf4["fraction_settled"], "rounds": inf4["rounds"], "delta": inf4["delta"],
-                              "tflops_algorithmic": n_emb / t_q * g100 / 1e3, "frac_mfma_peak": n_emb / t_q * g100 / 1e3 / MFMA_PEAK_TFLOPS,
-                              "speedup_over_exact_all": t_e / t_q,
-                              "identical_to_exact_all": bool(same4),
-                              "identical_means": "oracle-query count, number of fine-tunes and the student's weights afterwards equal the all-exact iteration's bit for bit (compared in this run)"},
-            "oracle_queries": st_e.active_count, "finetunes": st_e.finetunes,
-            "note": "whole iteration on the wall clock: noise kernels, embeddings, heads, host-side selection, fine-tune"}
+        rows4 = [inf4.get("rows_of_this_rank", P4)]
+        if dist is not None:
+            rows4 = [None] * world
+            dist.all_gather_object(rows4, inf4.get("rows_of_this_rank", P4))
+        if rank == 0:
+            line["config4"] = {
+                "workload": "one A-LINK iteration, IR-100 teacher (BatchNorm statistics matching the activations), 16 persons, 80 unique "
+                            "images, %d pairs, noises %s per pair occurrence = %d embeddings, heads' last layers rescaled (probabilities "
+                            "spread), selection + fine-tune" % (P4, "/".join(names), n_emb),
+                "n_gpus": world, "scaling_of_this_leg": "strong (ONE iteration of fixed size shared by all ranks)" if world > 1 else "n/a (one rank)",
+                "pair_rows_per_rank": rows4,
+                "sharding": ("pair rows split contiguously over %d ranks; clean pass (80 images), committee predictions, selection and "
+                             "the batch-16 fine-tune replicated; one all-gather of the (P, n_noise, 2) predictions, settle replies and "
+                             "fine-tune rows from their owners" % world) if world > 1 else "one process",
+                "ranks_end_with_identical_student_weights": bool(ranks_agree),
+                "exact_all": {"s_per_iteration": t_e, "embeddings_per_s": n_emb / t_e},
+                "screen_settle": {"s_per_iteration": t_q, "embeddings_per_s": n_emb / t_q, "screening_dtype": sdt,
+                                  "fraction_pair_noise_rows_settled": inf4["fraction_settled"], "rounds": inf4["rounds"], "delta": inf4["delta"],
+                                  "audit": inf4.get("audit"),
+                                  "tflops_algorithmic": n_emb / t_q * g100 / 1e3, "frac_mfma_peak": n_emb / t_q * g100 / 1e3 / (MFMA_PEAK_TFLOPS * world),
+                                  "speedup_over_exact_all": t_e / t_q,
+                                  "identical_to_exact_all": bool(same4),
+                                  "identical_means": "oracle-query count, number of fine-tunes and the student's weights afterwards equal the all-exact iteration's bit for bit (compared in this run)"},
+                "oracle_queries": st_e.active_count, "finetunes": st_e.finetunes,
+                "note": "whole iteration on the wall clock (max over ranks): noise kernels, embeddings, heads, host-side selection, collectives, fine-tune"}
 
     if rank == 0 and not args.no_extras and args.dtype == "f32":
         # ---- float32 mode: every convolution and the FC on gemm32_kernel (v_mfma_f32_32x32x2_f32); no per-launch

@@ -434,8 +434,9 @@ int alink_noise_perlin(const float* dev_in, float* dev_out, int n_images, int si
 /* committee.Bagging.resize (code/committee.py:22-26): cv2.resize(image, (Wo, Ho)), INTER_LINEAR */
 /* EXTENSION (FGSM / PGD, not in the reference whose only attack is the few-pixel search of code/attack.py): one
  * signed-gradient step and the projection back into the eps-ball of the clean image and the pixel range, in place:
- *   adv <- clip(clip(adv + step * sign(grad), clean - eps, clean + eps), lo, hi)      (n float32 elements, 16-B aligned;
- * pass -INFINITY / INFINITY for no pixel clip; step < 0 descends). */
+ *   adv <- clip(clip(adv + step * sign(grad), clean - eps, clean + eps), lo, hi)      (n float32 elements; 16-byte
+ * aligned buffers take 16-byte lane accesses, any other alignment the scalar form; pass -INFINITY / INFINITY for no pixel
+ * clip; step < 0 descends). */
 int alink_pgd_step(float* dev_adv, const float* dev_clean, const float* dev_grad, int64_t n, float step, float eps,
                    float lo, float hi, void* stream);
 int alink_resize_bilinear(const float* dev_in, float* dev_out, int n, int H, int W, int C, int Ho,

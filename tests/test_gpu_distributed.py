@@ -339,3 +339,109 @@ def test_screen_then_settle_over_two_ranks_equals_single_process_exact(gpu, tmp_
     print("two ranks: settled %d + %d of %d + %d images in %d rounds; screening alone differs in %d of 64"
           % (z[0]["settled"], z[1]["settled"], z[0]["n"], z[1]["n"], z[0]["rounds"],
              len(set(only_screen.cpu().numpy().tolist()) ^ set(want_i.cpu().numpy().tolist())) // 2))
+
+
+# ---- the multi-rank A-LINK loop on the device models (BASELINE configs[3] / configs[4]) -------------------------------
+_LOOP_SIZE = (32, 32)
+_LOOP_NOISES = ("gaussian", "saltpepper", "poisson", "speckle")
+
+
+def _loop_people(n, seed, lo=2, hi=3):
+    rng = np.random.RandomState(seed)
+    return [rng.randint(0, 256, (rng.randint(lo, hi + 1),) + _LOOP_SIZE + (3,)).astype(np.float32) for _ in range(n)]
+
+
+def _loop_run(group, rank, screen, tmp):
+    """run_alink_dfw on the HIP models (ArcFace in split precision with a 16-bit screening form, DenseHead student and
+    committee, the device noise kernels); returns what every rank — and the single-process loop — must agree on"""
+    from a_link_amd import alink_loop as AL, committee, noise, pairs, settle, siamese
+    flags = AL.Flags(alink_bs=3, batch_send=6, disparity_ratio=0.6, eps=0.0005, ft_epochs=2, mixture_ratio=2,
+                     out_model=os.path.join(tmp, "post%d" % rank), screen_settle=screen is not None)
+    X_plain, X_dig = _loop_people(6, 1), _loop_people(6, 2)
+    conv = siamese.ArcFace(_LOOP_SIZE, "synthetic:r18:3", screen_dtype=screen)
+    conv.calibrate(np.concatenate(X_plain + X_dig))                 # the SAME images on every rank: rank-consistent scales
+    student = siamese.SiameseNetwork((512,), "student", 0.1, seed=7)
+    ens = [siamese.SiameseNetwork((512,), "ens%d" % i, 0.1, seed=100 + i) for i in range(2)]
+    # rank 0 carries the single-process run's seeds; the other rank starts from different noise streams and host randomness
+    nz = [noise.get_relevant_noise(n)(model=student, sess=None, feature_model=conv, seed=1000 + i + 50 * rank) for i, n in enumerate(_LOOP_NOISES)]
+    bag = committee.Bagging(ens, nz)
+    feats_plain = [conv.process(p) for p in X_plain]
+    gen = pairs.getGenerator(pairs.getNormalGenerator(feats_plain, 8), pairs.getNormalGenerator(feats_plain, 8),
+                             pairs.getImposterGenerator(feats_plain, feats_plain, 8), 8)
+    np.random.seed(5 + 31 * rank)
+    sets = []
+    o1, o2 = AL.selection.select_queries, settle.select_queries_settled
+    AL.selection.select_queries = lambda *a, **k: (lambda r: (sets.append(list(r[0])), r)[1])(o1(*a, **k))
+    settle.select_queries_settled = lambda *a, **k: (lambda r: (sets.append(list(r[0])), r)[1])(o2(*a, **k))
+    try:
+        st = AL.run_alink_dfw(flags, conv, bag, nz, student, X_plain, X_dig, gen, _LOOP_SIZE, col=0, verbose=0, group=group)
+    finally:
+        AL.selection.select_queries, settle.select_queries_settled = o1, o2
+    return {"counts": np.array([st.active_count, st.un_size, st.finetunes]), "sets": np.array([len(s) for s in sets] + sum(sets, [])),
+            "w": np.concatenate([w.ravel() for w in student.siamese_net.get_weights()]),
+            "rows": np.array([i.get("rows_of_this_rank", -1) for i in st.settle_info]),
+            "saved": np.array([os.path.exists(flags.out_model + ".h5")])}
+
+
+def _loop_worker(rank, world, port, path, tmp):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import a_link_amd  # noqa: F401
+        for tag, screen in (("exact", None), ("settle", "f16")):
+            np.savez(path % (tag, rank), **_loop_run(dist.group.WORLD, rank, screen, tmp))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multirank_alink_loop_equals_single_process_loop(gpu, tmp_path):
+    """alink_loop.run_alink_dfw(group=...) with TWO ranks (two processes on one card, gloo carrying the prediction all-gather,
+    the settle replies and the fine-tune rows): each rank perturbs, embeds and scores its own rows of every iteration's pair
+    batch with the device kernels.  Every iteration's query list, the oracle count, the number of fine-tunes and the
+    student's weights afterwards must equal the single-process loop's BIT FOR BIT on both ranks — all-exact and
+    screen-then-settle — and only rank 0 writes the model file.  (Reference loop: code/ALINK_arc.py:142-254.)"""
+    import socket
+    import torch.multiprocessing as mp
+    want = {tag: _loop_run(None, 0, screen, str(tmp_path)) for tag, screen in (("exact", None), ("settle", "f16"))}
+    assert want["exact"]["counts"][2] >= 1 and want["exact"]["sets"].size > 8, "test data must select queries and fine-tune"
+    assert np.array_equal(want["exact"]["sets"], want["settle"]["sets"]) and np.array_equal(want["exact"]["w"], want["settle"]["w"])
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    path = str(tmp_path / "%s_rank%d.npz")
+    for f in os.listdir(str(tmp_path)):
+        if f.endswith(".h5"):
+            os.remove(os.path.join(str(tmp_path), f))
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, path, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    for tag in ("exact", "settle"):
+        for r in range(2):
+            z = np.load(path % (tag, r))
+            assert np.array_equal(z["counts"], want[tag]["counts"]), (tag, r, z["counts"], want[tag]["counts"])
+            assert np.array_equal(z["sets"], want[tag]["sets"]), (tag, r)
+            assert np.array_equal(z["w"], want[tag]["w"]), (tag, r, np.abs(z["w"] - want[tag]["w"]).max())
+            assert bool(z["saved"][0]) == (r == 0), (tag, r)
+        z0, z1 = np.load(path % (tag, 0)), np.load(path % (tag, 1))
+        if tag == "settle":
+            assert (z0["rows"] > 0).all() and (np.abs(z0["rows"] - z1["rows"]) <= 1).all()
+    print("two ranks: per-iteration rows %s / %s; queries per iteration %s"
+          % (z0["rows"].tolist(), z1["rows"].tolist(), want["exact"]["sets"][:int(want["exact"]["counts"][1] > 0) * 3].tolist()))
+
+
+def test_multirank_alink_loop_on_a_one_rank_rccl_group(rccl_group, tmp_path):
+    """The same loop under "nccl" (= RCCL) with one rank: the collectives of distributed.RowShards are staged on the DEVICE
+    there (all_gather_into_tensor on device buffers, object collectives through the GPU) — the path an 8-GPU job takes —
+    and must leave the single-process results untouched."""
+    want = _loop_run(None, 0, "f16", str(tmp_path))
+    got = _loop_run(rccl_group.group.WORLD, 0, "f16", str(tmp_path))
+    assert np.array_equal(got["counts"], want["counts"]) and np.array_equal(got["sets"], want["sets"]) and np.array_equal(got["w"], want["w"])
+    assert (got["rows"] > 0).all()

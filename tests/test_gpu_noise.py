@@ -212,3 +212,99 @@ def test_pixel_attack_device_objective_equals_generic_route(gpu):
     pairs = [_imgs(2, 32, 32, 10), _imgs(2, 32, 32, 11)]
     l, r = adv.addPairNoise(pairs, np.array([[1], [0]]))
     assert np.asarray(l).shape == (2, 32, 32, 3) and np.asarray(r).shape == (2, 32, 32, 3)
+
+
+def test_row_ranges_draw_what_the_whole_batch_draws(gpu):
+    """One process per GPU (alink_loop with `group`): a rank perturbs rows lo : hi of the pair batch with rows=(lo, total) and
+    must get, bit for bit, rows lo : hi of the whole-batch call — for every noise class, both sides of the pair, odd image
+    sizes (element counts that are no multiple of 4) and an empty shard."""
+    from a_link_amd import noise as N
+    for size, classes in (((13, 11), ("gaussian", "speckle", "saltpepper", "poisson")), ((30, 30), ("perlin", "gaussian", "poisson"))):
+        n = 7
+        L = torch.from_numpy(_imgs(n, size[0], size[1], 1)).cuda()
+        R = torch.from_numpy(_imgs(n, size[0], size[1], 2, integer=False)).cuda()
+        for name in classes:
+            whole_obj = N.get_relevant_noise(name)(seed=123)
+            if name == "perlin":
+                whole_obj.octaves = (lambda row: [15, 10, 5])          # 30 x 30 test images
+            whole = whole_obj.addPairNoise([L, R], None)
+            for cuts in ((0, 3, 7), (0, 0, 1, 7), (0, 7)):
+                obj = N.get_relevant_noise(name)(seed=123)
+                if name == "perlin":
+                    obj.octaves = (lambda row: [15, 10, 5])
+                parts = [[], []]
+                for lo, hi in zip(cuts[:-1], cuts[1:]):
+                    o = N.get_relevant_noise(name)(seed=123)                       # every "rank" holds the same stream state
+                    if name == "perlin":
+                        o.octaves = (lambda row: [15, 10, 5])
+                    got = o.addPairNoise([L[lo:hi], R[lo:hi]], None, rows=(lo, n))
+                    assert o.stream_state() == whole_obj.stream_state(), name      # an empty shard consumes its calls too
+                    for s in (0, 1):
+                        parts[s].append(got[s])
+                for s in (0, 1):
+                    assert torch.equal(torch.cat(parts[s]), whole[s]), (name, size, cuts, s)
+
+
+def test_pgd_step_matches_numpy_bit_for_bit(gpu):
+    """alink_pgd_step (extension: FGSM / PGD) is an elementwise sign / clamp kernel: adv <- clip(clip(adv + step *
+    sign(grad), clean - eps, clean + eps), lo, hi) — every float32 operation is exact or correctly rounded, so NumPy's
+    float32 result is the device's, bit for bit; lengths that are no multiple of 4, zero and negative gradients, both
+    step signs, no pixel clip."""
+    lib = gpu.load()
+    rng = np.random.RandomState(0)
+    for n, step, eps, lo, hi in ((4096, 1.0, 4.0, 0.0, 255.0), (1003, -0.75, 2.5, 0.0, 255.0), (7, 2.0, 1.0, float("-inf"), float("inf")),
+                                 (1, 1.0, 4.0, 0.0, 255.0)):
+        clean = rng.randint(0, 256, n).astype(np.float32)
+        adv = (clean + rng.uniform(-eps, eps, n)).astype(np.float32)
+        grad = rng.randn(n).astype(np.float32)
+        grad[::5] = 0.0
+        grad[1::7] = -0.0
+        want = adv + np.float32(step) * np.sign(grad).astype(np.float32)           # fmaf(step, s, a) with s in {-1, 0, 1}: exact product
+        want = np.minimum(np.maximum(want, clean - np.float32(eps)), clean + np.float32(eps))
+        want = np.minimum(np.maximum(want, np.float32(lo)), np.float32(hi)).astype(np.float32)
+        a, c, g = torch.from_numpy(adv).cuda(), torch.from_numpy(clean).cuda(), torch.from_numpy(grad).cuda()
+        gpu.check(lib.alink_pgd_step(gpu.ptr(a), gpu.ptr(c), gpu.ptr(g), n, step, eps, lo, hi, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(a.cpu().numpy(), want), (n, step)
+    # buffers that are not 16-byte aligned (a chunk of an odd-sized batch: ADVICE r4) take the scalar form
+    base = torch.zeros(1003 + 3, device="cuda")
+    for off in (1, 2, 3):
+        n = 1000
+        clean = rng.randint(0, 256, n).astype(np.float32)
+        adv = (clean + rng.uniform(-3, 3, n)).astype(np.float32)
+        grad = rng.randn(n).astype(np.float32)
+        bufs = [torch.zeros(n + 4, device="cuda") for _ in range(3)]
+        views = [b[off:off + n] for b in bufs]
+        for v, h in zip(views, (adv, clean, grad)):
+            v.copy_(torch.from_numpy(h))
+        gpu.check(lib.alink_pgd_step(gpu.ptr(views[0]), gpu.ptr(views[1]), gpu.ptr(views[2]), n, 1.0, 3.0, 0.0, 255.0, None))
+        torch.cuda.synchronize()
+        want = np.minimum(np.maximum(np.minimum(np.maximum(adv + np.sign(grad).astype(np.float32), clean - np.float32(3)), clean + np.float32(3)),
+                                     np.float32(0)), np.float32(255))
+        assert np.array_equal(views[0].cpu().numpy(), want), off
+        assert float(bufs[0][:off].abs().max()) == 0.0 and float(bufs[0][off + n:].abs().max()) == 0.0
+    del base
+
+
+def test_few_pixel_attack_rows_are_independent_of_the_batch(gpu):
+    """noise.AdversarialNoise (code/noise.py:171-188 over code/attack.py:91-103): every pair's differential-evolution search
+    has its own random stream keyed by the pair's global row, so a rank that attacks rows lo : hi finds what the
+    whole-batch call finds for them (a short search here: 3 pixels, 3 generations)."""
+    from a_link_amd import noise as N, siamese
+    size = (32, 32)
+    conv = siamese.ArcFace(size, "synthetic:r18:3", dtype="bf16", screen_dtype=None)
+    student = siamese.SiameseNetwork((512,), "s", 0.1, seed=3)
+    rng = np.random.RandomState(0)
+    L = rng.randint(0, 256, (4,) + size + (3,)).astype(np.float32)
+    R = rng.randint(0, 256, (4,) + size + (3,)).astype(np.float32)
+    labels = np.array([0, 1, 1, 0])
+    kw = dict(pixel_count=3, maxiter=3, popsize=30)
+    whole = N.AdversarialNoise(student, None, conv, seed=9, **kw).addPairNoise([L, R], labels)
+    parts = [[], []]
+    for lo, hi in ((0, 1), (1, 4)):
+        got = N.AdversarialNoise(student, None, conv, seed=9, **kw).addPairNoise([L[lo:hi], R[lo:hi]], labels[lo:hi], rows=(lo, 4))
+        for s in (0, 1):
+            parts[s] += list(got[s])
+    for s in (0, 1):
+        assert np.array_equal(np.stack(parts[s]), np.stack(whole[s]))
+    assert not np.array_equal(np.stack(whole[0]), L) or not np.array_equal(np.stack(whole[1]), R)      # pixels were written
