@@ -57,10 +57,15 @@ def merge_topk(local_vals, local_global_idx, k, largest=True, group=None):
     dist = _dist()
     world = dist.get_world_size(group)
     dev = local_vals.device
+    if k <= 0:                          # the same k on every rank: nothing to exchange
+        return local_vals[:0].to(torch.float32), local_global_idx[:0].to(torch.int64)
     n = min(k, local_vals.numel())
     # preconditions (checked, not assumed): the exchange carries indices as int32, and "ties -> lower global index"
     # rests on every rank handing in its candidates best-first with ties in ascending index order, from a contiguous
-    # ascending shard (what shard_range + alink_topk produce)
+    # ascending shard (what shard_range + alink_topk produce).  A rank whose candidates fail does NOT raise before the
+    # collective (its peers would wait in the all-gather for ever): the failure code travels in its slot of the exchange
+    # and every rank raises the same ValueError after it.
+    code = 0
     if n:
         # ONE device reduction and ONE read-back for all of them (this runs once per pass of the config-3 path)
         gi = local_global_idx[:n].to(torch.int64)
@@ -70,23 +75,31 @@ def merge_topk(local_vals, local_global_idx, k, largest=True, group=None):
             worse = (v_[1:] > v_[:-1]) if largest else (v_[1:] < v_[:-1])          # comparisons, not differences: equal
             flags.append((worse | ((v_[1:] == v_[:-1]) & (gi[1:] <= gi[:-1]))).any())   # infinities must count as ties
         code = int((torch.stack(flags).to(torch.int32) * torch.tensor([1, 2, 4][:len(flags)], dtype=torch.int32, device=dev)).sum())
-        if code & 1:
-            raise ValueError("merge_topk: global pair indices must lie in [0, 2^31): shard the pool into passes of fewer pairs")
-        if code & 2:
-            raise ValueError("merge_topk: a candidate score is NaN (scores must be ordered: an embedding left the float16 "
-                             "range, or a head produced NaN)")
-        if code & 4:
-            raise ValueError("merge_topk: candidates must be sorted best-first with ties in ascending index order")
     pad = float("-inf") if largest else float("inf")
     mine = torch.empty((k, 2), dtype=torch.int32, device=dev)
     mine[:, 0] = torch.full((k,), pad, dtype=torch.float32, device=dev).view(torch.int32)
     mine[:, 1] = -1
-    if n:
+    if n and not code:
         mine[:n, 0] = local_vals[:n].to(torch.float32).contiguous().view(torch.int32)
         mine[:n, 1] = local_global_idx[:n].to(torch.int32)
+    if code:
+        mine[:, 1] = -2 - code              # index < -1: "this rank's candidates failed check `code`"
+
+    def raise_if_any_rank_failed(idx_col):
+        bad = int(idx_col.min())
+        if bad < -1:
+            c = -2 - bad
+            who = "this rank's" if code else "another rank's"
+            if c & 1:
+                raise ValueError("merge_topk (%s candidates): global pair indices must lie in [0, 2^31): shard the pool into passes of fewer pairs" % who)
+            if c & 2:
+                raise ValueError("merge_topk (%s candidates): a candidate score is NaN (scores must be ordered: an embedding left the "
+                                 "float16 range, or a head produced NaN)" % who)
+            raise ValueError("merge_topk (%s candidates): candidates must be sorted best-first with ties in ascending index order" % who)
     every = torch.empty((world * k, 2), dtype=torch.int32, device=dev)
     if dev.type == "cuda":
         dist.all_gather_into_tensor(every, mine, group=group)
+        raise_if_any_rank_failed(every[:, 1])
         from . import uncertainty as _unc
         vals_all = every[:, 0].contiguous().view(torch.float32)
         # padding entries (index -1) score the worst possible value; a REAL candidate with that same score (-inf / +inf)
@@ -100,7 +113,9 @@ def merge_topk(local_vals, local_global_idx, k, largest=True, group=None):
         return v, idx.to(torch.int64)
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine, group=group)
-    every = torch.cat(parts).numpy()
+    every = torch.cat(parts)
+    raise_if_any_rank_failed(every[:, 1])
+    every = every.numpy()
     v = every[:, 0].copy().view(np.float32)
     i = every[:, 1].astype(np.int64)
     keep = i >= 0
@@ -213,8 +228,55 @@ def committee_pool_topk(backbones, heads, pool_shard, gallery, k, shard_offset, 
     return vals, gidx
 
 
+def merge_calibration(backbones, group=None):
+    """Every rank's split-precision scales -> their elementwise MINIMUM on every rank (a scale only ever goes down when a
+    batch leaves its range: the minimum covers what every rank has seen).  For the moment after some rank re-calibrated
+    by itself; returns True if this rank's scales changed."""
+    dist = _dist()
+    mine = [bb.state() if hasattr(bb, "state") else None for bb in backbones]
+    every = [None] * dist.get_world_size(group)
+    dist.all_gather_object(every, mine, group=group)
+    changed = False
+    for i, bb in enumerate(backbones):
+        if not mine[i]:
+            continue
+        lowest = np.min(np.asarray([st[i]["scale_exponents"] for st in every], np.int64), axis=0)
+        if list(lowest) != list(mine[i]["scale_exponents"]):
+            bb.load_state(dict(mine[i], scale_exponents=[int(v) for v in lowest]))
+            changed = True
+    return changed
+
+
 def committee_pool_topk_settled(screen_backbones, exact_backbones, heads, pool_shard, gallery, k, shard_offset,
                                 kind="entropy", group=None, settle_selected=True, info=None, **settle_kw):
+    """_committee_pool_topk_settled under a calibration guard: the exact handles re-calibrate themselves when a
+    batch leaves the split-precision range, which changes the last bits of everything embedded afterwards — the gallery
+    (embedded first) and the rows settled later would then mix two sets of scales, silently.  The scales are compared
+    before and after; on a change (on ANY rank: one small all-reduce) the ranks take the elementwise minimum of their
+    scales and the pass runs ONCE more under them, gallery included; a second change raises.  info["recalibrated"]
+    says whether that happened."""
+    from . import settle as _settle
+    states = lambda: [bb.state() if hasattr(bb, "state") else None for bb in exact_backbones]
+    comm = _settle.make_comm(group)
+    inf = {}
+    for attempt in (0, 1):
+        before = states()
+        out = _committee_pool_topk_settled(screen_backbones, exact_backbones, heads, pool_shard, gallery, k, shard_offset,
+                                           kind=kind, group=group, settle_selected=settle_selected, info=inf, **dict(settle_kw))
+        changed = float(comm.sum([0.0 if states() == before else 1.0])[0]) > 0
+        if not changed:
+            inf["recalibrated"] = bool(attempt)
+            if info is not None:
+                info.update(inf)
+            return out
+        if comm.world > 1:
+            merge_calibration(exact_backbones, group)
+    raise RuntimeError("committee_pool_topk_settled: the exact backbones re-calibrated themselves in two passes in a row: "
+                       "calibrate() them on images like the pool's first")
+
+
+def _committee_pool_topk_settled(screen_backbones, exact_backbones, heads, pool_shard, gallery, k, shard_offset,
+                                 kind="entropy", group=None, settle_selected=True, info=None, **settle_kw):
     """committee_pool_topk with the SAME result (scores, order and indices equal the all-exact run's bit for bit when
     settle_selected, the same set otherwise) at close to the screening rate: screen-then-settle (settle.py).
     `screen_backbones[m]` / `exact_backbones[m]` are member m's backbone in the 16-bit screening mode and in the exact

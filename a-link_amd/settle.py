@@ -1,4 +1,5 @@
-"""settle — screen-then-settle: selection sets IDENTICAL to the exact arithmetic's at close to the screening rate.
+"""settle — screen-then-settle: the exact arithmetic's selection sets at close to the screening rate — identical on every
+workload measured, under an error bound that is MEASURED (never assumed) and guarded by a sampled audit; not a theorem.
 
 The reference makes every selection from float32 probabilities (code/face_model.py:86-93 embeds in float32) with a
 handful of threshold / rank cuts: the committee's top-n most uncertain pairs (code/uncertainty.py:133-217 through
@@ -19,10 +20,20 @@ which turns over every pair that sits that close to a cut.  Only those pairs nee
                 pairs around the cut are exact the cut itself is, and the band that remains is one delta wide, not
                 two), re-score those pairs, repeat from 2 until nothing is uncertain.
 
-The result is the exact path's: members of the selected set are either settled (their exact scores rank them, with the
-exact path's own tie rule) or certain by interval.  With settle_selected=True every member is settled, and scores,
-order and indices equal the all-exact run bit for bit (the exact kernels are batch-invariant: an image embeds and a
-pair scores to the same bits whatever batch it arrives in).
+    5. AUDIT    the bound of step 2 is a sample maximum over the pairs NEAREST the cut; a pair far from the cut whose own
+                error exceeds both delta and its distance to the cut would keep the wrong side unseen.  So once nothing is
+                uncertain, a seeded UNIFORM sample of m never-settled units (images / (pair, noise) rows) is settled too:
+                an error above the largest seen so far widens delta and re-opens the resolution (and the audit), until a
+                sample shows none.  What that proves is statistical: no exceedance in m samples => the fraction of
+                unsettled units whose error exceeds the largest error seen lies below 3 / m at 95 % confidence (rule of
+                three; m = 300: below 1 %).  A single outlier among thousands can still go unseen (the CPU tests plant
+                one and show both outcomes); `info["audit"]` reports m, the largest audited error and the exceedances.
+
+What comes out is the exact path's result under that bound: members of the selected set are either settled (their exact
+scores rank them, with the exact path's own tie rule) or certain by interval.  With settle_selected=True every member is
+settled, and — on every workload measured (tests/, bench.py compare in the run) — scores, order and indices equal the
+all-exact run bit for bit (the exact kernels are batch-invariant: an image embeds and a pair scores to the same bits
+whatever batch it arrives in).
 
 Everything here is host logic on NumPy arrays (P is 200 k pairs per GPU at BASELINE configs[2]); the arithmetic — the
 two embedding modes, the pair heads, the uncertainty scores — runs in libalink_hip.so behind the callbacks the callers
@@ -167,6 +178,8 @@ def topk_undetermined(lo, hi, k, largest=True, comm=None, base=0):
         lo, hi = -hi, -lo
     P = len(lo)
     in_T = np.zeros(P, bool)
+    if k <= 0:                  # an empty selection: nothing is in it, nothing can enter it, nothing to settle (on any rank)
+        return in_T, in_T.copy(), in_T.copy(), float("inf"), float("-inf")
     order = _local_topk(lo, min(k, P)) if k > 0 else np.zeros(0, np.int64)
     gv, gi = comm.topk(lo[order], order.astype(np.int64) + int(base), k, largest=True)
     mine = gi[(gi >= base) & (gi < base + P)] - base
@@ -198,8 +211,29 @@ class ErrorBound(object):
         return self.delta
 
 
+AUDIT_DEFAULT = None        # audit sample size: None = auto (below); an int = that many units; 0 = no audit
+
+
+def audit_size(audit, unsettled):
+    """Units of one audit pass.  Auto: 2 % of the never-settled units, at least 32 and at most 300 (no exceedance in 300
+    samples => fewer than 1 % of the unsettled lie beyond the bound, at 95 %): a cost of a few per cent of the screening pass
+    whatever the workload's size."""
+    if audit is None:
+        return int(min(300, max(32, np.ceil(0.02 * unsettled))))
+    return int(audit)
+
+
+def _audit_pick(candidates, m, seed, salt):
+    """m of `candidates` (ascending positions), uniformly without replacement, from a stream of its own"""
+    if m <= 0 or len(candidates) == 0:
+        return np.zeros(0, np.int64)
+    rs = np.random.RandomState([int(seed) & 0x7FFFFFFF, int(salt) & 0x7FFFFFFF, 0x5E771E])
+    return np.sort(rs.choice(candidates, min(int(m), len(candidates)), replace=False))
+
+
 def settle_topk(p_screen, score_screen, owner, n_owner, exact_fn, k, kind="entropy", largest=True, comm=None, base=0,
-                safety=1.5, delta0=0.0, min_sample=64, stage_above=584, settle_selected=True, max_rounds=24):
+                safety=1.5, delta0=0.0, min_sample=64, stage_above=584, settle_selected=True, max_rounds=24,
+                audit=AUDIT_DEFAULT, audit_seed=0):
     """The exact top-k of `kind` over this rank's pairs, from screened probabilities.
 
     p_screen      (P,) first-column probability of every pair from the SCREENING embeddings
@@ -207,9 +241,17 @@ def settle_topk(p_screen, score_screen, owner, n_owner, exact_fn, k, kind="entro
     owner         (P,) int: the image that owns each pair — settling is per image (all of its pairs at once)
     exact_fn      f(sorted image indices) -> (pair positions, exact p0, exact float32 score): re-embeds those images in
                   the exact mode and re-scores every pair they own
-    Returns (vals float32, global index int64, info).  info: images settled, rounds, delta, d_max, widened.
+    audit         images of the uniform audit sample per pass, over all ranks (None: audit_size()'s choice; 0: no audit — the
+                  bound then rests on the pairs nearest the cut alone); audit_seed: its stream
+    Returns (vals float32, global index int64, info).  info: images settled, rounds, delta, d_max, widened, audit.
+    An error on one rank (the exact mode returning a non-finite value, exact_fn raising) is raised on EVERY rank: the flag
+    travels in the round's all-reduce, so no rank is left waiting in a collective.
     """
     comm = comm or LocalComm()
+    if k <= 0:
+        return (np.zeros(0, np.float32), np.zeros(0, np.int64),
+                {"images": int(n_owner), "images_settled": 0, "pairs": int(len(p_screen)), "rounds": 0, "delta": float(delta0),
+                 "d_max": 0.0, "widened": 0, "members_unsettled": 0, "audit": None})
     p_screen = np.asarray(p_screen, np.float64)
     P = len(p_screen)
     owner = np.asarray(owner, np.int64)
@@ -218,9 +260,40 @@ def settle_topk(p_screen, score_screen, owner, n_owner, exact_fn, k, kind="entro
     img_settled = np.zeros(int(n_owner), bool)
     bound = ErrorBound(delta0, safety)
     rounds = 0
+    aud = {"m": 0, "passes": 0, "max_err": 0.0, "exceedances": 0}
     # a screened probability that is not finite (a 16-bit forward that left its range) says nothing: such a pair can be anywhere
     unknown = ~np.isfinite(p_screen)
     p_screen = np.where(unknown, 0.5, p_screen)
+
+    def settle_images(imgs, thr=None):
+        """exact_fn on `imgs` (may be empty); returns (largest |exact - screened| among them, error text or None, number
+        of these images with a pair whose error exceeds `thr`)"""
+        if not len(imgs):
+            return 0.0, None, 0
+        try:
+            pos, p_x, s_x = exact_fn(imgs)
+            pos = np.asarray(pos, np.int64)
+            p_x, s_x = np.asarray(p_x, np.float64), np.asarray(s_x, np.float32)
+            if not (np.isfinite(p_x).all() and np.isfinite(s_x).all()):
+                return 0.0, "the exact mode returned a non-finite probability or score", 0
+        except Exception as e:              # raised together on every rank below
+            return 0.0, "%s: %s" % (type(e).__name__, e), 0
+        known = ~unknown[pos]
+        dd = np.where(known, np.abs(p_x - p_screen[pos]), 0.0)
+        d = float(dd.max()) if len(dd) else 0.0
+        over = int(len(np.unique(owner[pos][dd > thr]))) if thr is not None else 0
+        val[pos] = s_x
+        pair_settled[pos] = True
+        img_settled[imgs] = True
+        return d, None, over
+
+    def agree(d_loc, err):
+        """one all-reduce: the largest error seen on any rank + whether any rank failed"""
+        got = comm.max([d_loc, 1.0 if err else 0.0])
+        if got[1] > 0:
+            raise RuntimeError("settle_topk: %s" % (err or "another rank failed while settling (its own message says why)"))
+        return float(got[0])
+
     while True:
         lo, hi = binary_score_interval(p_screen, bound.delta, kind)
         lo = np.where(unknown, _NEG, lo)
@@ -258,22 +331,35 @@ def settle_topk(p_screen, score_screen, owner, n_owner, exact_fn, k, kind="entro
             imgs = np.sort(imgs)
         todo = float(comm.sum([len(imgs)])[0])
         if todo == 0:
-            break
+            # nothing is uncertain under the bound measured so far — on the pairs nearest the cut.  AUDIT it on a uniform
+            # sample of the images never settled; an error above the largest seen widens the bound and re-opens the resolution
+            if audit is not None and audit <= 0:
+                break
+            cand = np.flatnonzero(~img_settled)
+            left = float(comm.sum([len(cand)])[0])
+            if left == 0:
+                break
+            share = int(np.ceil(audit_size(audit, left) * len(cand) / left)) if len(cand) else 0       # this rank's part of the sample
+            pick = _audit_pick(cand, share, audit_seed, int(base) + 7919 * aud["passes"])
+            d_loc, err, over = settle_images(pick, thr=bound.d_max)
+            d_aud = agree(d_loc, err)
+            tot = comm.sum([len(pick), over])
+            aud["m"] += int(tot[0])
+            aud["passes"] += 1
+            aud["max_err"] = max(aud["max_err"], d_aud)
+            aud["exceedances"] += int(tot[1])
+            held = bound.delta
+            bound.observe(d_aud)
+            rounds += 1
+            if bound.delta == held:
+                break                   # the sample showed nothing beyond what the bound already covers: the determination stands
+            if rounds >= max_rounds:
+                raise RuntimeError("settle_topk: the audit kept widening the bound (%d rounds, delta %.3g)" % (rounds, bound.delta))
+            continue
         if rounds >= max_rounds:
             raise RuntimeError("settle_topk: %d images still undetermined after %d rounds (delta %.3g)" % (todo, rounds, bound.delta))
-        d_loc = 0.0
-        if len(imgs):
-            pos, p_x, s_x = exact_fn(imgs)
-            pos = np.asarray(pos, np.int64)
-            p_x, s_x = np.asarray(p_x, np.float64), np.asarray(s_x, np.float32)
-            if not (np.isfinite(p_x).all() and np.isfinite(s_x).all()):
-                raise RuntimeError("settle_topk: the exact mode returned a non-finite probability or score")
-            known = ~unknown[pos]
-            d_loc = float(np.abs(p_x[known] - p_screen[pos][known]).max()) if known.any() else 0.0
-            val[pos] = s_x
-            pair_settled[pos] = True
-            img_settled[imgs] = True
-        bound.observe(float(comm.max([d_loc])[0]))
+        d_loc, err, _ = settle_images(imgs)
+        bound.observe(agree(d_loc, err))
         rounds += 1
     # every member of T is settled or certain; non-members never outrank one.  Hand the candidate exchange T itself.
     cand = np.flatnonzero(in_T)
@@ -282,7 +368,9 @@ def settle_topk(p_screen, score_screen, owner, n_owner, exact_fn, k, kind="entro
     vals, gidx = comm.topk(val[order], order.astype(np.int64) + int(base), k, largest=largest)
     info = {"images": int(n_owner), "images_settled": int(img_settled.sum()), "pairs": int(P), "rounds": rounds,
             "delta": bound.delta, "d_max": bound.d_max, "widened": bound.widened,
-            "members_unsettled": int((in_T & ~pair_settled).sum())}
+            "members_unsettled": int((in_T & ~pair_settled).sum()),
+            "audit": dict(aud, unit="image", claim="no exceedance in m uniform samples => fraction of never-settled images whose error "
+                                                   "exceeds the largest error seen < 3/m at 95 %") if (audit is None or audit > 0) else None}
     return vals, gidx, info
 
 
@@ -299,7 +387,7 @@ def _disparity_interval(m, e, delta):
 
 def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, settle_fn, col=0, disparity_ratio=0.25,
                            eps=0.05, blind_strategy=False, safety=1.5, delta0=0.0, min_sample=32, max_rounds=24,
-                           settle_many=None):
+                           settle_many=None, audit=AUDIT_DEFAULT, audit_seed=0):
     """selection.select_queries with the noisy passes SCREENED: the clean pass (`ensemblePredictions`, every unique image
     of the mini-batch once: a few dozen embeddings) is exact, the 2 P n_noise noisy pair occurrences — the bulk of an
     iteration's embeddings — were embedded in the 16-bit mode, and `settle_fn(k, pairs)` returns the
@@ -311,7 +399,10 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
     is exact.  Returns (queryIndices ascending, active_count, labels, disguisedPredictions with the settled rows exact,
     settled masks per noise, info) — queryIndices / active_count / labels equal selection.select_queries on all-exact
     predictions.  settle_many (optional): f([(k, pairs), ...]) -> [predictions, ...] — a whole round's requests in ONE
-    call, so that the caller can embed them as one batch (a round asks for a few dozen to a few hundred pairs per noise)."""
+    call, so that the caller can embed them as one batch (a round asks for a few dozen to a few hundred pairs per noise).
+    audit / audit_seed: once nothing is uncertain, a seeded uniform sample of never-settled (pair, noise) rows is settled
+    as well (module header, step 5); an error above the largest seen widens the bound and re-opens the resolution.
+    info["audit"] = {m, passes, max_err, exceedances}."""
     from .helpers import roundoff
     ens = np.asarray(ensemblePredictions)
     P = len(ens)
@@ -330,11 +421,14 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
     rounds = 0
     n_settled = 0
 
-    state = {"d": 0.0}
+    state = {"d": 0.0, "over": 0}
+    aud = {"m": 0, "passes": 0, "max_err": 0.0, "exceedances": 0}
 
-    def settle_all(requests):
-        """requests: [(k, pair indices)] — drop what is settled already, ask for the rest in one call"""
+    def settle_all(requests, thr=None):
+        """requests: [(k, pair indices)] — drop what is settled already, ask for the rest in one call.  Returns the largest
+        |exact - screened| among THESE rows (state["d"] keeps the largest ever) and counts the rows beyond `thr`."""
         nonlocal n_settled
+        worst = 0.0
         todo = []
         for k, idx in requests:
             idx = np.asarray(sorted(set(int(i) for i in idx)), np.int64)
@@ -342,7 +436,7 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
             if len(idx):
                 todo.append((k, idx))
         if not todo:
-            return
+            return worst
         got = settle_many(todo) if settle_many is not None else [settle_fn(k, idx) for k, idx in todo]
         for (k, idx), px in zip(todo, got):
             px = np.asarray(px, np.float32)
@@ -350,10 +444,15 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
                 raise RuntimeError("select_queries_settled: the exact mode returned a non-finite prediction")
             known = ~unknown[k][idx]
             if known.any():
-                state["d"] = max(state["d"], float(np.abs(px[known, col].astype(np.float64) - scr[k][idx][known]).max()))
+                dd = np.abs(px[known, col].astype(np.float64) - scr[k][idx][known])
+                worst = max(worst, float(dd.max()))
+                if thr is not None:
+                    state["over"] += int((dd > thr).sum())
             dis[k][idx] = px
             settled[k][idx] = True
             n_settled += len(idx)
+        state["d"] = max(state["d"], worst)
+        return worst
 
     def membership():
         """per noise: (member mask by the pessimistic rule, pairs settling can help, pairs whose own side is uncertain,
@@ -371,7 +470,7 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
             lo, hi = np.where(unknown[k], np.float32(0), lo), np.where(unknown[k], _POS, hi)
             lo = np.where(settled[k], d_exact, lo)
             hi = np.where(settled[k], d_exact, hi)
-            in_T, need, und, a, b = topk_undetermined(lo, hi, K, largest=True)
+            in_T, need, und, a, b = topk_undetermined(lo, hi, K, largest=True)       # K == 0: nothing selected, nothing to settle
             mid = 0.5 * (a + b) if np.isfinite(a) and np.isfinite(b) else 0.0
             with np.errstate(invalid="ignore"):
                 centre = 0.5 * (lo.astype(np.float64) + hi)
@@ -427,9 +526,31 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
         before = n_settled
         settle_all([(i, queryIndices[i * mp:(i + 1) * mp]) for i in range(n_noise)])
         held = bound.delta
-        if n_settled == before or bound.observe(state["d"]) == held:
-            break             # the bound did not move: the determination above stands (points only replaced intervals)
+        if n_settled != before and bound.observe(state["d"]) != held:
+            continue          # the selected rows' own errors widened the bound: resolve again
+        # the determination stands under the bound measured so far — on the rows nearest the cuts and the selected ones.
+        # AUDIT it on a uniform sample of the (pair, noise) rows never settled (module header, step 5)
+        if (audit is not None and audit <= 0) or n_noise == 0:
+            break
+        flat = np.flatnonzero(~np.concatenate(settled))                         # position k * P + j
+        if len(flat) == 0:
+            break
+        pick = _audit_pick(flat, audit_size(audit, len(flat)), audit_seed, 7919 * aud["passes"] + P)
+        state["over"] = 0
+        d_aud = settle_all([(k, pick[(pick >= k * P) & (pick < (k + 1) * P)] - k * P) for k in range(n_noise)], thr=bound.d_max)
+        aud["m"] += len(pick)
+        aud["passes"] += 1
+        aud["max_err"] = max(aud["max_err"], d_aud)
+        aud["exceedances"] += state["over"]
+        rounds += 1
+        if bound.observe(state["d"]) == held:
+            break             # the sample showed nothing beyond what the bound already covers
+        if rounds > max_rounds:
+            raise RuntimeError("select_queries_settled: the audit kept widening the bound (%d rounds, delta %.3g)" % (rounds, bound.delta))
     labels = roundoff(ens[queryIndices, col]) if queryIndices else np.zeros((0, 1), dtype=int)
     info = {"pairs": P, "noises": n_noise, "pair_noise_settled": int(n_settled), "fraction_settled": n_settled / float(max(P * n_noise, 1)),
-            "rounds": rounds, "delta": bound.delta, "d_max": bound.d_max, "widened": bound.widened}
+            "rounds": rounds, "delta": bound.delta, "d_max": bound.d_max, "widened": bound.widened,
+            "audit": dict(aud, unit="(pair, noise) row", claim="no exceedance in m uniform samples => fraction of never-settled rows whose "
+                                                                "error exceeds the largest error seen < 3/m at 95 %")
+                     if (audit is None or audit > 0) else None}
     return queryIndices, active, labels, dis, settled, info

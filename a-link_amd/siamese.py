@@ -245,26 +245,35 @@ class ArcFace:
         # fit its range (the fastest and finest), else f16x2/1 (exact model in split precision) or bf16.  Not in the reference.
         # Default: "auto" when the model is the exact one (split precision) — `process` and every result stay the exact mode's, the
         # framework loop just reaches them ~2x sooner; None / False builds no screening form.
-        self.screen = None
+        # The screening handle is built LAZILY, on the first process_screen / backbones() / .screen access: a caller that
+        # only ever calls process() (the reference's API) pays for one network, not two.
         if screen_dtype == "default":
             screen_dtype = "auto" if (self.model.model.dtype == "f16x2" and not enable_grad) else None
-        if screen_dtype:
-            exact = self.model.model
+        self._screen_dtype, self._screen_args, self._screen = (screen_dtype or None), args, None
+        if self._screen_dtype:
+            self.process_screen = self._process_screen
+
+    @property
+    def screen(self):
+        """the screening form (None when the model has none); built on first use"""
+        if self._screen is None and self._screen_dtype:
+            screen_dtype, args, exact = self._screen_dtype, self._screen_args, self.model.model
             if screen_dtype == "auto":
                 from ._abi import AlinkError
                 cand = face_model.FaceModel(_Args(dict(args, dtype="f16")))
                 try:                                   # do the probe images (uniform noise, black, white) fit plain f16?
                     cand.model.embed_device(cand.model._probe_images())
-                    self.screen = cand
+                    self._screen = cand
                 except AlinkError:
                     del cand
                     screen_dtype = "f16x2/1" if exact.dtype == "f16x2" else "bf16"
-            if screen_dtype == "f16x2/1":
-                view = exact.screening_view()
-                self.screen = _Args({"model": view, "get_features": view.embed})
-            elif self.screen is None:
-                self.screen = face_model.FaceModel(_Args(dict(args, dtype=screen_dtype)))
-            self.process_screen = self._process_screen
+            if self._screen is None:
+                if screen_dtype == "f16x2/1":
+                    view = exact.screening_view()
+                    self._screen = _Args({"model": view, "get_features": view.embed})
+                else:
+                    self._screen = face_model.FaceModel(_Args(dict(args, dtype=screen_dtype)))
+        return self._screen
 
     def backbones(self):
         """(screening IRBackbone or None, exact IRBackbone): what distributed.committee_pool_topk_settled takes"""

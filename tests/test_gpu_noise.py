@@ -205,10 +205,7 @@ def test_pixel_attack_device_objective_equals_generic_route(gpu):
     assert after[0] >= before[0] - 1e-6
     assert abs((1 - after[0]) - att.last_result.fun) < 1e-5
     # AdversarialNoise end to end on two pairs
-    adv = N.AdversarialNoise(pm, None, fm)
-    adv.attacker = A.PixelAttacker(adv.e2e_model, seed=np.random.RandomState(2))
-    orig_all = adv.attacker.attack_all
-    adv.attacker.attack_all = lambda data, t, dimensions: orig_all(data, t, dimensions, pixel_count=3, maxiter=2, popsize=15)
+    adv = N.AdversarialNoise(pm, None, fm, seed=2, pixel_count=3, maxiter=2, popsize=15)
     pairs = [_imgs(2, 32, 32, 10), _imgs(2, 32, 32, 11)]
     l, r = adv.addPairNoise(pairs, np.array([[1], [0]]))
     assert np.asarray(l).shape == (2, 32, 32, 3) and np.asarray(r).shape == (2, 32, 32, 3)
