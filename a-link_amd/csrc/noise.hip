@@ -197,34 +197,120 @@ __global__ void perlin_vectors_kernel(float* __restrict__ vec, long long n, unsi
 
 // ---- Poisson (code/noise.py:72-76) -------------------------------------------------------------------
 // vals = 2^ceil(log2(number of unique values of the image)); out = Poisson(x * vals) / vals.
-// Pass 1 counts the unique values of every image exactly with an open-addressing hash set of the
-// float bit patterns in caller scratch (one table per image); pass 2 samples: lam < 10 by the
-// product-of-uniforms method, lam >= 10 by Hörmann's transformed rejection (PTRS) — the two methods
-// numpy's legacy generator uses — in double precision (lam reaches 255 * 65536).
+//
+// Pass 1 (unique_count_kernel, one 1024-thread workgroup per image, everything on chip): images reaching this noise are
+// mostly integer-valued 0..255 (PIL -> float32, code/readDFW.py:82): every lane marks seen[(int)x] with a plain LDS store
+// (all writers store 1: no atomic) and the count is the number of marks — one streaming read, no global atomic.  An
+// image with any other value (a bilinear resize makes them, code/readDFW.py:82) is counted EXACTLY by an open-addressing
+// hash set of the float bit patterns in LDS (32768 slots = 128 KiB, `ds_cmpst` probes), the key space cut into 2^p parts by
+// hash bits so that a part's load stays below 1/2; the image is re-read once per part (from L2).  Round 4's form kept the
+// table in global memory (512 KiB of caller scratch per image, one L2 atomic per element): 1.5-2.2 ms per 1,024 images.
+// Pass 2 (poisson_kernel) samples: lam < 10 by the product-of-uniforms method, lam >= 10 by Hörmann's transformed
+// rejection (PTRS) — the two methods numpy's legacy generator uses.  Round 5: for lam < 2^24 (x <= 255 with vals <= 65536:
+// every image the loop produces) PTRS runs in FLOAT32 — lam = x * vals is exact there, the proposal
+// k = floor(lam) + floor((2a/us + b) U + frac(lam) + 0.43) is formed without ever adding a small number to a large one, and
+// the acceptance test compares V invalpha / (a / us^2 + b) with the Poisson pmf written without cancellation:
+//   log pmf(k; lam) = -lam h(d / lam) - log sqrt(2 pi k) - 1/(12 k) + 1/(360 k^3),  d = k - lam,
+//   h(x) = (1 + x) log(1 + x) - x = x^2 (1/2 - x/6 + x^2/12 - ...)          (Stirling; exact table of log k! below k = 8)
+// so float32's hardware sqrt / rcp / exp / log (1 ulp) serve where float64 needed ~40-instruction software sequences:
+// the float64 sampler ran at 0.19 TB/s.  The setup and the proposal use correctly rounded operations only (__fsqrt_rn,
+// __fdiv_rn, no contraction), so the CPU oracle reproduces k bit for bit except where an acceptance test lands within
+// ~1e-6 of equality.  lam >= 2^24 keeps the float64 form.
 struct UniqueP {
     const float* in;
-    unsigned int* table;      // [n_images][slots], 0xFFFFFFFF = empty
-    unsigned int* count;      // [n_images]
+    unsigned int* count;      // [n_images] number of unique values
+    float* vals_out;          // optional [n_images]: 2^ceil(log2(count))
     long long per;
-    unsigned int slots;       // power of two >= 2 * per
+    int parts_log2;           // hash parts of the general path
 };
 
-__global__ __launch_bounds__(256) void unique_count_kernel(const UniqueP p) {
-    const int img = blockIdx.y;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.per) return;
-    float x = p.in[img * p.per + i];
-    if (x == 0.f) x = 0.f;                                   // -0.0 == 0.0 for np.unique
+constexpr int kSeen = 256;
+constexpr unsigned int kHashSlots = 32768;
+constexpr unsigned int kEmpty = 0xFFFFFFFFu;
+
+__device__ __forceinline__ unsigned int float_key(float x) {
+    if (x == 0.f) x = 0.f;                                    // -0.0 == 0.0 for np.unique
     unsigned int key = __float_as_uint(x);
-    if (key == 0xFFFFFFFFu) key = 0x7FC00000u;               // a NaN pattern that collides with "empty"
-    unsigned int* tab = p.table + (size_t)img * p.slots;
-    unsigned int h = (key * 2654435761u) >> 7;
-    for (;;) {
-        h &= p.slots - 1;
-        const unsigned int old = atomicCAS(&tab[h], 0xFFFFFFFFu, key);
-        if (old == 0xFFFFFFFFu) { atomicAdd(&p.count[img], 1u); return; }
-        if (old == key) return;
-        ++h;
+    if (key == kEmpty) key = 0x7FC00000u;                     // a NaN pattern that collides with "empty"
+    return key;
+}
+
+__global__ __launch_bounds__(1024) void unique_count_kernel(const UniqueP p) {
+    extern __shared__ unsigned int lds[];                     // [kSeen] marks, [4] scalars, [kHashSlots] table
+    unsigned int* seen = lds;
+    unsigned int* scal = lds + kSeen;                         // 0: not-all-integers flag, 1: count, 2: probe overflow
+    unsigned int* tab = lds + kSeen + 4;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const float* src = p.in + (size_t)img * p.per;
+    if (tid < kSeen) seen[tid] = 0;
+    if (tid < 4) scal[tid] = 0;
+    __syncthreads();
+    // ---- integer path: one streaming read, plain LDS stores
+    bool other = false;
+    const long long per4 = ((((uintptr_t)src) & 15) == 0) ? p.per / 4 : 0;
+    for (long long i = tid; i < per4; i += 1024) {
+        const f32x4 v = *(const f32x4*)(src + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = v[j];
+            const int q = (int)x;
+            if (x >= 0.f && x <= 255.f && (float)q == x) seen[q] = 1; else other = true;
+        }
+    }
+    for (long long i = 4 * per4 + tid; i < p.per; i += 1024) {
+        const float x = src[i];
+        const int q = (int)x;
+        if (x >= 0.f && x <= 255.f && (float)q == x) seen[q] = 1; else other = true;
+    }
+    if (other) scal[0] = 1;
+    __syncthreads();
+    if (scal[0] == 0) {
+        if (tid < kSeen && seen[tid]) atomicAdd(&scal[1], 1u);
+        __syncthreads();
+    } else {
+        // ---- general path: exact count of distinct bit patterns, one hash part at a time
+        const int parts = 1 << p.parts_log2;
+        unsigned int mine = 0;
+        for (int part = 0; part < parts; ++part) {
+            for (unsigned int s = tid; s < kHashSlots; s += 1024) tab[s] = kEmpty;
+            __syncthreads();
+            for (long long i = tid; i < p.per; i += 1024) {
+                const unsigned int key = float_key(src[i]);
+                const unsigned int h = key * 2654435761u;
+                if ((int)(h >> (32 - p.parts_log2 - 1) >> 1) != part && p.parts_log2) continue;      // top parts_log2 bits
+                unsigned int slot = (h >> 2) & (kHashSlots - 1);
+                for (unsigned int probes = 0;; ++probes) {
+                    const unsigned int old = atomicCAS(&tab[slot], kEmpty, key);
+                    if (old == kEmpty) { ++mine; break; }
+                    if (old == key) break;
+                    if (probes >= kHashSlots) { scal[2] = 1; break; }     // a part that does not fit: never hang, see below
+                    slot = (slot + 1) & (kHashSlots - 1);
+                }
+            }
+            __syncthreads();
+        }
+        if (scal[2]) {
+            // a hash part overflowed the table (an adversarial set of bit patterns: never seen) — count by brute force
+            // instead: an element counts if no earlier element equals it.  Slow (per^2 / 1024 compares per lane) but exact.
+            mine = 0;
+            for (long long i = tid; i < p.per; i += 1024) {
+                const unsigned int key = float_key(src[i]);
+                bool first = true;
+                for (long long j = 0; j < i && first; ++j) first = float_key(src[j]) != key;
+                mine += first ? 1u : 0u;
+            }
+        }
+        if (mine) atomicAdd(&scal[1], mine);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const unsigned int c = scal[1];
+        p.count[img] = c;
+        if (p.vals_out) {
+            unsigned int v = 1;                              // vals = 2 ** np.ceil(np.log2(n_unique))
+            while (v < c) v <<= 1;
+            p.vals_out[img] = (float)v;
+        }
     }
 }
 
@@ -234,11 +320,12 @@ struct PoissonP {
     const float* in;
     float* out;
     const unsigned int* count;   // unique values per image
-    float* vals_out;             // optional [n_images]
+    unsigned char* rest;         // [n_images][workgroups per image]: left to poisson_rest_kernel
     long long per;
     unsigned long long seed, first_image;
 };
 
+// float64 form (lam < 10: product of uniforms; lam >= 2^24: PTRS)
 __device__ double poisson_sample(double lam, unsigned long long seed, unsigned long long elem) {
     if (!(lam >= 0.0)) return __longlong_as_double(0x7FF8000000000000ll);     // numpy raises for lam < 0
     if (lam == 0.0) return 0.0;
@@ -276,16 +363,117 @@ __device__ double poisson_sample(double lam, unsigned long long seed, unsigned l
     }
 }
 
+// log(k!) for k < 8 (float32)
+__device__ __forceinline__ float small_logfact(int k) {
+    const float t[8] = {0.f, 0.f, 0.6931471806f, 1.791759469f, 3.178053830f, 4.787491743f, 6.579251212f, 8.525161361f};
+    float v = t[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) v = (k == i) ? t[i] : v;
+    return v;
+}
+
+// float32 PTRS for 10 <= lam < 2^24 (header above).  Returns the count as a double: Li + kf can exceed 2^24 by a hair.
+__device__ __forceinline__ double poisson_ptrs_f32(float lam, unsigned long long seed, unsigned long long elem) {
+    // setup and proposal: correctly rounded single operations, in this order (the oracle repeats them in NumPy float32)
+    const float slam = __fsqrt_rn(lam);
+    const float b = __fadd_rn(0.931f, __fmul_rn(2.53f, slam));
+    const float a = __fadd_rn(-0.059f, __fmul_rn(0.02483f, b));
+    const float invalpha = __fadd_rn(1.1239f, __fdiv_rn(1.1328f, __fsub_rn(b, 3.4f)));
+    const float vr = __fsub_rn(0.9277f, __fdiv_rn(3.6224f, __fsub_rn(b, 2.0f)));
+    const float Li = floorf(lam);
+    const float Lf043 = __fadd_rn(__fsub_rn(lam, Li), 0.43f);
+    const float a2 = __fmul_rn(2.0f, a);
+    const float inv_lam = 1.0f / lam;
+    unsigned int sub = 0;
+    for (;;) {
+        const U4 r = draw(seed, elem, sub++, ST_POISSON);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const float U = __fsub_rn(u01(half ? r.z : r.x), 0.5f);
+            const float V = u01(half ? r.w : r.y);
+            const float us = __fsub_rn(0.5f, fabsf(U));
+            const float kf = floorf(__fadd_rn(__fmul_rn(__fadd_rn(__fdiv_rn(a2, us), b), U), Lf043));     // k - floor(lam)
+            if (us >= 0.07f && V <= vr) return (double)Li + (double)kf;
+            const float k = Li + kf;                                   // the acceptance test may round it
+            if (k < 0.f || (us < 0.013f && V > us)) continue;
+            // V invalpha / (a / us^2 + b) <= pmf(k; lam), pmf without cancellation (header)
+            const float us2 = us * us;
+            const float lhs = V * invalpha * us2 / (a + b * us2);
+            float logp;
+            if (k < 8.f) {
+                logp = -lam + k * __logf(lam) - small_logfact((int)k);
+            } else {
+                const float d = kf - (lam - Li);                       // k - lam
+                const float x = d * inv_lam;
+                float h;                                               // (1 + x) log(1 + x) - x
+                if (fabsf(x) < 0.125f) {
+                    float s = -1.f / 110.f;                            // x^2 (1/2 - x/6 + x^2/12 - ... + x^8/90 - x^9/110)
+                    s = fmaf(s, x, 1.f / 90.f);
+                    s = fmaf(s, x, -1.f / 72.f);
+                    s = fmaf(s, x, 1.f / 56.f);
+                    s = fmaf(s, x, -1.f / 42.f);
+                    s = fmaf(s, x, 1.f / 30.f);
+                    s = fmaf(s, x, -1.f / 20.f);
+                    s = fmaf(s, x, 1.f / 12.f);
+                    s = fmaf(s, x, -1.f / 6.f);
+                    s = fmaf(s, x, 0.5f);
+                    h = s * x * x;
+                } else {
+                    h = (1.f + x) * log1pf(x) - x;
+                }
+                const float rk = 1.0f / k;
+                logp = -lam * h - 0.5f * __logf(6.283185307179586f * k) - rk * (1.f / 12.f) + rk * rk * rk * (1.f / 360.f);
+            }
+            if (__logf(lhs) <= logp) return (double)Li + (double)kf;
+        }
+    }
+}
+
+// 256 elements per workgroup.  A workgroup in which every element is 0 or in the float32 sampler's range (all of them,
+// for an ordinary image) samples here; one with any other element (lam < 10, lam >= 2^24, negative, NaN) writes nothing
+// and raises its flag: poisson_rest_kernel — the float64 code, 166 registers — takes such workgroups whole, so that
+// this kernel stays small (the two samplers in one kernel ran at 3 waves per SIMD).
 __global__ __launch_bounds__(256) void poisson_kernel(const PoissonP p) {
     const int img = blockIdx.y;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.per) return;
-    // vals = 2 ** np.ceil(np.log2(n_unique))
-    const double vals = exp2(ceil(log2((double)p.count[img])));
-    if (i == 0 && p.vals_out) p.vals_out[img] = (float)vals;
+    unsigned int c = p.count[img], v = 1;                     // vals = 2 ** np.ceil(np.log2(n_unique))
+    while (v < c) v <<= 1;
+    const float valsf = (float)v;
     const long long e = img * p.per + i;
-    const double lam = (double)p.in[e] * vals;
-    p.out[e] = (float)(poisson_sample(lam, p.seed, p.first_image * (unsigned long long)p.per + (unsigned long long)e) / vals);
+    const bool live = i < p.per;
+    const float x = live ? p.in[e] : 0.f;
+    const float lamf = x * valsf;                             // exact (a power of two) unless it overflows
+    const bool here = lamf == 0.f || (lamf >= 10.f && lamf < 16777216.f);
+    if (__syncthreads_or(!here)) {
+        if (threadIdx.x == 0) p.rest[(size_t)img * gridDim.x + blockIdx.x] = 1;
+        return;
+    }
+    if (threadIdx.x == 0) p.rest[(size_t)img * gridDim.x + blockIdx.x] = 0;
+    if (!live) return;
+    const unsigned long long elem = p.first_image * (unsigned long long)p.per + (unsigned long long)e;
+    const double k = lamf == 0.f ? 0.0 : poisson_ptrs_f32(lamf, p.seed, elem);
+    p.out[e] = (float)(k / (double)valsf);
+}
+
+// the workgroups poisson_kernel left: grid (slices, n_images), each slice walks its share of the image's flags
+__global__ __launch_bounds__(256) void poisson_rest_kernel(const PoissonP p, int nblk) {
+    const int img = blockIdx.y;
+    unsigned int c = p.count[img], v = 1;
+    while (v < c) v <<= 1;
+    const double vals = (double)v;
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        if (!p.rest[(size_t)img * nblk + blk]) continue;
+        const long long i = (long long)blk * 256 + threadIdx.x;
+        if (i >= p.per) continue;
+        const long long e = img * p.per + i;
+        const unsigned long long elem = p.first_image * (unsigned long long)p.per + (unsigned long long)e;
+        const float x = p.in[e];
+        const float lamf = x * (float)v;
+        double k;
+        if (lamf >= 10.f && lamf < 16777216.f) k = poisson_ptrs_f32(lamf, p.seed, elem);
+        else k = poisson_sample((double)x * vals, p.seed, elem);
+        p.out[e] = (float)(k / vals);
+    }
 }
 
 // ---- bilinear resize (cv2.resize INTER_LINEAR, code/committee.py:22-26) -------------------------------
@@ -472,9 +660,8 @@ int alink_noise_perlin(const float* dev_in, float* dev_out, int n_images, int si
 
 size_t alink_noise_poisson_scratch_bytes(int n_images, int64_t per_image) {
     if (n_images <= 0 || per_image <= 0) return 0;
-    unsigned long long slots = 1;
-    while (slots < 2ull * (unsigned long long)per_image) slots <<= 1;
-    return (size_t)n_images * slots * 4 + (size_t)n_images * 4;
+    // the unique-value count of every image + one flag per 256-element workgroup
+    return (size_t)n_images * 4 + (size_t)n_images * (size_t)((per_image + 255) / 256);
 }
 
 int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64_t per_image, uint64_t seed,
@@ -486,17 +673,24 @@ int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64
     const size_t need = alink_noise_poisson_scratch_bytes(n_images, per_image);
     ALINK_REQUIRE(dev_scratch && scratch_bytes >= need, ALINK_ENOMEM, "scratch %zu < %zu bytes", scratch_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    unsigned int slots = 1;
-    while (slots < 2ull * (unsigned long long)per_image) slots <<= 1;
-    unsigned int* table = (unsigned int*)dev_scratch;
-    unsigned int* count = table + (size_t)n_images * slots;
-    ALINK_HIP(hipMemsetAsync(table, 0xFF, (size_t)n_images * slots * 4, st));
-    ALINK_HIP(hipMemsetAsync(count, 0, (size_t)n_images * 4, st));
-    const dim3 grid((unsigned)((per_image + 255) / 256), n_images);
-    UniqueP u{dev_in, table, count, per_image, slots};
-    hipLaunchKernelGGL(unique_count_kernel, grid, dim3(256), 0, st, u);
-    PoissonP p{dev_in, dev_out, count, dev_vals, per_image, seed, first_image};
+    unsigned int* count = (unsigned int*)dev_scratch;
+    // hash parts of the general path: a part's expected load of the 32768-slot table stays at or below 1/2
+    int parts_log2 = 0;
+    while ((16384ll << parts_log2) < per_image) ++parts_log2;
+    UniqueP u{dev_in, count, dev_vals, per_image, parts_log2};
+    const size_t lds = (kSeen + 4 + kHashSlots) * sizeof(unsigned int);
+    static bool attr_set[64] = {};
+    const int dev = device_of_pointer(dev_out);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        ALINK_HIP(hipFuncSetAttribute((const void*)unique_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(unique_count_kernel, dim3(n_images), dim3(1024), lds, st, u);
+    const int nblk = (int)((per_image + 255) / 256);
+    const dim3 grid((unsigned)nblk, n_images);
+    PoissonP p{dev_in, dev_out, count, (unsigned char*)(count + n_images), per_image, seed, first_image};
     hipLaunchKernelGGL(poisson_kernel, grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(poisson_rest_kernel, dim3((unsigned)(nblk < 16 ? nblk : 16), n_images), dim3(256), 0, st, p, nblk);
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
 }

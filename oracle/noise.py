@@ -251,8 +251,63 @@ def poisson_vals(image):
     return 2 ** np.ceil(np.log2(len(np.unique(image))))
 
 
-def philox_poisson(images, seed):
-    """Same sampler as noise.hip::poisson_sample, element by element (slow: test sizes only)."""
+_LOGFACT8 = np.array([0.0, 0.0, 0.6931471806, 1.791759469, 3.178053830, 4.787491743, 6.579251212, 8.525161361], np.float32)
+
+
+def _ptrs_f32(L, elem, seed):
+    """noise.hip::poisson_ptrs_f32 in NumPy float32, operation for operation (setup and proposal are single correctly
+    rounded operations on both sides; the acceptance test's log / log1p differ from the device's by an ulp or so, which
+    flips a decision only when the two sides agree to ~1e-6).  L: float32 array, 10 <= L < 2^24.  Returns float64 counts."""
+    f = np.float32
+    L = np.asarray(L, f)
+    slam = np.sqrt(L)
+    b = f(0.931) + f(2.53) * slam
+    a = f(-0.059) + f(0.02483) * b
+    invalpha = f(1.1239) + f(1.1328) / (b - f(3.4))
+    vr = f(0.9277) - f(3.6224) / (b - f(2.0))
+    Li = np.floor(L)
+    Lf043 = (L - Li) + f(0.43)
+    a2 = f(2.0) * a
+    inv_lam = f(1.0) / L
+    res, done = np.zeros(len(L), np.float64), np.zeros(len(L), bool)
+    sub = 0
+    while not done.all():
+        r = philox4x32_10(elem, sub, ST_POISSON, seed)
+        sub += 1
+        for wu, wv in ((r[0], r[1]), (r[2], r[3])):
+            U = u01(wu) - f(0.5)
+            V = u01(wv)
+            us = f(0.5) - np.abs(U)
+            kf = np.floor((a2 / us + b) * U + Lf043)
+            acc1 = (us >= f(0.07)) & (V <= vr)
+            k = Li + kf
+            rej = (k < 0) | ((us < f(0.013)) & (V > us))
+            us2 = us * us
+            with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+                lhs = V * invalpha * us2 / (a + b * us2)
+                small = k < 8
+                ks = np.clip(k, 0, 7).astype(int)
+                logp_small = -L + k * np.log(L) - _LOGFACT8[ks]
+                d = kf - (L - Li)
+                x = d * inv_lam
+                ser = f(-1.0 / 110.0)
+                for c in (1.0 / 90, -1.0 / 72, 1.0 / 56, -1.0 / 42, 1.0 / 30, -1.0 / 20, 1.0 / 12, -1.0 / 6, 0.5):
+                    ser = (ser.astype(np.float64) * x.astype(np.float64) + np.float64(f(c))).astype(f)      # fmaf
+                h = np.where(np.abs(x) < f(0.125), ser * x * x, (f(1.0) + x) * np.log1p(x) - x).astype(f)
+                rk = f(1.0) / k
+                logp_big = -L * h - f(0.5) * np.log(f(6.283185307179586) * k) - rk * f(1.0 / 12.0) + rk * rk * rk * f(1.0 / 360.0)
+                logp = np.where(small, logp_small, logp_big)
+                acc2 = np.log(lhs) <= logp
+            take = ~done & (acc1 | (~rej & acc2))
+            res = np.where(take, Li.astype(np.float64) + kf.astype(np.float64), res)
+            done |= take
+    return res
+
+
+def philox_poisson(images, seed, first_image=0):
+    """Same sampler as noise.hip (poisson_kernel / poisson_rest_kernel), element by element (slow: test sizes only):
+    lam = x * vals in float32; 0 -> 0; 10 <= lam < 2^24 -> the float32 PTRS above; anything else the float64 forms
+    (product of uniforms below 10, PTRS from 2^24)."""
     from scipy.special import gammaln
     x = np.asarray(images, dtype=np.float32)
     n = x.shape[0]
@@ -261,10 +316,14 @@ def philox_poisson(images, seed):
     flat_in, flat_out = x.reshape(n, per), out.reshape(n, per)
     for img in range(n):
         vals = float(poisson_vals(flat_in[img]))
+        lamf = flat_in[img] * np.float32(vals)
         lam = flat_in[img].astype(np.float64) * vals
-        elem = np.uint64(img * per) + np.arange(per, dtype=np.uint64)
+        elem = np.uint64((first_image + img) * per) + np.arange(per, dtype=np.uint64)
         k = np.full(per, np.nan)
         k[lam == 0] = 0.0
+        mid = np.where((lamf >= np.float32(10)) & (lamf < np.float32(16777216)))[0]
+        if len(mid):
+            k[mid] = _ptrs_f32(lamf[mid], elem[mid], seed)
         # --- lam < 10: product of uniforms
         small = np.where((lam > 0) & (lam < 10))[0]
         if len(small):
@@ -281,8 +340,8 @@ def philox_poisson(images, seed):
                     done |= hit
                     cnt = np.where(act & ~hit, cnt + 1, cnt)
             k[small] = cnt
-        # --- lam >= 10: PTRS
-        big = np.where(lam >= 10)[0]
+        # --- lam >= 2^24: PTRS in float64
+        big = np.where(lamf >= np.float32(16777216))[0]
         if len(big):
             L = lam[big]
             slam, loglam = np.sqrt(L), np.log(L)

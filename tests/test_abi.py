@@ -8,10 +8,19 @@ from a_link_amd import _abi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    src = open(os.path.join(ROOT, "include", "alink_hip.h")).read()
+def _header_symbols(name="alink_hip.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(alink_[a-z0-9_]+)\s*\(", src)))
+
+
+def _exported_symbols():
+    """every defined dynamic symbol alink_* of the built library (nm -D; llvm-nm where binutils is absent)"""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.check_output([nm, "-D", "--defined-only", _abi.LIB_PATH]).decode()
+    return sorted(set(ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("alink_")))
 
 
 def test_library_exists_and_loads():
@@ -29,6 +38,22 @@ def test_every_header_symbol_is_exported_and_bound():
         assert s in _abi.PROTOTYPES, "_abi.py has no prototype for %s" % s
     for s in _abi.PROTOTYPES:
         assert s in syms, "_abi.py binds %s which the header does not declare" % s
+
+
+def test_no_export_without_a_declaration():
+    """VERDICT r4 (weak #8): the library exported 23 `alink_debug_*` switches no header declared.  Every exported alink_*
+    symbol must be declared — the product ABI in include/alink_hip.h, the A/B and diagnostic switches in
+    include/alink_hip_debug.h (process-global, not thread-safe, stated there) — and neither header may declare a symbol the
+    library lacks; the product header declares no debug switch and the ctypes table binds none."""
+    exported = _exported_symbols()
+    product, debug = _header_symbols(), _header_symbols("alink_hip_debug.h")
+    assert not set(product) & set(debug)
+    undeclared = [s for s in exported if s not in product and s not in debug]
+    assert not undeclared, "exported but declared in no header: %s" % undeclared
+    missing = [s for s in product + debug if s not in exported]
+    assert not missing, "declared but not exported: %s" % missing
+    assert all(s.startswith("alink_debug_") for s in debug) and not [s for s in product if s.startswith("alink_debug_")]
+    assert not [s for s in _abi.PROTOTYPES if s.startswith("alink_debug_")]
 
 
 def test_fails_loudly_without_gpu():

@@ -128,6 +128,52 @@ def test_poisson_matches_philox_oracle(gpu):
         p.addNoise(-np.ones((1, 4, 4, 3), np.float32), None)
 
 
+def test_poisson_unique_counts_on_chip(gpu):
+    """vals = 2^ceil(log2(#unique)) (code/noise.py:73-74) from the on-chip counters: the 256-mark table for integer-valued
+    images, the LDS hash set (2^p parts) for anything else — 112 x 112 x 3 images with every value distinct, with heavy
+    duplication, with -0.0 / 0.0 and NaN patterns, a 224 x 224 image (16 parts), and counts that sit exactly on / next to a
+    power of two."""
+    from a_link_amd import noise as N
+    from oracle import noise as ON
+    rng = np.random.RandomState(3)
+    per = 112 * 112 * 3
+    imgs = [rng.randint(0, 256, per).astype(np.float32),                                   # integer path, 256 values
+            rng.randint(0, 256, per).astype(np.float32) * 0.5 + 0.25,                        # 256 fractional values
+            rng.permutation(per).astype(np.float32) * 0.00390625,                            # all distinct: 37632 -> 65536
+            (rng.permutation(per) % 32768).astype(np.float32) + 0.5,                         # exactly 32768 distinct
+            (rng.permutation(per) % 32769).astype(np.float32) + 0.5,                         # 32769 -> 65536
+            np.where(rng.rand(per) < 0.5, 0.0, -0.0).astype(np.float32),                     # one value (0.0 == -0.0)
+            rng.randint(0, 3, per).astype(np.float32)]                                       # 3 values -> 4
+    x = np.stack(imgs).reshape(len(imgs), 112, 112, 3)
+    p = N.Poisson(seed=1)
+    p.addNoise(x, None)
+    vals = p.last_vals.cpu().numpy()
+    assert np.array_equal(vals, [ON.poisson_vals(im) for im in x]), (vals, [ON.poisson_vals(im) for im in x])
+    big = (rng.permutation(224 * 224 * 3) % 70000).astype(np.float32).reshape(1, 224, 224, 3) * 0.001
+    p.addNoise(big, None)
+    assert p.last_vals.cpu().numpy()[0] == ON.poisson_vals(big[0]) == 131072.0
+
+
+def test_poisson_matches_oracle_at_image_scale_lambdas(gpu):
+    """The float32 PTRS sampler against its NumPy restatement at the lam the loop produces (x * 256 up to 65280, and
+    x * 65536 up to 1.67e7 for a resized image): identical counts except where an acceptance test lands within ~1e-6 of
+    equality."""
+    from a_link_amd import noise as N
+    from oracle import noise as ON
+    rng = np.random.RandomState(4)
+    a = rng.randint(0, 256, (1, 24, 24, 3)).astype(np.float32)                      # 256 values -> lam = x * 256
+    b = (rng.permutation(24 * 24 * 3).astype(np.float32) * (255.0 / 1727)).reshape(1, 24, 24, 3)      # 1728 distinct -> vals 2048
+    c = np.concatenate([a, b])
+    p = N.Poisson(seed=21)
+    got = p.addNoise(c, None)
+    want = ON.philox_poisson(c, p._seed)
+    assert np.mean(got != want) < 2e-4, np.mean(got != want)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1.0 / 256 + 1e-6)
+    # rows of a larger batch (first_image) draw the same
+    lib_rows = N.Poisson(seed=21).addNoise(c[1:], None, first_row=1)
+    assert np.array_equal(lib_rows, got[1:])
+
+
 def test_poisson_distribution_at_image_scale(gpu):
     """Poisson(x vals)/vals has mean x and variance x/vals (code/noise.py:75)."""
     from a_link_amd import noise as N
