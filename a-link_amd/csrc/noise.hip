@@ -225,6 +225,7 @@ struct UniqueP {
 };
 
 constexpr int kSeen = 256;
+constexpr unsigned int kIntegerImage = 0x80000000u;          // flag in count[]: every element an integer in 0..255
 constexpr unsigned int kHashSlots = 32768;
 constexpr unsigned int kEmpty = 0xFFFFFFFFu;
 
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(1024) void unique_count_kernel(const UniqueP p) {
     }
     if (tid == 0) {
         const unsigned int c = scal[1];
-        p.count[img] = c;
+        p.count[img] = c | (scal[0] == 0 ? kIntegerImage : 0u);
         if (p.vals_out) {
             unsigned int v = 1;                              // vals = 2 ** np.ceil(np.log2(n_unique))
             while (v < c) v <<= 1;
@@ -319,8 +320,6 @@ __device__ __forceinline__ double loggam(double x) { return lgamma(x); }
 struct PoissonP {
     const float* in;
     float* out;
-    const unsigned int* count;   // unique values per image
-    unsigned char* rest;         // [n_images][workgroups per image]: left to poisson_rest_kernel
     long long per;
     unsigned long long seed, first_image;
 };
@@ -372,107 +371,202 @@ __device__ __forceinline__ float small_logfact(int k) {
     return v;
 }
 
-// float32 PTRS for 10 <= lam < 2^24 (header above).  Returns the count as a double: Li + kf can exceed 2^24 by a hair.
-__device__ __forceinline__ double poisson_ptrs_f32(float lam, unsigned long long seed, unsigned long long elem) {
-    // setup and proposal: correctly rounded single operations, in this order (the oracle repeats them in NumPy float32)
+// float32 PTRS for 10 <= lam < 2^24 (header above), in two pieces: the per-lambda constants and one attempt.
+// Setup and proposal are correctly rounded single operations in this order (the oracle repeats them in NumPy float32).
+struct PtrsC { float b, a, a2, vr, invalpha, inv_lam; };
+
+__device__ __forceinline__ PtrsC ptrs_setup(float lam) {
+    PtrsC c;
     const float slam = __fsqrt_rn(lam);
-    const float b = __fadd_rn(0.931f, __fmul_rn(2.53f, slam));
-    const float a = __fadd_rn(-0.059f, __fmul_rn(0.02483f, b));
-    const float invalpha = __fadd_rn(1.1239f, __fdiv_rn(1.1328f, __fsub_rn(b, 3.4f)));
-    const float vr = __fsub_rn(0.9277f, __fdiv_rn(3.6224f, __fsub_rn(b, 2.0f)));
+    c.b = __fadd_rn(0.931f, __fmul_rn(2.53f, slam));
+    c.a = __fadd_rn(-0.059f, __fmul_rn(0.02483f, c.b));
+    c.invalpha = __fadd_rn(1.1239f, __fdiv_rn(1.1328f, __fsub_rn(c.b, 3.4f)));
+    c.vr = __fsub_rn(0.9277f, __fdiv_rn(3.6224f, __fsub_rn(c.b, 2.0f)));
+    c.a2 = __fmul_rn(2.0f, c.a);
+    c.inv_lam = 1.0f / lam;
+    return c;
+}
+
+// one attempt with the uniforms of words (wu, wv): true = accepted, kf = k - floor(lam)
+__device__ __forceinline__ bool ptrs_attempt(const PtrsC& c, float lam, float Li, float Lf043, unsigned int wu, unsigned int wv, float& kf) {
+    const float U = __fsub_rn(u01(wu), 0.5f);
+    const float V = u01(wv);
+    const float us = __fsub_rn(0.5f, fabsf(U));
+    kf = floorf(__fadd_rn(__fmul_rn(__fadd_rn(__fdiv_rn(c.a2, us), c.b), U), Lf043));
+    if (us >= 0.07f && V <= c.vr) return true;
+    const float k = Li + kf;                                   // the acceptance test may round it
+    if (k < 0.f || (us < 0.013f && V > us)) return false;
+    // V invalpha / (a / us^2 + b) <= pmf(k; lam), pmf without cancellation (header)
+    const float us2 = us * us;
+    const float lhs = V * c.invalpha * us2 / (c.a + c.b * us2);
+    float logp;
+    if (k < 8.f) {
+        logp = -lam + k * __logf(lam) - small_logfact((int)k);
+    } else {
+        const float d = kf - (lam - Li);                       // k - lam
+        const float x = d * c.inv_lam;
+        float h;                                               // (1 + x) log(1 + x) - x
+        if (fabsf(x) < 0.125f) {
+            float s = -1.f / 110.f;                            // x^2 (1/2 - x/6 + x^2/12 - ... + x^8/90 - x^9/110)
+            s = fmaf(s, x, 1.f / 90.f);
+            s = fmaf(s, x, -1.f / 72.f);
+            s = fmaf(s, x, 1.f / 56.f);
+            s = fmaf(s, x, -1.f / 42.f);
+            s = fmaf(s, x, 1.f / 30.f);
+            s = fmaf(s, x, -1.f / 20.f);
+            s = fmaf(s, x, 1.f / 12.f);
+            s = fmaf(s, x, -1.f / 6.f);
+            s = fmaf(s, x, 0.5f);
+            h = s * x * x;
+        } else {
+            h = (1.f + x) * log1pf(x) - x;
+        }
+        const float rk = 1.0f / k;
+        logp = -lam * h - 0.5f * __logf(6.283185307179586f * k) - rk * (1.f / 12.f) + rk * rk * rk * (1.f / 360.f);
+    }
+    return __logf(lhs) <= logp;
+}
+
+// element by element (poisson_rest_kernel, and the definition the oracle follows): Philox block (elem, sub) serves two
+// attempts, (x, y) then (z, w).  Returns the count as a double: Li + kf can exceed 2^24 by a hair.
+__device__ __forceinline__ double poisson_ptrs_f32(float lam, unsigned long long seed, unsigned long long elem) {
+    const PtrsC c = ptrs_setup(lam);
     const float Li = floorf(lam);
     const float Lf043 = __fadd_rn(__fsub_rn(lam, Li), 0.43f);
-    const float a2 = __fmul_rn(2.0f, a);
-    const float inv_lam = 1.0f / lam;
-    unsigned int sub = 0;
+    float kf;
+    for (unsigned int sub = 0;; ++sub) {
+        const U4 r = draw(seed, elem, sub, ST_POISSON);
+        if (ptrs_attempt(c, lam, Li, Lf043, r.x, r.y, kf)) break;
+        if (ptrs_attempt(c, lam, Li, Lf043, r.z, r.w, kf)) break;
+    }
+    return (double)Li + (double)kf;
+}
+
+// Pass 2.  A wave owns kWaveRange consecutive elements of an image and hands them to its lanes ONE AT A TIME: a lane whose
+// element was accepted takes the next unclaimed one in the same round (ballot + prefix count), so that every round nearly
+// all 64 lanes make a real attempt.  (One 16-wave workgroup per image drawing from a counter in LDS — fewer drains — was
+// 13 % slower: profiles/experiments/r05_poisson_kernel.txt.)  (A lane-per-element loop runs until the slowest of its 64 lanes accepts: 12 % of the
+// attempts fail, so almost every wave paid a second and a third round for a handful of lanes — 3.2 attempts and 1.6 Philox
+// blocks per element-slot against 1.14 here.)  The per-element stream is untouched: element e draws Philox blocks
+// (e, 0), (e, 1), ... and uses (x, y) then (z, w) of each.  For an integer-valued image (unique_count_kernel marks it) lam
+// takes at most 256 values: their constants — a square root and three divisions each — come from a table in LDS built
+// once per workgroup.  Elements outside the float32 sampler's range (0 < lam < 10, lam >= 2^24, negative, NaN) are left to
+// poisson_rest_kernel through a bitmap; a negative one also raises the flag the host turns into numpy's ValueError.
+constexpr int kWaveRange = 1536;      // sweep (1,024 images of 112 x 112 x 3): 512..2048 within 3 %, 3072+ 10-15 % slower
+
+struct PoissonScratch {
+    unsigned int* count;       // [n] unique values | kIntegerImage
+    unsigned int* any_rest;    // [n] image has elements for poisson_rest_kernel
+    unsigned int* negative;    // [1] some element was negative (np.random.poisson raises)
+    unsigned int* bitmap;      // [n][words_per_image]
+};
+
+__global__ __launch_bounds__(256) void poisson_kernel(const PoissonP p, const PoissonScratch sc, int words_per_image, long long range) {
+    __shared__ float tab[256 * 6];
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const unsigned int craw = sc.count[img];
+    const bool int_image = (craw & kIntegerImage) != 0;
+    unsigned int c = craw & ~kIntegerImage, v = 1;            // vals = 2 ** np.ceil(np.log2(n_unique))
+    while (v < c) v <<= 1;
+    const float valsf = (float)v;
+    const double inv_vals = 1.0 / (double)v;                  // a power of two: k * inv_vals == k / vals exactly
+    if (int_image) {
+        const float lam = (float)tid * valsf;
+        if (lam >= 10.f && lam < 16777216.f) {
+            const PtrsC t = ptrs_setup(lam);
+            float* q = tab + tid * 6;
+            q[0] = t.b; q[1] = t.a; q[2] = t.a2; q[3] = t.vr; q[4] = t.invalpha; q[5] = t.inv_lam;
+        }
+    }
+    __syncthreads();
+    const long long start = ((long long)blockIdx.x * 4 + (tid >> 6)) * range;         // `range` elements per WAVE
+    if (start >= p.per) return;
+    const long long end = start + range < p.per ? start + range : p.per;
+    const float* src = p.in + (size_t)img * p.per;
+    float* dst = p.out + (size_t)img * p.per;
+    const unsigned long long elem0 = (p.first_image + (unsigned long long)img) * (unsigned long long)p.per;
+    long long next = start;                                   // wave-uniform
+    bool active = false;
+    long long e = 0;
+    float lam = 0.f, Li = 0.f, Lf043 = 0.f, kf = 0.f;
+    PtrsC k{};
+    unsigned int sub = 0, rz = 0, rw = 0;
+    bool second = false;
     for (;;) {
-        const U4 r = draw(seed, elem, sub++, ST_POISSON);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const float U = __fsub_rn(u01(half ? r.z : r.x), 0.5f);
-            const float V = u01(half ? r.w : r.y);
-            const float us = __fsub_rn(0.5f, fabsf(U));
-            const float kf = floorf(__fadd_rn(__fmul_rn(__fadd_rn(__fdiv_rn(a2, us), b), U), Lf043));     // k - floor(lam)
-            if (us >= 0.07f && V <= vr) return (double)Li + (double)kf;
-            const float k = Li + kf;                                   // the acceptance test may round it
-            if (k < 0.f || (us < 0.013f && V > us)) continue;
-            // V invalpha / (a / us^2 + b) <= pmf(k; lam), pmf without cancellation (header)
-            const float us2 = us * us;
-            const float lhs = V * invalpha * us2 / (a + b * us2);
-            float logp;
-            if (k < 8.f) {
-                logp = -lam + k * __logf(lam) - small_logfact((int)k);
-            } else {
-                const float d = kf - (lam - Li);                       // k - lam
-                const float x = d * inv_lam;
-                float h;                                               // (1 + x) log(1 + x) - x
-                if (fabsf(x) < 0.125f) {
-                    float s = -1.f / 110.f;                            // x^2 (1/2 - x/6 + x^2/12 - ... + x^8/90 - x^9/110)
-                    s = fmaf(s, x, 1.f / 90.f);
-                    s = fmaf(s, x, -1.f / 72.f);
-                    s = fmaf(s, x, 1.f / 56.f);
-                    s = fmaf(s, x, -1.f / 42.f);
-                    s = fmaf(s, x, 1.f / 30.f);
-                    s = fmaf(s, x, -1.f / 20.f);
-                    s = fmaf(s, x, 1.f / 12.f);
-                    s = fmaf(s, x, -1.f / 6.f);
-                    s = fmaf(s, x, 0.5f);
-                    h = s * x * x;
+        // ---- lanes without an element claim the next ones
+        const unsigned long long want = next < end ? __ballot(!active) : 0ull;
+        if (want) {
+            const int pre = __builtin_amdgcn_mbcnt_hi((unsigned int)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)want, 0u));
+            const long long mine = next + pre;
+            if (!active && mine < end) {
+                e = mine;
+                const float x = src[e];
+                lam = x * valsf;                              // exact (a power of two) unless it overflows
+                if (lam == 0.f) {
+                    dst[e] = 0.f;
+                } else if (lam >= 10.f && lam < 16777216.f) {
+                    Li = floorf(lam);
+                    Lf043 = __fadd_rn(__fsub_rn(lam, Li), 0.43f);
+                    if (int_image) {
+                        const float* q = tab + (int)x * 6;
+                        k.b = q[0]; k.a = q[1]; k.a2 = q[2]; k.vr = q[3]; k.invalpha = q[4]; k.inv_lam = q[5];
+                    } else {
+                        k = ptrs_setup(lam);
+                    }
+                    sub = 0;
+                    second = false;
+                    active = true;
                 } else {
-                    h = (1.f + x) * log1pf(x) - x;
+                    atomicOr(&sc.bitmap[(size_t)img * words_per_image + (e >> 5)], 1u << (e & 31));
+                    sc.any_rest[img] = 1;
+                    if (x < 0.f) sc.negative[0] = 1;
                 }
-                const float rk = 1.0f / k;
-                logp = -lam * h - 0.5f * __logf(6.283185307179586f * k) - rk * (1.f / 12.f) + rk * rk * rk * (1.f / 360.f);
             }
-            if (__logf(lhs) <= logp) return (double)Li + (double)kf;
+            next += __popcll(want);
+        }
+        if (!__any(active)) {
+            if (next >= end) break;
+            continue;
+        }
+        // ---- one attempt per lane that holds an element
+        if (active) {
+            unsigned int wu, wv;
+            if (!second) {
+                const U4 r = draw(p.seed, elem0 + (unsigned long long)e, sub, ST_POISSON);
+                wu = r.x; wv = r.y; rz = r.z; rw = r.w;
+            } else {
+                wu = rz; wv = rw;
+                ++sub;
+            }
+            second = !second;
+            if (ptrs_attempt(k, lam, Li, Lf043, wu, wv, kf)) {
+                dst[e] = (float)(((double)Li + (double)kf) * inv_vals);
+                active = false;
+            }
         }
     }
 }
 
-// 256 elements per workgroup.  A workgroup in which every element is 0 or in the float32 sampler's range (all of them,
-// for an ordinary image) samples here; one with any other element (lam < 10, lam >= 2^24, negative, NaN) writes nothing
-// and raises its flag: poisson_rest_kernel — the float64 code, 166 registers — takes such workgroups whole, so that
-// this kernel stays small (the two samplers in one kernel ran at 3 waves per SIMD).
-__global__ __launch_bounds__(256) void poisson_kernel(const PoissonP p) {
+// what poisson_kernel left in the bitmap: the float64 samplers (product of uniforms below 10, PTRS from 2^24, NaN for a
+// negative rate).  grid (slices, n_images); an image without such elements costs one load.
+__global__ __launch_bounds__(256) void poisson_rest_kernel(const PoissonP p, const PoissonScratch sc, int words_per_image) {
     const int img = blockIdx.y;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    unsigned int c = p.count[img], v = 1;                     // vals = 2 ** np.ceil(np.log2(n_unique))
-    while (v < c) v <<= 1;
-    const float valsf = (float)v;
-    const long long e = img * p.per + i;
-    const bool live = i < p.per;
-    const float x = live ? p.in[e] : 0.f;
-    const float lamf = x * valsf;                             // exact (a power of two) unless it overflows
-    const bool here = lamf == 0.f || (lamf >= 10.f && lamf < 16777216.f);
-    if (__syncthreads_or(!here)) {
-        if (threadIdx.x == 0) p.rest[(size_t)img * gridDim.x + blockIdx.x] = 1;
-        return;
-    }
-    if (threadIdx.x == 0) p.rest[(size_t)img * gridDim.x + blockIdx.x] = 0;
-    if (!live) return;
-    const unsigned long long elem = p.first_image * (unsigned long long)p.per + (unsigned long long)e;
-    const double k = lamf == 0.f ? 0.0 : poisson_ptrs_f32(lamf, p.seed, elem);
-    p.out[e] = (float)(k / (double)valsf);
-}
-
-// the workgroups poisson_kernel left: grid (slices, n_images), each slice walks its share of the image's flags
-__global__ __launch_bounds__(256) void poisson_rest_kernel(const PoissonP p, int nblk) {
-    const int img = blockIdx.y;
-    unsigned int c = p.count[img], v = 1;
+    if (!sc.any_rest[img]) return;
+    unsigned int c = sc.count[img] & ~kIntegerImage, v = 1;
     while (v < c) v <<= 1;
     const double vals = (double)v;
-    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        if (!p.rest[(size_t)img * nblk + blk]) continue;
-        const long long i = (long long)blk * 256 + threadIdx.x;
-        if (i >= p.per) continue;
-        const long long e = img * p.per + i;
-        const unsigned long long elem = p.first_image * (unsigned long long)p.per + (unsigned long long)e;
-        const float x = p.in[e];
-        const float lamf = x * (float)v;
-        double k;
-        if (lamf >= 10.f && lamf < 16777216.f) k = poisson_ptrs_f32(lamf, p.seed, elem);
-        else k = poisson_sample((double)x * vals, p.seed, elem);
-        p.out[e] = (float)(k / vals);
+    const unsigned int* bm = sc.bitmap + (size_t)img * words_per_image;
+    const unsigned long long elem0 = (p.first_image + (unsigned long long)img) * (unsigned long long)p.per;
+    for (int w = blockIdx.x * 256 + threadIdx.x; w < words_per_image; w += gridDim.x * 256) {
+        unsigned int bits = bm[w];
+        while (bits) {
+            const int bit = __ffs(bits) - 1;
+            bits &= bits - 1;
+            const long long e = (long long)w * 32 + bit;
+            const float x = p.in[(size_t)img * p.per + e];
+            const double k = poisson_sample((double)x * vals, p.seed, elem0 + (unsigned long long)e);
+            p.out[(size_t)img * p.per + e] = (float)(k / vals);
+        }
     }
 }
 
@@ -658,10 +752,13 @@ int alink_noise_perlin(const float* dev_in, float* dev_out, int n_images, int si
     return ALINK_OK;
 }
 
+static inline size_t poisson_words_per_image(int64_t per_image) { return (size_t)((per_image + 31) / 32); }
+
 size_t alink_noise_poisson_scratch_bytes(int n_images, int64_t per_image) {
     if (n_images <= 0 || per_image <= 0) return 0;
-    // the unique-value count of every image + one flag per 256-element workgroup
-    return (size_t)n_images * 4 + (size_t)n_images * (size_t)((per_image + 255) / 256);
+    // per image: the unique-value count, the "has elements for the float64 sampler" word, one bit per element; + the
+    // negative-rate flag (first word of the scratch: the host reads it to raise numpy's ValueError)
+    return 16 + (size_t)n_images * 8 + (size_t)n_images * poisson_words_per_image(per_image) * 4;
 }
 
 int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64_t per_image, uint64_t seed,
@@ -671,13 +768,19 @@ int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64
     ALINK_REQUIRE(per_image < (1ll << 30), ALINK_EINVAL, "image of %lld elements too large", (long long)per_image);
     if (n_images == 0) return ALINK_OK;
     const size_t need = alink_noise_poisson_scratch_bytes(n_images, per_image);
-    ALINK_REQUIRE(dev_scratch && scratch_bytes >= need, ALINK_ENOMEM, "scratch %zu < %zu bytes", scratch_bytes, need);
+    ALINK_REQUIRE(dev_scratch && scratch_bytes >= need && (((uintptr_t)dev_scratch) & 3) == 0, ALINK_ENOMEM, "scratch %zu < %zu bytes (or unaligned)", scratch_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    unsigned int* count = (unsigned int*)dev_scratch;
+    const int wpi = (int)poisson_words_per_image(per_image);
+    PoissonScratch sc;
+    sc.negative = (unsigned int*)dev_scratch;
+    sc.count = sc.negative + 4;
+    sc.any_rest = sc.count + n_images;
+    sc.bitmap = sc.any_rest + n_images;
+    ALINK_HIP(hipMemsetAsync(dev_scratch, 0, need, st));
     // hash parts of the general path: a part's expected load of the 32768-slot table stays at or below 1/2
     int parts_log2 = 0;
     while ((16384ll << parts_log2) < per_image) ++parts_log2;
-    UniqueP u{dev_in, count, dev_vals, per_image, parts_log2};
+    UniqueP u{dev_in, sc.count, dev_vals, per_image, parts_log2};
     const size_t lds = (kSeen + 4 + kHashSlots) * sizeof(unsigned int);
     static bool attr_set[64] = {};
     const int dev = device_of_pointer(dev_out);
@@ -686,11 +789,12 @@ int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64
         attr_set[dev] = true;
     }
     hipLaunchKernelGGL(unique_count_kernel, dim3(n_images), dim3(1024), lds, st, u);
-    const int nblk = (int)((per_image + 255) / 256);
-    const dim3 grid((unsigned)nblk, n_images);
-    PoissonP p{dev_in, dev_out, count, (unsigned char*)(count + n_images), per_image, seed, first_image};
-    hipLaunchKernelGGL(poisson_kernel, grid, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(poisson_rest_kernel, dim3((unsigned)(nblk < 16 ? nblk : 16), n_images), dim3(256), 0, st, p, nblk);
+    PoissonP p{dev_in, dev_out, per_image, seed, first_image};
+    const long long range = kWaveRange;
+    const unsigned int nblk = (unsigned int)((per_image + 4 * range - 1) / (4 * range));
+    hipLaunchKernelGGL(poisson_kernel, dim3(nblk, n_images), dim3(256), 0, st, p, sc, wpi, range);
+    const unsigned int slices = (unsigned int)((wpi + 255) / 256);
+    hipLaunchKernelGGL(poisson_rest_kernel, dim3(slices < 8 ? slices : 8, n_images), dim3(256), 0, st, p, sc, wpi);
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
 }

@@ -157,14 +157,16 @@ class Poisson(Noise):
         lib = _abi.init(self.device)
         n = x.shape[0]
         per = x[0].numel()
-        if bool((x < 0).any()):
-            raise ValueError("lam < 0")                        # np.random.poisson (code/noise.py:75)
         nbytes = lib.alink_noise_poisson_scratch_bytes(n, per)
-        scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        scratch = torch.empty(nbytes // 4 + 1, dtype=torch.int32, device=x.device)
         vals = torch.empty(n, dtype=torch.float32, device=x.device)
         out = torch.empty_like(x)
         _abi.check(lib.alink_noise_poisson(_abi.ptr(x), _abi.ptr(out), n, per, self._next_seed(), first, _abi.ptr(scratch),
                                            nbytes, _abi.ptr(vals), self._stream()), "alink_noise_poisson")
+        # np.random.poisson raises for a negative rate (code/noise.py:75): the sampling kernel raises a flag in the first
+        # word of the scratch when it meets one — one 4-byte read-back instead of a reduction over the batch before the launch
+        if int(scratch[0]) != 0:
+            raise ValueError("lam < 0")
         self.last_vals = vals
         return out
 

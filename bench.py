@@ -132,6 +132,72 @@ def _timed(fn, reps, barrier, dist):
     return float(t.item()), r
 
 
+def _preflight(dist, rank, world, local_rank, quiet=False):
+    """Every collective shape the timed legs use, on tiny known data, each under a watchdog: a rank that cannot reach its peers
+    fails HERE, within seconds and with the step's name, instead of hanging the timed run.  Returns 0 / raises."""
+    import threading
+    import numpy as np
+    import torch
+    from a_link_amd import distributed as D
+    from a_link_amd.backbone import IRBackbone
+    from a_link_amd import weights as W
+    step = {"name": "start"}
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(60.0):
+            sys.stderr.write("[preflight] rank %d of %d (cuda:%d) STUCK in step %r for 60 s: a peer is unreachable or has died — "
+                             "check HSA_ENABLE_IPC_MODE_LEGACY=0, MASTER_ADDR/PORT, one process per GPU\n" % (rank, world, local_rank, step["name"]))
+            sys.stderr.flush()
+            os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
+    ok = []
+    try:
+        if dist is None:
+            step["name"] = "no process group (one process): nothing to exchange"
+        else:
+            g = dist.group.WORLD
+            step["name"] = "all_reduce of a known vector"
+            t = torch.arange(4, dtype=torch.float64, device="cuda") + rank
+            dist.all_reduce(t)
+            want = world * np.arange(4) + world * (world - 1) / 2.0
+            assert np.array_equal(t.cpu().numpy(), want), (t, want)
+            ok.append("all_reduce")
+            step["name"] = "merge_topk on known candidates"
+            vals = torch.tensor([10.0 - rank, 1.0], device="cuda")
+            v, i = D.merge_topk(vals, torch.tensor([2 * rank, 2 * rank + 1], device="cuda"), 3, largest=True, group=g)
+            want_i = [j for _, j in sorted([(-(10.0 - r), 2 * r) for r in range(world)] + [(-1.0, 2 * r + 1) for r in range(world)])[:3]]
+            assert i.cpu().tolist() == want_i, (i, want_i)
+            ok.append("merge_topk")
+            step["name"] = "RowShards gathers"
+            sh = D.RowShards(5 * world + 3, g)
+            table = np.arange((5 * world + 3) * 2, dtype=np.float32).reshape(-1, 2)
+            assert np.array_equal(sh.all_rows(table[sh.lo:sh.hi]), table)
+            req = [np.array([0, 4, 5 * world + 2]), np.arange(sh.P)[::3]]
+            got = sh.subsets(req, [table[sh.lo:sh.hi][sh.owned(r)] for r in req], (2,))
+            assert all(np.array_equal(a, table[r]) for a, r in zip(got, req))
+            assert sh.bcast(rank) == 0 and sh.all_true(True) and (world == 1 or not sh.same_everywhere(rank))
+            ok.append("row_shards")
+            step["name"] = "calibration broadcast"
+            pr = W.synthetic_ir_params((1, 1, 1, 1), size=(32, 32), seed=3)
+            bb = IRBackbone(pr, image_size=(32, 32), max_batch=8, dtype="f16x2", device=local_rank)
+            rng = np.random.default_rng(rank)
+            bb.calibrate(rng.integers(0, 256, (8, 32, 32, 3)).astype(np.float32) * (1.0 + 3.0 * rank))
+            D.broadcast_calibration([bb], group=g)
+            assert sh.same_everywhere(bb.state()), "calibration differs between ranks after the broadcast"
+            ok.append("broadcast_calibration")
+            step["name"] = "barrier"
+            dist.barrier()
+    finally:
+        done.set()
+    if not quiet:
+        print("[preflight] rank %d of %d on cuda:%d: %s ok" % (rank, world, local_rank, ", ".join(ok) or "single process"), file=sys.stderr if rank else sys.stdout)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +235,10 @@ def main():
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 leg (one A-LINK iteration, IR-100 teacher: all-exact and screen-then-settle)")
     ap.add_argument("--no-configs1", action="store_true", help="skip the configs[1] leg (IR-50, one 256-image batch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-small", action="store_true", help="skip the N = 256 CPU forward (~30 s of host time): batches <= 128 only")
+    ap.add_argument("--dry-ranks", action="store_true", help="pre-flight of a multi-GPU run: every rank creates its communicator, all-reduces a known "
+                    "vector, runs merge_topk on a known candidate set, RowShards gathers and a calibration broadcast, prints one line per rank "
+                    "and exits — seconds, before any timing (a first 8-GPU run should fail here with a reason, not hang a lease)")
     ap.add_argument("--strict", action="store_true", help="make the identity checks of the screen-then-settle legs fatal instead of reported")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile / fine-tune timing")
     ap.add_argument("--select-dtype", default="f16x2", choices=["f16x2", "f32", "none"], help="the exact-selection leg: the same "
@@ -197,6 +267,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             dist.barrier()                                   # creates the communicator (and its banner) now
             torch.cuda.synchronize()
+
+    if args.dry_ranks:
+        sys.exit(_preflight(dist, rank, world, local_rank))
+    if dist is not None and world > 1:
+        _preflight(dist, rank, world, local_rank, quiet=True)       # the same checks, silently, before every multi-rank run (~1 s)
 
     if args.linear >= 0:
         from a_link_amd import _abi
@@ -307,7 +382,8 @@ def main():
         "selection_identity_cited": {"bf16": "screening only: 394 of 1,024 golden config-3 selections differ from the f32 oracle's",
                                      "f16": "41 of 1,024 differ", "f32": "identical (exact-f32 MFMA, ~3.8 k IR-100 embeddings/s)",
                                      "f16x2": "identical (split precision on the f16 matrix cores)",
-                                     "screen-then-settle": "identical (16-bit screening + split precision near the cuts)"},
+                                     "screen-then-settle": "identical on every workload measured (16-bit screening + split precision near the cuts, under "
+                                                           "a MEASURED error bound with a sampled audit: config3 / config4 .audit; not a theorem)"},
         "headline_mode_note": "value is the %s SCREENING rate; the rate with selection sets identical to the float32 arithmetic is "
                               "exact_selection (every image exact) and config3.screen_settle (exact only near a cut)" % args.dtype
                               if args.dtype in ("bf16", "f16") else None,
@@ -374,12 +450,36 @@ def main():
                            "measured_in_this_run": False}
         except Exception:
             traffic = None
+        # the same kernel by rocprofv3: the newest committed --kernel-trace summary for this network and dtype (a profiled pass
+        # runs ~2-4 % slower than an un-profiled one: MI355X_MICROARCH.md, DVFS) — printed BESIDE the HIP-event figure, not merged
+        rocprof = None
+        try:
+            import glob
+            ks = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_%s_%s_streams1_kernel_stats.csv" % (args.model, dt_name))))
+            if ks and "stage3" in dom_name:
+                import csv
+                rows = [r_ for r_ in csv.DictReader(open(ks[-1])) if "conv3x3_linear_kernel" in r_["Name"] and "Li14ELi4E" in r_["Name"]]
+                if rows:
+                    gmax = max(int(r_["GridX"]) for r_ in rows)
+                    rows = [r_ for r_ in rows if int(r_["GridX"]) == gmax]
+                    calls = sum(int(r_["Calls"]) for r_ in rows)
+                    avg_ns = sum(float(r_["TotalDurationNs"]) for r_ in rows) / calls
+                    rocprof = {"avg_launch_us": avg_ns / 1e3, "calls": calls, "source": os.path.basename(ks[-1]),
+                               "instantiations": sorted(set(r_["Name"][:96] for r_ in rows)),
+                               "note": "mean over the kernel's epilogue forms, weighted by calls; the profile's launch batch must equal --chunk (%d) for "
+                                       "frac_rocprof to price the same launch" % args.chunk}
+                    rocprof["achieved"] = dom_f / (avg_ns * 1e-9) / 1e12
+                    rocprof["frac"] = rocprof["achieved"] / MFMA_PEAK_TFLOPS
+        except Exception as e_:
+            rocprof = {"error": repr(e_)}
         return {"bound": "mfma",
                             "kernel": "%s, %s: %d launches per %d-image forward, %.1f GFLOP each"
                                       % ("conv3x3_linear_kernel (linear 16-pixel tiles, 4 waves, 2 workgroups/CU)"
                                          if (args.linear < 0 or args.linear & 4) else "conv3x3_direct_kernel", dom_name, len(dom_ms) // len(profs), args.chunk, dom_f / 1e9),
                             "achieved": dom_achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": dom_achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                            "frac_hip_events": dom_achieved / MFMA_PEAK_TFLOPS,
+                            "frac_rocprof": rocprof.get("frac") if rocprof else None, "rocprof": rocprof,
                             "flops_per_launch": dom_f, "avg_launch_ms": dom_avg,
                             # split precision issues three MFMA FLOPs per algorithmic FLOP (hi*hi, hi*lo, lo*hi): what the matrix
                             # pipes actually do, beside the algorithmic fraction above
@@ -555,6 +655,7 @@ def main():
                 "screen_settle": {"pool_images_per_s": pool_n / t_ss, "ms_per_pass": 1e3 * t_ss,
                                   "fraction_re_embedded": inf3["fraction_re_embedded"], "rounds": inf3["rounds"],
                                   "delta": inf3["delta"], "largest_dp_seen": inf3["d_max"], "widened": inf3["widened"],
+                                  "audit": inf3.get("audit"), "recalibrated": inf3.get("recalibrated"),
                                   "identical_to_exact_all": identical,
                                   "identical_means": "scores, order and indices of the top-%d equal the all-exact pass's bit for bit (compared in this run)" % k3,
                                   "speedup_over_exact_all": t_x / t_ss},
@@ -822,22 +923,36 @@ def main():
         t1 = time.perf_counter()
         ref8 = ir_resnet.embed(params, xs, batch=8)
         one = time.perf_counter() - t1
-        # (i) batched forward at the batch the host cores are fastest at: 8, then 32 / 64 / 128 / 256 while the
-        # predicted time of the next size fits what is left of a ~20 s budget (BASELINE.md asks for N = 256; a
-        # 128-thread host needs ~25 s for that, which the last step takes only when the smaller ones went fast)
+        # (i) batched forward: BASELINE.md §4 asks for ONE N = 256 forward — timed as such (`value`; ~25-35 s on a 128-thread
+        # host: the driver's run has the headroom).  Before it the smaller batches 32 / 64 / 128 while they fit a ~12 s
+        # budget: the batch the host is FASTEST at is reported beside it (`fastest_batch`), and the oracle rows of the
+        # parity check below come out of these forwards at no extra cost.
         best_b, best_rate, spent, trials = 8, 8 / one, one, [(8, 8 / one)]
-        for b in (32, 64, 128, 256):
+        oracle_rows = ref8
+        for b in (32, 64, 128):
             predicted = b / best_rate * 0.8
-            if spent + predicted > 20.0 or b > B:
+            if spent + predicted > 12.0 or b > B:
                 break
             xb = x[:b].float().cpu().numpy()
             t1 = time.perf_counter()
-            ir_resnet.embed(params, xb, batch=b)
+            rb = ir_resnet.embed(params, xb, batch=b)
             tb = time.perf_counter() - t1
             spent += tb
             trials.append((b, b / tb))
+            if b >= 32 and oracle_rows.shape[0] < 32:
+                oracle_rows = rb[:32]
             if b / tb > best_rate:
                 best_b, best_rate = b, b / tb
+        n256 = None
+        if B >= 256 and not args.cpu_baseline_small:
+            x256c = x[:256].float().cpu().numpy()
+            t1 = time.perf_counter()
+            r256 = ir_resnet.embed(params, x256c, batch=256)
+            t256 = time.perf_counter() - t1
+            n256 = {"batch": 256, "seconds": t256, "value": 256 / t256}
+            trials.append((256, 256 / t256))
+            if oracle_rows.shape[0] < 32:
+                oracle_rows = r256[:32]
         reps, cpu_dt = 1, best_b / best_rate
         # (ii) the reference's own shape: one image per call, normalised per image (FaceModel.get_feature,
         # reference code/face_model.py:86-93, looped by ArcFace.process, code/siamese.py:232-234)
@@ -864,26 +979,35 @@ def main():
         for s0 in range(0, 1 << 18, 1 << 14):
             oh.predict([Ec[lc[s0:s0 + (1 << 14)]], Ec[rc_[s0:s0 + (1 << 14)]]])
         ps_dt = time.perf_counter() - t1
-        line["cpu_baseline"] = {"value": best_rate, "unit": "embeddings/s", "cores": cores, "kind": "port",
-                                "sample": "one batch-%d forward of the same %s network (torch-CPU f32 oracle): the fastest of the batch "
-                                          "sizes tried inside a ~20 s budget, %s.  DEVIATES from BASELINE.md §4 (one N = 256 forward): "
-                                          "at this host's rate that single forward alone would take %.0f s, beyond the budget that keeps "
-                                          "the default run within minutes" % (best_b, args.model, ", ".join("batch %d: %.2f/s" % t for t in trials), 256 / best_rate),
-                                "batch": best_b,
+        line["cpu_baseline"] = {"value": n256["value"] if n256 else best_rate, "unit": "embeddings/s", "cores": cores, "kind": "port",
+                                "sample": ("ONE N = 256 forward of the same %s network through the torch-CPU f32 oracle (BASELINE.md §4, leg 1): %.1f s; "
+                                           "smaller batches tried before it: %s" % (args.model, n256["seconds"], ", ".join("batch %d: %.2f/s" % t for t in trials)))
+                                          if n256 else
+                                          ("one batch-%d forward of the same %s network (torch-CPU f32 oracle), the fastest of %s; the N = 256 forward of "
+                                           "BASELINE.md §4 was skipped (--cpu-baseline-small or --batch < 256)" % (best_b, args.model, ", ".join("batch %d: %.2f/s" % t for t in trials))),
+                                "batch": 256 if n256 else best_b,
+                                "fastest_batch": {"batch": best_b, "value": best_rate},
                                 "reference_shaped": {"value": n_one / one_dt, "unit": "embeddings/s",
                                                      "sample": "%d batch-1 forwards, each L2-normalised on its own: the "
                                                                "reference's get_feature loop" % n_one},
                                 "finetune_step_ms_cpu": 1e3 * float(np.median(ts)),
                                 "pair_scores_per_s_cpu": (1 << 18) / ps_dt}
-        # parity of the timed output against the oracle on the same 8 images (north_star: 1e-3 cosine)
-        got8 = out[:8].cpu().numpy().astype(np.float64)
-        parity["one_minus_cos_vs_cpu_oracle_max"] = float((1.0 - (got8 * ref8).sum(1)).max())
-        parity["oracle_rows"] = 8
+        # parity of the timed output against the oracle on the same images — 32 rows where the CPU legs above produced them
+        # (8 rows at a 1.6x margin was thin), max AND mean (north_star: 1e-3 cosine)
+        nrow = oracle_rows.shape[0]
+        gotn = out[:nrow].cpu().numpy().astype(np.float64)
+        omc = 1.0 - (gotn * oracle_rows).sum(1)
+        parity["one_minus_cos_vs_cpu_oracle_max"] = float(omc.max())
+        parity["one_minus_cos_vs_cpu_oracle_mean"] = float(omc.mean())
+        parity["rows_above_8e-4"] = int((omc > 8e-4).sum())
+        parity["oracle_rows"] = int(nrow)
+        parity["weights"] = args.weights
         assert parity["one_minus_cos_vs_cpu_oracle_max"] < 1e-3, parity
         if sel_out is not None:
-            s8 = sel_out[:8].cpu().numpy().astype(np.float64)
-            line["exact_selection"]["max_abs_diff_vs_cpu_oracle"] = float(np.abs(s8 - ref8).max())
-            line["exact_selection"]["one_minus_cos_vs_cpu_oracle_max"] = float((1.0 - (s8 * ref8).sum(1)).max())
+            sn = sel_out[:nrow].cpu().numpy().astype(np.float64)
+            line["exact_selection"]["max_abs_diff_vs_cpu_oracle"] = float(np.abs(sn - oracle_rows).max())
+            line["exact_selection"]["one_minus_cos_vs_cpu_oracle_max"] = float((1.0 - (sn * oracle_rows).sum(1)).max())
+            line["exact_selection"]["oracle_rows"] = int(nrow)
             assert line["exact_selection"]["max_abs_diff_vs_cpu_oracle"] < 2e-5, line["exact_selection"]
 
     # which device every rank's handles live on (the C ABI's device rule: a handle belongs to the device current at its create
