@@ -343,7 +343,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
                 for (int j = 0; j < 4; ++j) acc[t][u][j] = fmaf(acc[t][u][j], p.acc_scale, b[j]);
             }
         }
-        if (p.alpha) {
+        if (EPI == 1 || (EPI == 0 && p.alpha)) {
 #pragma unroll
             for (int t = 0; t < TCW; ++t) {
                 const f32x4 a4 = *(const f32x4*)(ealpha + chan_t(t));
@@ -356,7 +356,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
         int so[CPL / 8];
 #pragma unroll
         for (int h = 0; h < CPL / 8; ++h) so[h] = ((n0 + chan_h(h)) >> 6) * 128 + ((n0 + chan_h(h)) & 63);
-        if (p.resid) {
+        // EPI == 2 keeps this a RUN-TIME branch (always taken there): as straight-line code the residual's loads are scheduled
+        // into the bias / scale pass above and the 128-channel form needs 444 bytes of scratch per lane
+        if (EPI != 1 && p.resid) {
             const T* r = (const T*)p.resid;
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_linear_kernel(const ConvParams 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float v = acc[2 * h + (i >> 2)][u][i & 3];
-                    if (p.post_relu) v = relu_keep_nan(v);
+                    if (EPI == 0 && p.post_relu) v = relu_keep_nan(v);
                     o8[i] = (T)v;
                     l8[i] = (T)(v - (float)o8[i]);
                 }
@@ -481,14 +483,21 @@ hipError_t launch_one(const ConvParams& p, hipStream_t st) {
     const long long nwg = groups * (p.Cout / G::BN);
     if (nwg <= 0 || nwg >= (1ll << 31)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)nwg, (unsigned)p.splitk);
-    if (SP) {      // one epilogue form: it is a third of the 16-bit kernel's share of the time
+    if (SP) {
         if (p.dact) return hipErrorInvalidValue;
         if (p.nprod == 1) {
             if (p.splitk > 1) hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 3, SP, 1>), grid, dim3(NT), G::lds_bytes(), st, p);
             else              hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 0, SP, 1>), grid, dim3(NT), G::lds_bytes(), st, p);
             return hipGetLastError();
         }
+        // round 5: the exact mode's two forward forms get compile-time epilogues too (1: bias + PReLU, 2: bias + residual),
+        // as the 16-bit kernels did in round 2 — same arithmetic in the same order, bit-identical (tests/test_gpu_conv.py)
+        const bool plain_sp = p.splitk == 1 && !p.post_relu && !p.stamps && !g_generic_epilogue;
         if (p.splitk > 1) hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 3, SP>), grid, dim3(NT), G::lds_bytes(), st, p);
+        else if (plain_sp && p.alpha && !p.resid)
+            hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 1, SP>), grid, dim3(NT), G::lds_bytes(), st, p);
+        else if (plain_sp && !p.alpha && p.resid)
+            hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 2, SP>), grid, dim3(NT), G::lds_bytes(), st, p);
         else              hipLaunchKernelGGL((conv3x3_linear_kernel<T, W, TCW, 0, SP>), grid, dim3(NT), G::lds_bytes(), st, p);
         return hipGetLastError();
     }
@@ -515,6 +524,12 @@ hipError_t set_attr_sp() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lin<W, TCW>::lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<_Float16, W, TCW, 3, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lin<W, TCW>::lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<_Float16, W, TCW, 1, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lin<W, TCW>::lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<_Float16, W, TCW, 2, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lin<W, TCW>::lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv3x3_linear_kernel<_Float16, W, TCW, 0, true, 1>,

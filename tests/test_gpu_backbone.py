@@ -597,3 +597,28 @@ def test_latency_form_of_small_launches_is_bit_identical_to_the_tile_kernels(gpu
     finally:
         lib.alink_debug_set_latency_form(1600)
         lib.alink_debug_set_latency_tiles(-1)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16x2"])
+def test_compile_time_epilogues_are_bit_identical_to_the_generic_one(gpu, dtype):
+    """csrc/conv3x3_linear.hip: a unit's conv1 (bias + PReLU) and conv2 (bias + residual) run on instantiations whose
+    epilogue is fixed at compile time — since round 5 in split precision too — against the run-time-flag epilogue
+    (alink_debug_set_generic_epilogue): the same operations in the same order, so embeddings are equal bit for bit.  64- and
+    128-channel forms (40 and 292 images)."""
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    params = W.synthetic_ir_params((1, 2, 2, 1), seed=6, normalized=True)
+    lib = gpu.load()
+    bb = IRBackbone(params, dtype=dtype, max_batch=292)
+    rng = np.random.default_rng(12)
+    x = torch.from_numpy(rng.integers(0, 256, (292, 112, 112, 3), dtype=np.uint8)).cuda()
+    if dtype == "f16x2":
+        bb.calibrate(x[:64])
+    for n in (40, 292):
+        fixed = bb.embed_device(x[:n]).clone()
+        lib.alink_debug_set_generic_epilogue(1)
+        try:
+            generic = bb.embed_device(x[:n]).clone()
+        finally:
+            lib.alink_debug_set_generic_epilogue(0)
+        assert torch.isfinite(fixed).all() and torch.equal(fixed, generic), (dtype, n, (fixed - generic).abs().max().item())
