@@ -329,6 +329,11 @@ def settle_topk(p_screen, score_screen, owner, n_owner, exact_fn, k, kind="entro
             np.minimum.at(dimg, owner[need], dist[need])
             imgs = imgs[np.argsort(dimg[imgs], kind="stable")][:max(stage_above, (len(imgs) + 1) // 2)]
             imgs = np.sort(imgs)
+        if rounds == 0 and (audit is None or audit > 0):
+            # with the audit on, the first round also takes a uniform draw of a third of an audit pass: the images nearest the
+            # cut under-estimate the largest error of the pool, and every later widening costs a round
+            first = _audit_pick(np.flatnonzero(~img_settled), max(4, audit_size(audit, n_owner) // 3), audit_seed, int(base) + 104729)
+            imgs = np.unique(np.concatenate([imgs, first]))
         todo = float(comm.sum([len(imgs)])[0])
         if todo == 0:
             # nothing is uncertain under the bound measured so far — on the pairs nearest the cut.  AUDIT it on a uniform
@@ -500,10 +505,16 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
                 else:
                     idx = np.zeros(0, np.int64)
                 if rounds == 0:
-                    # the mandatory first sample: the pairs nearest this noise's cut, whatever delta0 claims
+                    # the mandatory first sample: the pairs nearest this noise's cut, whatever delta0 claims ...
                     want = max(8, min_sample // max(n_noise, 1))
                     near = np.argsort(np.where(settled[k], np.inf, dist), kind="stable")[:want]
                     idx = np.union1d(idx, near[~settled[k][near]])
+                    # ... and, with the audit on, a uniform draw of a third of an audit pass: the errors of the rows nearest a
+                    # cut under-estimate the largest error of the batch (measured: 8e-4 against 2.2e-3 at config 4), and every
+                    # later widening costs a resolution round — start from a bound the whole population has had a say in
+                    if audit is None or audit > 0:
+                        first = _audit_pick(np.arange(P), max(4, audit_size(audit, P * n_noise) // (3 * max(n_noise, 1))), audit_seed, 104729 + k)
+                        idx = np.union1d(idx, first)
                 todo += len(idx)
                 requests.append((k, idx))
             settle_all(requests)
