@@ -460,7 +460,10 @@ def main():
                 import csv
                 rows = [r_ for r_ in csv.DictReader(open(ks[-1])) if "conv3x3_linear_kernel" in r_["Name"] and "Li14ELi4E" in r_["Name"]]
                 if rows:
-                    gmax = max(int(r_["GridX"]) for r_ in rows)
+                    by_grid = {}
+                    for r_ in rows:
+                        by_grid[int(r_["GridX"])] = by_grid.get(int(r_["GridX"]), 0) + int(r_["Calls"])
+                    gmax = max(by_grid, key=by_grid.get)                    # the launch shape with the most calls: the dominant layer's
                     rows = [r_ for r_ in rows if int(r_["GridX"]) == gmax]
                     calls = sum(int(r_["Calls"]) for r_ in rows)
                     avg_ns = sum(float(r_["TotalDurationNs"]) for r_ in rows) / calls

@@ -1,12 +1,14 @@
 # usage (on the GPU box): bash tools/profile_round.sh <prefix, e.g. r03a>
 # Every bench line / rocprofv3 summary the round's documents cite; writes gpurun_out/<prefix>_*.
 set -x
-P=${1:-r04a}
+P=${1:-r05a}
+PART=${2:-all}      # benches | traces | all
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O/prof
 cd $R
+if [ $PART != traces ]; then
 python bench.py --steps 100 --warmup 10 > $O/${P}_bench_r100.json 2> $O/${P}_bench_r100.err      # the driver's command: every leg
 X="--no-config3 --no-config4 --no-configs1"        # the secondary lines: headline + roofline + exact leg only
 python bench.py $X --dtype f16x2 --no-cpu-baseline > $O/${P}_bench_r100_f16x2.json 2>/dev/null
@@ -18,6 +20,8 @@ python bench.py $X --model r50 --batch 256 --chunk 256 --streams 1 --no-cpu-base
 python tools/layer_profile.py --batch 292 > $O/${P}_layers_r100_b292.txt 2>&1
 python tools/layer_profile.py --batch 292 --dtype f16x2 > $O/${P}_layers_r100_b292_f16x2.txt 2>&1
 python tools/layer_profile.py --model r50 --batch 256 > $O/${P}_layers_r50_b256.txt 2>&1
+fi
+if [ $PART = benches ]; then ls -la $O | tail -25; exit 0; fi
 cd /tmp
 for DT in bf16 f16x2 f32; do
   if [ $DT = f32 ]; then B="--batch 128 --chunk 128 --steps 3 --warmup 1"; else B="--batch 292 --chunk 292 --steps 10 --warmup 3"; fi
