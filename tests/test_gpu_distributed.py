@@ -445,3 +445,82 @@ def test_multirank_alink_loop_on_a_one_rank_rccl_group(rccl_group, tmp_path):
     got = _loop_run(rccl_group.group.WORLD, 0, "f16", str(tmp_path))
     assert np.array_equal(got["counts"], want["counts"]) and np.array_equal(got["sets"], want["sets"]) and np.array_equal(got["w"], want["w"])
     assert (got["rows"] > 0).all()
+
+
+def _mtp_and_attack_run(group, rank, tmp):
+    """(1) run_alink_mtp: SmallRes student trained on low-res pixels, replicated train steps, dropout masks and shuffles from
+    rank 0's host randomness; (2) run_alink_dfw with the few-pixel attack (a short search) beside Gaussian noise: the
+    differential-evolution searches shard by pair, each with the stream of its global row."""
+    from a_link_amd import alink_loop as AL, committee, noise, pairs, siamese
+    out = {}
+    conv = siamese.ArcFace(_LOOP_SIZE, "synthetic:r18:3", screen_dtype=None)
+    conv.calibrate(np.concatenate(_loop_people(6, 1) + _loop_people(6, 2)))
+    # ---- (1) Multi-PIE shape
+    low = (16, 16)
+    student = siamese.SmallRes(low + (3,), (64,), os.path.join(tmp, "lowres%d" % rank), 0.1, seed=2)
+    ens = [siamese.SiameseNetwork((512,), "e%d" % i, 0.1, seed=50 + i) for i in range(2)]
+    nz = [noise.Gaussian(seed=1 + 9 * rank), noise.Noise()]
+    bag = committee.Bagging(ens, nz)
+    rng = np.random.RandomState(3)
+    people = [rng.randint(0, 256, (2, 40, 40, 3)).astype(np.float32) for _ in range(6)]
+    gen = pairs.getGeneratorMTP(pairs.getNormalGenerator(people, 16), 8, resize_res=low)
+    flags = AL.Flags(alink_bs=3, batch_send=4, disparity_ratio=1.0, eps=0.0, ft_epochs=1, active_ratio=2.0, out_model="")
+    np.random.seed(rank * 17)
+    st = AL.run_alink_mtp(flags, conv, bag, nz, student, people, gen, _LOOP_SIZE, low, verbose=0, group=group)
+    out["mtp_counts"] = np.array([st.iterations, st.un_size, st.active_count, st.finetunes])
+    out["mtp_w"] = np.concatenate([np.asarray(w).ravel() for w in student.siamese_net.get_weights()])
+    # ---- (2) A2-LINK: few-pixel attack among the noises
+    student2 = siamese.SiameseNetwork((512,), "student", 0.1, seed=7)
+    ens2 = [siamese.SiameseNetwork((512,), "ens%d" % i, 0.1, seed=100 + i) for i in range(2)]
+    nz2 = [noise.Gaussian(seed=40 + rank), noise.AdversarialNoise(student2, None, conv, seed=41 + 5 * rank, pixel_count=3, maxiter=2, popsize=15)]
+    bag2 = committee.Bagging(ens2, nz2)
+    X_plain, X_dig = _loop_people(3, 1), _loop_people(3, 2)
+    feats_plain = [conv.process(p) for p in X_plain]
+    gen2 = pairs.getGenerator(pairs.getNormalGenerator(feats_plain, 8), pairs.getNormalGenerator(feats_plain, 8),
+                              pairs.getImposterGenerator(feats_plain, feats_plain, 8), 8)
+    flags2 = AL.Flags(alink_bs=3, batch_send=6, disparity_ratio=0.6, eps=0.0005, ft_epochs=1, mixture_ratio=2, out_model="", screen_settle=False)
+    np.random.seed(5 + 31 * rank)
+    st2 = AL.run_alink_dfw(flags2, conv, bag2, nz2, student2, X_plain, X_dig, gen2, _LOOP_SIZE, col=0, verbose=0, group=group)
+    out["adv_counts"] = np.array([st2.active_count, st2.un_size, st2.finetunes])
+    out["adv_w"] = np.concatenate([w.ravel() for w in student2.siamese_net.get_weights()])
+    return out
+
+
+def _mtp_worker(rank, world, port, path, tmp):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import a_link_amd  # noqa: F401
+        np.savez(path % rank, **_mtp_and_attack_run(dist.group.WORLD, rank, tmp))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multirank_mtp_loop_and_few_pixel_attack_equal_single_process(gpu, tmp_path):
+    """Two ranks on one card: the Multi-PIE loop (code/ALINK_MTP.py:150-266 — SmallRes trained end to end, every rank running
+    the same train steps on rank 0's dropout masks and shuffles) and an A2-LINK iteration whose noises include the few-pixel
+    attack (code/attack.py:91-103: the searches split by pair).  Counts and student weights equal the single-process runs
+    bit for bit on both ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    want = _mtp_and_attack_run(None, 0, str(tmp_path))
+    assert want["mtp_counts"][3] >= 1 and want["adv_counts"][0] > 0
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    path = str(tmp_path / "mtp_rank%d.npz")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_mtp_worker, args=(r, 2, port, path, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    for r in range(2):
+        z = np.load(path % r)
+        for k in want:
+            assert np.array_equal(z[k], want[k]), (r, k, z[k][:4], want[k][:4])
