@@ -226,26 +226,34 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
             """a round's requests [(noise, pairs)]: both sides of every request converted in ONE exact call — by the
             rank that owns the rows; the exact predictions of all requests then travel in one all-gather"""
             mine = [(jj, np.asarray(idx, np.int64) - lo if shards is None else shards.owned(idx)) for jj, idx in requests]
-            parts = [_rows(pixels[s][jj], own) for jj, own in mine for s in (0, 1) if len(own)]
-            conv = None
-            if parts:
-                if hasattr(parts[0], "detach"):
-                    import torch
-                    conv = noisy_for_student(torch.cat(parts))
-                else:
-                    conv = noisy_for_student(np.concatenate([np.asarray(p) for p in parts]))
-            out, o = [], 0
-            for jj, own in mine:
-                sides = []
-                for s in (0, 1):
-                    if len(own):
-                        sides.append(conv[o:o + len(own)])
-                        _set_rows(noisy_data[s][jj], own, sides[-1])     # the exact rows replace the screened ones
-                        o += len(own)
-                out.append(predict_rows(sides) if len(own) else np.zeros((0,) + tuple(pred_shape), np.float32))
-            if shards is not None:
-                out = shards.subsets([idx for _, idx in requests], out, pred_shape)
-            return out
+
+            def local_part():
+                parts = [_rows(pixels[s][jj], own) for jj, own in mine for s in (0, 1) if len(own)]
+                conv = None
+                if parts:
+                    if hasattr(parts[0], "detach"):
+                        import torch
+                        conv = noisy_for_student(torch.cat(parts))
+                    else:
+                        conv = noisy_for_student(np.concatenate([np.asarray(p) for p in parts]))
+                out, o = [], 0
+                for jj, own in mine:
+                    sides = []
+                    for s in (0, 1):
+                        if len(own):
+                            sides.append(conv[o:o + len(own)])
+                            _set_rows(noisy_data[s][jj], own, sides[-1])     # the exact rows replace the screened ones
+                            o += len(own)
+                    out.append(predict_rows(sides) if len(own) else np.zeros((0,) + tuple(pred_shape), np.float32))
+                return out
+            if shards is None:
+                return local_part()
+            try:
+                out = local_part()
+            except Exception as exc:          # this rank's peers are on their way into the exchange: fail THERE, on every rank
+                shards.fail("%s: %s" % (type(exc).__name__, exc))
+                out = [np.zeros((len(own),) + tuple(pred_shape), np.float32) for _, own in mine]
+            return shards.subsets([idx for _, idx in requests], out, pred_shape)
         queryIndices, active, labels, disguisedPredictions, _, info = settle.select_queries_settled(
             ensemblePredictions, screened, batch_y, None, col=col, disparity_ratio=flags.disparity_ratio,
             eps=flags.eps, blind_strategy=flags.blind_strategy, settle_many=settle_many,

@@ -344,17 +344,25 @@ class RowShards(object):
         self.ranges = [shard_range(self.P, r, self.world) for r in range(self.world)]
         self.lo, self.hi = self.ranges[self.rank]
         self.device = "cuda:%d" % torch.cuda.current_device() if dist.get_backend(group) == "nccl" else "cpu"
+        self._failed = None
+
+    def fail(self, message):
+        """This rank could not produce its part (its exact mode raised, say).  It must still take part in the next
+        gather — its peers are on their way into it — so the failure travels THERE, in a flag row every gather carries, and
+        every rank raises together instead of one raising and the others waiting for ever."""
+        self._failed = str(message)
 
     def _gather(self, local, counts):
         """local: (counts[rank], ...) host array -> [(counts[r], ...) host array for every rank r]"""
         torch = self.torch
         local = np.ascontiguousarray(local)
+        if self._failed is not None:                         # whatever was computed is not to be trusted: right shape, zeros
+            local = np.zeros((counts[self.rank],) + local.shape[1:], local.dtype)
         assert local.shape[0] == counts[self.rank], (local.shape, counts, self.rank)
-        m = max(counts)
-        if m == 0:
-            return [local[:0] for _ in counts]
+        m = max(counts) + 1                                  # + the flag row
         pad = np.zeros((m,) + local.shape[1:], local.dtype)
         pad[:local.shape[0]] = local
+        pad[m - 1].flat[0] = 1 if self._failed is not None else 0
         mine = torch.from_numpy(pad).to(self.device)
         if self.device != "cpu":
             every = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=self.device)
@@ -364,6 +372,10 @@ class RowShards(object):
             parts = [torch.empty_like(mine) for _ in range(self.world)]
             self.dist.all_gather(parts, mine, group=self.group)
             every = np.stack([p.numpy() for p in parts])
+        bad = [r for r in range(self.world) if every[r, m - 1].flat[0] != 0]
+        if bad:
+            mine_msg, self._failed = self._failed, None
+            raise RuntimeError("rank(s) %s failed before this exchange%s" % (bad, ": " + mine_msg if mine_msg else " (their own message says why)"))
         return [every[r, :counts[r]] for r in range(self.world)]
 
     def all_rows(self, local):

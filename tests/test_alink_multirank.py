@@ -270,6 +270,16 @@ def _shards_worker(rank, world, port, q):
             ok &= sh.bcast({"x": rank}) == {"x": 0}
             ok &= sh.all_true(True) and not sh.all_true(rank != 1)
             ok &= sh.same_everywhere("a") and not sh.same_everywhere(rank)
+        # a rank that could not produce its part says so IN the exchange: every rank raises, nobody waits
+        sh = Dm.RowShards(9, dist.group.WORLD)
+        if rank == 2:
+            sh.fail("boom")
+        try:
+            sh.all_rows(np.zeros((sh.hi - sh.lo, 2), np.float32))
+            ok = False
+        except RuntimeError as e:
+            ok &= "[2]" in str(e) and (("boom" in str(e)) == (rank == 2))
+        ok &= np.array_equal(sh.all_rows(np.ones((sh.hi - sh.lo, 2), np.float32)), np.ones((9, 2), np.float32))      # and the next exchange is clean
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
