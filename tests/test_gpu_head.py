@@ -277,3 +277,31 @@ def test_tiny_batch_step_equals_generic_chain(gpu, d, out_dim):
     for x, z in zip(ga, gb):
         np.testing.assert_allclose(x, z, rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(a.grads_tensor().cpu().numpy(), b.grads_tensor().cpu().numpy(), rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("bs,n", [(16, 203), (64, 300), (16, 16)])
+def test_device_resident_fit_equals_step_by_step_fit(gpu, bs, n):
+    """DenseHead.fit keeps the training set on the device (index gathers, one metrics read-back per epoch); KerasFitMixin.fit
+    is the step-by-step form (host gather, upload, train_on_batch, synchronise — Keras' own control flow, reference
+    code/siamese.py:57).  Same kernels on the same batches in the same order: weights and the per-epoch logs are equal bit for
+    bit, with a validation split, a ragged last batch, batches on both sides of the tiny-step switch (32 rows), and the
+    finetune() callbacks attached."""
+    from a_link_amd.head import DenseHead, KerasFitMixin, EarlyStopping, ReduceLROnPlateau
+    rng = np.random.RandomState(0)
+    L, R = rng.randn(n, 512).astype(np.float32), rng.randn(n, 512).astype(np.float32)
+    y = np.zeros((n, 2), np.float32)
+    y[np.arange(n), rng.randint(0, 2, n)] = 1
+    out = []
+    for fast in (True, False):
+        hd = DenseHead(512, lr=0.1, seed=3)
+        cbs = [EarlyStopping(monitor='val_loss', min_delta=0.1, patience=5), ReduceLROnPlateau(monitor='val_loss', factor=0.2, patience=5, min_lr=0.01)]
+        np.random.seed(11)
+        fit = hd.fit if fast else (lambda *a, **k: KerasFitMixin.fit(hd, *a, **k))
+        hist = fit([L, R], y, batch_size=bs, epochs=3, validation_split=0.2, verbose=0, callbacks=cbs)
+        out.append((hd.get_weights(), hist))
+    (wa, ha), (wb, hb) = out
+    for a, b in zip(wa, wb):
+        assert np.array_equal(a, b)
+    assert sorted(ha) == sorted(hb)
+    for k in ha:
+        assert ha[k] == hb[k], (k, ha[k], hb[k])
