@@ -375,6 +375,9 @@ def main():
         "frac_mfma_peak_end_to_end": emb_per_s * gflop_per_emb / 1e3 / (MFMA_PEAK_TFLOPS * world),
         "rccl_world_size": world if dist is not None else 0,
         "sustained_check": sustained,
+        # how long the number above was measured for: with the driver's flags (--steps 20) the timed region is half a second — the
+        # 60-second runs under profiles/ (r04o_sustained_*.json: 46.0 k / 15.72 k, halves within 0.25 %) are what say it holds
+        "timed_region_s": dt,
         # what a model built through the reference's API computes in when the caller names no dtype (ArcFace / FaceModel)
         "default_api_dtype": __import__("a_link_amd.face_model", fromlist=["x"]).default_dtype(),
         # CITATIONS of the committed test results (tests/test_gpu_pool.py, golden config3_r50.npz), not measurements of this

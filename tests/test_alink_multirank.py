@@ -280,6 +280,26 @@ def _shards_worker(rank, world, port, q):
         except RuntimeError as e:
             ok &= "[2]" in str(e) and (("boom" in str(e)) == (rank == 2))
         ok &= np.array_equal(sh.all_rows(np.ones((sh.hi - sh.lo, 2), np.float32)), np.ones((9, 2), np.float32))      # and the next exchange is clean
+
+        # merge_calibration: every rank ends with the elementwise minimum of the ranks' scale exponents (a scale only goes down)
+        class FakeBackbone(object):
+            def __init__(self, e):
+                self.st = {"dtype": "f16x2", "scale_exponents": list(e)}
+
+            def state(self):
+                return dict(self.st)
+
+            def load_state(self, st):
+                self.st = dict(st)
+        bb = FakeBackbone([5 - rank, 3 + rank, 7])
+        changed = Dm.merge_calibration([bb], dist.group.WORLD)
+        ok &= bb.state()["scale_exponents"] == [3, 3, 7] and changed == (rank != 1 or True) and sh.same_everywhere(bb.state())
+        # sync_host_randomness: rank 0's NumPy stream and noise stream states on every rank
+        nzs = [FakeNoise(100 + rank, 1.0)]
+        nzs[0]._calls = rank
+        np.random.seed(rank)
+        AL.sync_host_randomness(nzs, sh)
+        ok &= nzs[0].stream_state() == (100, 0) and sh.same_everywhere(float(np.random.rand()))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
