@@ -351,3 +351,25 @@ def test_few_pixel_attack_rows_are_independent_of_the_batch(gpu):
     for s in (0, 1):
         assert np.array_equal(np.stack(parts[s]), np.stack(whole[s]))
     assert not np.array_equal(np.stack(whole[0]), L) or not np.array_equal(np.stack(whole[1]), R)      # pixels were written
+
+
+def test_poisson_unique_count_survives_an_overfull_hash_part(gpu):
+    """The general path of unique_count_kernel cuts the key space into 2^p parts by the top bits of a multiplicative hash so
+    that a part fits its 32,768-slot LDS table.  An adversarial image — 37,632 distinct values whose hashes all fall into ONE
+    of the four parts — overfills it: the kernel must neither hang nor miscount (it gives up on the table after a full
+    round of probes and counts by brute force)."""
+    from a_link_amd import noise as N
+    rng = np.random.RandomState(7)
+    per = 112 * 112 * 3
+    vals = np.unique(rng.uniform(1.0, 200.0, 400000).astype(np.float32))
+    h = (vals.view(np.uint32).astype(np.uint64) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    bad = vals[(h >> np.uint64(30)) == 0][:per]
+    assert len(bad) == per
+    x = rng.permutation(bad).reshape(1, 112, 112, 3)
+    p = N.Poisson(seed=2)
+    p.addNoise(x, None)
+    assert p.last_vals.cpu().numpy()[0] == 65536.0               # 37,632 distinct -> 2^16
+    half = bad.copy()
+    half[per // 2:] = half[:per - per // 2]                        # 18,816 distinct, all in one part: fits, counted by the table
+    p.addNoise(rng.permutation(half).reshape(1, 112, 112, 3), None)
+    assert p.last_vals.cpu().numpy()[0] == 32768.0

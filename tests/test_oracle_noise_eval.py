@@ -151,3 +151,28 @@ def test_roc_precompute_full_size_matches_reference_output():
             tpr, fpr = OE.roc_precompute(scores, mask, thr, case)
             np.testing.assert_allclose(tpr, z["case%d" % case][0], rtol=0, atol=1e-15)
             np.testing.assert_allclose(fpr, z["case%d" % case][1], rtol=0, atol=1e-15)
+
+
+def test_float32_ptrs_sampler_draws_poisson():
+    """The float32 PTRS sampler the device and the oracle share since round 5 (oracle/noise.py::_ptrs_f32 = noise.hip::
+    poisson_ptrs_f32: Hörmann's transformed rejection with the pmf written without cancellation, a table of log k! below 8)
+    must DRAW Poisson(lam) — the reference's np.random.poisson(image * vals) (code/noise.py:75) fixes the distribution, not the
+    stream.  Chi-square against scipy.stats.poisson at the edge of the method's range (lam = 10: small-k table), a
+    fractional lam, the image scale (x * 256) and the resized-image scale (x * 65536); mean within 4 standard errors."""
+    from scipy import stats
+    from oracle import noise as ON
+    n = 120000
+    for lam, seed in ((10.0, 1), (12.3, 2), (177.0 * 256.0, 3), (200.5 * 65536.0, 4)):
+        L = np.full(n, lam, np.float32)
+        k = ON._ptrs_f32(L, np.arange(n, dtype=np.uint64) + np.uint64(seed * 10 ** 7), seed)
+        lam = float(L[0])
+        assert abs(k.mean() - lam) < 4.0 * np.sqrt(lam / n), (lam, k.mean())
+        assert abs(k.var() / lam - 1.0) < 0.03, (lam, k.var() / lam)
+        lo, hi = int(stats.poisson.ppf(1e-4, lam)), int(stats.poisson.ppf(1 - 1e-4, lam))
+        cuts = np.unique(np.linspace(lo, hi, min(60, hi - lo + 1)).astype(np.int64))      # bins (-inf, c0], (c0, c1], ..., (c_last, inf)
+        below = np.array([(k <= c).sum() for c in cuts], float)
+        obs = np.diff(np.concatenate([[0.0], below, [float(n)]]))
+        exp = np.diff(np.concatenate([[0.0], stats.poisson.cdf(cuts, lam), [1.0]])) * n
+        m = exp > 5
+        chi = ((obs[m] - exp[m]) ** 2 / exp[m]).sum()
+        assert stats.chi2.sf(chi, int(m.sum()) - 1) > 1e-4, (lam, chi, int(m.sum()))
