@@ -277,8 +277,9 @@ def committee_pool_topk_settled(screen_backbones, exact_backbones, heads, pool_s
 
 def _committee_pool_topk_settled(screen_backbones, exact_backbones, heads, pool_shard, gallery, k, shard_offset,
                                  kind="entropy", group=None, settle_selected=True, info=None, **settle_kw):
-    """committee_pool_topk with the SAME result (scores, order and indices equal the all-exact run's bit for bit when
-    settle_selected, the same set otherwise) at close to the screening rate: screen-then-settle (settle.py).
+    """committee_pool_topk's result at close to the screening rate: screen-then-settle (settle.py) — on every workload
+    measured, scores, order and indices equal the all-exact run's bit for bit when settle_selected (the same set otherwise),
+    under an error bound that is measured and audited on a uniform sample (info["audit"]), not proven.
     `screen_backbones[m]` / `exact_backbones[m]` are member m's backbone in the 16-bit screening mode and in the exact
     mode ("f16x2" or "f32").  The gallery (replicated, a handful of images) is embedded in the exact mode only; the pool
     shard in the screening mode; then only the pool images that own a pair whose side of the k-th cut is uncertain —
