@@ -208,8 +208,8 @@ def resize_images(images, new_size, device=None):
     """cv2.resize(image, new_size) per image (code/committee.py:22-26; readMTP.resizeImages,
     code/readMTP.py:116-119): new_size = (width, height), bilinear."""
     import torch
-    if len(images) == 0:
-        return np.array(images)
+    if len(images) == 0:                  # an empty shard (more ranks than pairs): nothing to resize, the container stays what it was
+        return images if hasattr(images, "detach") else np.array(images)
     device = _abi.resolve_device(device)
     x, as_torch = _as_device(images if not isinstance(images, (list, tuple)) else np.stack(images), device)
     n, H, W, Cc = x.shape

@@ -288,6 +288,18 @@ def test_row_ranges_draw_what_the_whole_batch_draws(gpu):
                     assert torch.equal(torch.cat(parts[s]), whole[s]), (name, size, cuts, s)
 
 
+def test_empty_shards_pass_through_the_perturbation_stage(gpu):
+    """More ranks than pair rows: a rank's shard is empty — noise, resize and the committee's attackModel hand back empty
+    containers (CUDA tensors stay CUDA tensors) and still consume their streams."""
+    from a_link_amd import committee, noise as N
+    e = torch.empty((0, 16, 16, 3), device="cuda")
+    nz = [N.Gaussian(seed=1), N.SaltPepper(seed=2), N.Poisson(seed=3), N.Speckle(seed=4)]
+    out = committee.Bagging([], nz).attackModel([e, e], (8, 8), np.zeros((0,), int), rows=(5, 5))
+    assert len(out) == 2 and all(len(side) == 4 and all(len(t) == 0 for t in side) for side in out)
+    assert all(z.stream_state()[1] == 2 for z in nz)
+    assert len(N.resize_images(e, (8, 8))) == 0 and len(N.resize_images(np.zeros((0, 16, 16, 3), np.float32), (8, 8))) == 0
+
+
 def test_pgd_step_matches_numpy_bit_for_bit(gpu):
     """alink_pgd_step (extension: FGSM / PGD) is an elementwise sign / clamp kernel: adv <- clip(clip(adv + step *
     sign(grad), clean - eps, clean + eps), lo, hi) — every float32 operation is exact or correctly rounded, so NumPy's
