@@ -139,11 +139,12 @@ def _people(n, seed, lo=2, hi=3):
     return [rng.randint(0, 256, (rng.randint(lo, hi + 1),) + SIZE + (3,)).astype(np.float32) for _ in range(n)]
 
 
-def _run(group, rank, screen):
-    """one full loop; returns what must agree between ranks and with the single-process run"""
-    flags = AL.Flags(alink_bs=3, batch_send=6, disparity_ratio=0.6, eps=0.0005, ft_epochs=2, mixture_ratio=2, out_model="",
-                     screen_settle=screen)
-    X_plain, X_dig = _people(9, 1), _people(9, 2)
+def _run(group, rank, screen, tiny=False):
+    """one full loop; returns what must agree between ranks and with the single-process run.  tiny: one person with one plain and
+    one disguised image per iteration — P = 2 pair rows, fewer than a world of 3 has ranks (an empty shard every iteration)"""
+    flags = AL.Flags(alink_bs=1 if tiny else 3, batch_send=2 if tiny else 6, disparity_ratio=1.0 if tiny else 0.6, eps=0.0005, ft_epochs=2,
+                     mixture_ratio=2, out_model="", screen_settle=screen)
+    X_plain, X_dig = (_people(5, 1, 1, 1), _people(5, 2, 1, 1)) if tiny else (_people(9, 1), _people(9, 2))
     conv = FakeFeature()
     if not screen:
         conv.process_screen = None
@@ -188,6 +189,7 @@ def _worker(rank, world, port, q):
         out = {}
         for screen in (False, True):
             out[screen] = _run(dist.group.WORLD, rank, screen)
+        out["tiny"] = _run(dist.group.WORLD, rank, True, tiny=True)
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -196,6 +198,7 @@ def _worker(rank, world, port, q):
 @pytest.mark.parametrize("world", [2, 3])
 def test_multirank_loop_equals_single_process_loop(world):
     want = {screen: _run(None, 0, screen) for screen in (False, True)}
+    want_tiny = _run(None, 0, True, tiny=True)
     assert want[False]["finetunes"] >= 1 and len(want[False]["sets"]) >= 3 and sum(len(s) for s in want[False]["sets"]) >= 10, \
         "test data must select queries and trigger a fine-tune"
     assert want[True]["sets"] == want[False]["sets"]            # screen-then-settle reaches the all-exact selection here too
@@ -209,6 +212,11 @@ def test_multirank_loop_equals_single_process_loop(world):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    for r in range(world):                       # P = 2 rows per iteration: with three ranks one shard is always empty
+        g = res[r]["tiny"]
+        assert (g["active"], g["un"], g["finetunes"], g["sets"]) == (want_tiny["active"], want_tiny["un"], want_tiny["finetunes"], want_tiny["sets"]), r
+        assert all(np.array_equal(a, b) for a, b in zip(g["weights"], want_tiny["weights"])), r
+    assert want_tiny["un"] == 10
     for screen in (False, True):
         w = want[screen]
         for r in range(world):
