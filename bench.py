@@ -376,7 +376,7 @@ def main():
         "rccl_world_size": world if dist is not None else 0,
         "sustained_check": sustained,
         # how long the number above was measured for: with the driver's flags (--steps 20) the timed region is half a second — the
-        # 60-second runs under profiles/ (r04o_sustained_*.json: 46.0 k / 15.72 k, halves within 0.25 %) are what say it holds
+        # 60-second runs under profiles/ (r05d_sustained_*.json: 47.6 k bf16 / 16.3 k f16x2, halves within 0.3 %) are what say it holds
         "timed_region_s": dt,
         # what a model built through the reference's API computes in when the caller names no dtype (ArcFace / FaceModel)
         "default_api_dtype": __import__("a_link_amd.face_model", fromlist=["x"]).default_dtype(),
