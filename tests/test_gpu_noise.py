@@ -341,20 +341,28 @@ def test_pgd_step_matches_numpy_bit_for_bit(gpu):
     del base
 
 
-def test_few_pixel_attack_rows_are_independent_of_the_batch(gpu):
+@pytest.mark.parametrize("search", ["exact", "screen"])
+def test_few_pixel_attack_rows_are_independent_of_the_batch(gpu, search):
     """noise.AdversarialNoise (code/noise.py:171-188 over code/attack.py:91-103): every pair's differential-evolution search
     has its own random stream keyed by the pair's global row, so a rank that attacks rows lo : hi finds what the
     whole-batch call finds for them (a short search here: 3 pixels, 3 generations)."""
     from a_link_amd import noise as N, siamese
     size = (32, 32)
-    conv = siamese.ArcFace(size, "synthetic:r18:3", dtype="bf16", screen_dtype=None)
+    # search="screen": the candidates of the search are embedded by the feature model's 16-bit screening form (3x the rate)
+    conv = siamese.ArcFace(size, "synthetic:r18:3", screen_dtype="f16") if search == "screen" else \
+        siamese.ArcFace(size, "synthetic:r18:3", dtype="bf16", screen_dtype=None)
     student = siamese.SiameseNetwork((512,), "s", 0.1, seed=3)
     rng = np.random.RandomState(0)
     L = rng.randint(0, 256, (4,) + size + (3,)).astype(np.float32)
     R = rng.randint(0, 256, (4,) + size + (3,)).astype(np.float32)
     labels = np.array([0, 1, 1, 0])
-    kw = dict(pixel_count=3, maxiter=3, popsize=30)
-    whole = N.AdversarialNoise(student, None, conv, seed=9, **kw).addPairNoise([L, R], labels)
+    kw = dict(pixel_count=3, maxiter=3, popsize=30, search=search)
+    whole_obj = N.AdversarialNoise(student, None, conv, seed=9, **kw)
+    whole = whole_obj.addPairNoise([L, R], labels)
+    if search == "screen":
+        from a_link_amd import attack as A
+        sc = A._DevicePairScorer(whole_obj.e2e_model, np.concatenate([L[0], R[0]]), search="screen")
+        assert sc.bb is conv.screen.model and sc.bb.dtype == "f16"
     parts = [[], []]
     for lo, hi in ((0, 1), (1, 4)):
         got = N.AdversarialNoise(student, None, conv, seed=9, **kw).addPairNoise([L[lo:hi], R[lo:hi]], labels[lo:hi], rows=(lo, 4))

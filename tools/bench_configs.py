@@ -95,13 +95,13 @@ def config4(out, noises, student_dtype="f32"):
     return conv, student
 
 
-def config5(out, conv, student, n_pairs):
+def config5(out, conv, student, n_pairs, search="exact"):
     import numpy as np
     from a_link_amd import attack as A, noise
     wrapped = noise.PredictionWrappedModel(student, conv)
     rng = np.random.RandomState(0)
     imgs = [rng.randint(0, 256, (224, 112, 3)).astype(np.float32) for _ in range(n_pairs)]
-    att = A.PixelAttacker(wrapped, seed=np.random.RandomState(1))
+    att = A.PixelAttacker(wrapped, seed=np.random.RandomState(1), search=search)
     # force every generation to run: a callback that never stops, as when the attack does not succeed
     att.attack_success = lambda *a, **k: None
     t = time.perf_counter()
@@ -111,7 +111,7 @@ def config5(out, conv, student, n_pairs):
         gens += int(att.last_result.nit)
         evals += int(att.last_result.nfev)
     dt = time.perf_counter() - t
-    out["config5_pixel_attack_r100"] = {
+    out["config5_pixel_attack_r100" + ("" if search == "exact" else "_search_in_screening_mode")] = {
         "pairs": n_pairs, "s_per_pair": dt / n_pairs, "generations_per_pair": gens / n_pairs,
         "candidate_evaluations_per_pair": evals / n_pairs, "backbone_forwards_per_pair": 2 * evals / n_pairs,
         "backbone_forwards_per_s": 2 * evals / dt}
@@ -173,6 +173,8 @@ def main():
             conv = siamese.ArcFace((112, 112), "synthetic:r100", dtype=DTYPE)
             student = siamese.SiameseNetwork((512,), "/tmp/alink_student", 0.1, seed=1)
         config5(out, conv, student, a.attack_pairs)
+        if getattr(conv, "screen", None) is not None:      # the same searches with their candidates in the screening form
+            config5(out, conv, student, a.attack_pairs, search="screen")
     if "g" not in a.skip:
         del conv, student
         config5_gradient(out, 1024)
