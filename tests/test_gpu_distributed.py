@@ -483,6 +483,21 @@ def _mtp_and_attack_run(group, rank, tmp):
     st2 = AL.run_alink_dfw(flags2, conv, bag2, nz2, student2, X_plain, X_dig, gen2, _LOOP_SIZE, col=0, verbose=0, group=group)
     out["adv_counts"] = np.array([st2.active_count, st2.un_size, st2.finetunes])
     out["adv_w"] = np.concatenate([w.ravel() for w in student2.siamese_net.get_weights()])
+    # ---- (3) BASELINE configs[4] as worded: gradient-attack noise (FGSM / PGD: extensions, a random start keyed by the global
+    # element) + a student fine-tuned in the head's bf16 compute mode
+    convg = siamese.ArcFace(_LOOP_SIZE, "synthetic:r18:3", enable_grad=True, max_batch=64)
+    student3 = siamese.SiameseNetwork((512,), "student", 0.1, seed=7, compute_dtype="bf16")
+    ens3 = [siamese.SiameseNetwork((512,), "ens%d" % i, 0.1, seed=100 + i) for i in range(2)]
+    nz3 = [noise.FGSM(student3, None, convg, eps=4.0, seed=60 + rank), noise.PGD(student3, None, convg, eps=4.0, alpha=1.5, steps=2, seed=61 + 3 * rank)]
+    bag3 = committee.Bagging(ens3, nz3)
+    feats3 = [convg.process(p) for p in X_plain]
+    gen3 = pairs.getGenerator(pairs.getNormalGenerator(feats3, 8), pairs.getNormalGenerator(feats3, 8),
+                              pairs.getImposterGenerator(feats3, feats3, 8), 8)
+    flags3 = AL.Flags(alink_bs=3, batch_send=6, disparity_ratio=0.6, eps=0.0005, ft_epochs=1, mixture_ratio=2, out_model="", screen_settle=False)
+    np.random.seed(9 + 13 * rank)
+    st3 = AL.run_alink_dfw(flags3, convg, bag3, nz3, student3, X_plain, X_dig, gen3, _LOOP_SIZE, col=0, verbose=0, group=group)
+    out["pgd_counts"] = np.array([st3.active_count, st3.un_size, st3.finetunes])
+    out["pgd_w"] = np.concatenate([w.ravel() for w in student3.siamese_net.get_weights()])
     return out
 
 
@@ -501,13 +516,14 @@ def _mtp_worker(rank, world, port, path, tmp):
 
 def test_multirank_mtp_loop_and_few_pixel_attack_equal_single_process(gpu, tmp_path):
     """Two ranks on one card: the Multi-PIE loop (code/ALINK_MTP.py:150-266 — SmallRes trained end to end, every rank running
-    the same train steps on rank 0's dropout masks and shuffles) and an A2-LINK iteration whose noises include the few-pixel
-    attack (code/attack.py:91-103: the searches split by pair).  Counts and student weights equal the single-process runs
-    bit for bit on both ranks."""
+    the same train steps on rank 0's dropout masks and shuffles), an A2-LINK iteration whose noises include the few-pixel
+    attack (code/attack.py:91-103: the searches split by pair), and BASELINE configs[4] as worded — FGSM / PGD noise
+    (extensions) with a student fine-tuned in the bf16 compute mode.  Counts and student weights equal the single-process
+    runs bit for bit on both ranks."""
     import socket
     import torch.multiprocessing as mp
     want = _mtp_and_attack_run(None, 0, str(tmp_path))
-    assert want["mtp_counts"][3] >= 1 and want["adv_counts"][0] > 0
+    assert want["mtp_counts"][3] >= 1 and want["adv_counts"][0] > 0 and want["pgd_counts"][0] > 0
     sk = socket.socket()
     sk.bind(("127.0.0.1", 0))
     port = sk.getsockname()[1]
