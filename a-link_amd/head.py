@@ -471,10 +471,20 @@ class DenseHead(KerasFitMixin):
         L, R, yd = self._dev(L), self._dev(R), self._dev(y)
         n = L.shape[0]
         dL, dR = torch.empty_like(L), torch.empty_like(R)
-        _abi.check(self.lib.alink_head_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), None, n, 0.0, 0,
-                                                  _abi.ptr(self._metrics), _abi.current_stream(self.device)), "alink_head_train_step")
-        _abi.check(self.lib.alink_head_input_grads(self.h, _abi.ptr(L), _abi.ptr(R), n, _abi.ptr(dL), _abi.ptr(dR),
-                                                   _abi.current_stream(self.device)), "alink_head_input_grads")
+        # the input-gradient kernels are float32 only; a head in the bf16 compute mode (BASELINE configs[4]: gradient-attack
+        # noise + bf16 fine-tune in ONE loop) differentiates its float32 MASTER weights for the call — an attack needs a
+        # direction, and the masters are what the bf16 copies are rounded from — and returns to its mode afterwards
+        quantised = self.compute_dtype == "bf16"
+        if quantised:
+            self.set_compute_dtype("f32")
+        try:
+            _abi.check(self.lib.alink_head_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), None, n, 0.0, 0,
+                                                      _abi.ptr(self._metrics), _abi.current_stream(self.device)), "alink_head_train_step")
+            _abi.check(self.lib.alink_head_input_grads(self.h, _abi.ptr(L), _abi.ptr(R), n, _abi.ptr(dL), _abi.ptr(dR),
+                                                       _abi.current_stream(self.device)), "alink_head_input_grads")
+        finally:
+            if quantised:
+                self.set_compute_dtype("bf16")
         return dL, dR
 
     def test_on_batch(self, x, y):
