@@ -95,16 +95,49 @@ def imposter_pair_indices(plain_counts, imposter_counts):
     return li, ri, np.zeros(n_a * n_b, np.int64)
 
 
-def index_batches(li, ri, y, batch_size, infinite=True):
-    """Generator of (li, ri, y[:, None]) slices of batch_size; the remainder of a sweep that does not
-    fill a batch is discarded before the next sweep starts (the reference resets its lists there)."""
-    full = (len(y) // batch_size) * batch_size
-    while True:
-        for s in range(0, full, batch_size):
-            e = s + batch_size
-            yield li[s:e], ri[s:e], y[s:e].reshape(-1, 1)
-        if not infinite:
-            return
+class index_batches(object):
+    """Iterator of (li, ri, y[:, None]) slices of batch_size over a pair list; the remainder of a sweep that does not
+    fill a batch is discarded before the next sweep starts (the reference resets its lists there).  Beyond a generator it
+    knows, without drawing them, which of its coming batches hold a positive / a negative label (`flags_ahead`) and can
+    `skip` batches: what mix_balanced uses to pass over the rounds the reference's getGenerator throws away
+    (code/readDFW.py:191-193: `if minSamp == 0: continue` — with hundreds of persons ~400 draws per batch it keeps)."""
+
+    def __init__(self, li, ri, y, batch_size, infinite=True):
+        self.li, self.ri, self.y = li, ri, np.asarray(y)
+        self.bs = int(batch_size)
+        self.nb = len(self.y) // self.bs                       # full batches per sweep
+        self.infinite = bool(infinite)
+        self.k = 0                                             # batches drawn so far
+        yb = self.y[:self.nb * self.bs].reshape(self.nb, self.bs) if self.nb else np.zeros((0, self.bs), self.y.dtype)
+        self.has_pos = (yb == 1).any(axis=1)
+        self.has_neg = (yb == 0).any(axis=1)
+
+    def __iter__(self):
+        return self
+
+    def remaining(self):
+        """batches left before StopIteration (None: never)"""
+        return None if self.infinite else max(self.nb - self.k, 0)
+
+    def __next__(self):
+        if self.nb == 0:
+            if self.infinite:
+                raise RuntimeError("a pair list shorter than one batch never yields (the reference's generator would spin for ever)")
+            raise StopIteration
+        if not self.infinite and self.k >= self.nb:
+            raise StopIteration
+        b = self.k % self.nb
+        self.k += 1
+        s0 = b * self.bs
+        return self.li[s0:s0 + self.bs], self.ri[s0:s0 + self.bs], self.y[s0:s0 + self.bs].reshape(-1, 1)
+
+    def flags_ahead(self, n):
+        """(has a positive, has a negative) for the next n batches (cyclic over the sweep)"""
+        idx = (self.k + np.arange(n)) % max(self.nb, 1)
+        return self.has_pos[idx], self.has_neg[idx]
+
+    def skip(self, n):
+        self.k += int(n)
 
 
 def balance_rows(y):
@@ -150,13 +183,50 @@ def _take(rows, idx):
     return rows[idx]
 
 
+def _rounds_to_skip(sources, window=4096):
+    """How many coming rounds of mix_balanced draw a joined batch WITHOUT a positive or without a negative label — rounds the
+    reference draws, joins and throws away (`continue`, no random number used) — when every source can tell (`_Gathering` over
+    index_batches).  None: a source cannot tell (a foreign generator) — draw round by round.  Stops at the first useful round,
+    at a finite source's end, or after `window` rounds (the caller asks again)."""
+    if not all(isinstance(g, _Gathering) for g in sources):
+        return None
+    lab = list(sources)
+    if len(lab) == 3:
+        lab[2] = lab[1]                                       # the reference's (Y1, Y2, Y2)
+    n = window
+    for g in sources:
+        r = g.index.remaining()
+        if r is not None:
+            n = min(n, r)
+        if g.index.nb == 0:
+            return 0                                          # let next() raise what it raises
+    if n <= 0:
+        return 0
+    pos = np.zeros(n, bool)
+    neg = np.zeros(n, bool)
+    for g in lab:
+        p_, n_ = g.index.flags_ahead(n)
+        pos |= p_
+        neg |= n_
+    useful = np.flatnonzero(pos & neg)
+    return int(useful[0]) if len(useful) else n
+
+
 def mix_balanced(sources, batch_size, transform=None):
     """`sources`: generators of ([left, right], Y).  Per round: draw one batch from every source (stop
     when one is exhausted), join, balance classes, optionally transform the two sides, accumulate until
     batch_size rows are waiting.  With three sources the joined labels are (Y1, Y2, Y2): the reference
-    repeats the second label block for the third source (code/readDFW.py:185) — kept."""
+    repeats the second label block for the third source (code/readDFW.py:185) — kept.
+    Rounds whose joined labels lack a class are dropped by the reference AFTER drawing and joining them, without touching
+    the random stream; with this module's own sources they are passed over by index arithmetic instead (_rounds_to_skip):
+    the same batches, the same np.random.choice calls, ~100x less host time at DFW scale (tools/custom_train_time.py)."""
     waiting = Pending()
     while True:
+        k = _rounds_to_skip(sources)
+        while k:                                               # k is None for foreign generators
+            for g in sources:
+                g.index.skip(k)
+            k = _rounds_to_skip(sources)
         try:
             drawn = [next(g) for g in sources]
         except StopIteration:
@@ -179,10 +249,24 @@ def mix_balanced(sources, batch_size, transform=None):
 
 
 # ---- the reference's names and signatures ---------------------------------------------------------------
+class _Gathering(object):
+    """generator of ([rows[li], rows[ri]], y) over an index_batches iterator (kept reachable: mix_balanced skips on it)"""
+
+    def __init__(self, table, index):
+        self.rows, self.index = table, index
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        li, ri, y = next(self.index)
+        return [self.rows[li], self.rows[ri]], y
+
+    next = __next__                                            # the reference calls gen.next() (Python 2)
+
+
 def _gathering(table, idx_gen):
-    rows = table
-    for li, ri, y in idx_gen:
-        yield [rows[li], rows[ri]], y
+    return _Gathering(table, idx_gen)
 
 
 def createMiniBatch(X_plain, X_dig):

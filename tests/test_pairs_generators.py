@@ -68,3 +68,58 @@ def test_createMiniBatchMTP_counts():
     (xl, xr), y = AL.createMiniBatchMTP(plain)
     n = sum(len(p) for p in plain)
     assert len(y) == n * n and int(y.sum()) == sum(len(p) ** 2 for p in plain)
+
+
+def _foreign(gen):
+    """the same batches through a plain generator function: mix_balanced cannot look ahead in it (the round-by-round form)"""
+    for b in gen:
+        yield b
+
+
+def test_skipping_the_rounds_the_reference_discards_changes_nothing():
+    """getGenerator (reference code/readDFW.py:180-209) draws a batch from each of its three sources per round and DROPS the
+    round when the joined labels lack a class — with many persons nearly every round of the all-pairs sweep is all-negative.
+    pairs.mix_balanced passes over such rounds by index arithmetic when the sources are its own; the batches it yields, and the
+    np.random stream it consumes, must equal the round-by-round form's: 60 persons, infinite and finite sources, one- and
+    three-source forms."""
+    import time
+    from a_link_amd import pairs
+    rng = np.random.RandomState(3)
+    people = [rng.randn(rng.randint(2, 5), 6).astype(np.float32) for _ in range(60)]
+    imposters = [rng.randn(rng.randint(1, 3), 6).astype(np.float32) for _ in range(20)]
+
+    def build(fast, infinite=True):
+        srcs = [pairs.getNormalGenerator(people, 16, infinite), pairs.getNormalGenerator(people[::-1], 16, infinite),
+                pairs.getImposterGenerator(people, imposters, 16, infinite)]
+        if not fast:
+            srcs = [_foreign(s) for s in srcs]
+        return pairs.getGenerator(srcs[0], srcs[1], srcs[2], 16)
+
+    out, took = {}, {}
+    for fast in (True, False):
+        np.random.seed(11)
+        g = build(fast)
+        t = time.perf_counter()
+        out[fast] = [next(g) for _ in range(40)]
+        took[fast] = time.perf_counter() - t
+        out[fast].append(np.random.rand())                      # the stream afterwards is the same too
+    for a, b in zip(out[True][:-1], out[False][:-1]):
+        assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1]) and np.array_equal(a[1], b[1])
+    assert out[True][-1] == out[False][-1]
+    assert took[True] < took[False]
+    # finite sources: both forms end after the same number of batches
+    ends = []
+    for fast in (True, False):
+        np.random.seed(5)
+        ends.append(len(list(build(fast, infinite=False))))
+    assert ends[0] == ends[1] > 0
+    # the one-source form (readMTP.getGenerator)
+    one = []
+    for fast in (True, False):
+        np.random.seed(7)
+        src = pairs.getNormalGenerator(people, 16)
+        g = pairs.getGeneratorMTP(src if fast else _foreign(src), 8)
+        one.append([next(g) for _ in range(10)])
+    for a, b in zip(*one):
+        assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[1], b[1])
+    print("mix_balanced, 40 batches over 60 persons: %.1f ms skipping ahead, %.1f ms round by round" % (1e3 * took[True], 1e3 * took[False]))
