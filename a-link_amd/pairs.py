@@ -111,6 +111,7 @@ class index_batches(object):
         yb = self.y[:self.nb * self.bs].reshape(self.nb, self.bs) if self.nb else np.zeros((0, self.bs), self.y.dtype)
         self.has_pos = (yb == 1).any(axis=1)
         self.has_neg = (yb == 0).any(axis=1)
+        self.pos_at = np.flatnonzero(self.has_pos)              # batches of a sweep that hold a positive, ascending
 
     def __iter__(self):
         return self
@@ -131,10 +132,16 @@ class index_batches(object):
         s0 = b * self.bs
         return self.li[s0:s0 + self.bs], self.ri[s0:s0 + self.bs], self.y[s0:s0 + self.bs].reshape(-1, 1)
 
-    def flags_ahead(self, n):
-        """(has a positive, has a negative) for the next n batches (cyclic over the sweep)"""
-        idx = (self.k + np.arange(n)) % max(self.nb, 1)
-        return self.has_pos[idx], self.has_neg[idx]
+    def to_next_positive(self, ahead):
+        """batches from (the batch `ahead` draws from now) to the first one that holds a positive; None: no batch ever does"""
+        if len(self.pos_at) == 0:
+            return None
+        b = (self.k + ahead) % self.nb
+        i = int(np.searchsorted(self.pos_at, b))
+        return int(self.pos_at[i] - b) if i < len(self.pos_at) else int(self.pos_at[0] + self.nb - b)
+
+    def holds_negative(self, ahead):
+        return bool(self.has_neg[(self.k + ahead) % self.nb])
 
     def skip(self, n):
         self.k += int(n)
@@ -183,33 +190,38 @@ def _take(rows, idx):
     return rows[idx]
 
 
-def _rounds_to_skip(sources, window=4096):
+def _rounds_to_skip(sources):
     """How many coming rounds of mix_balanced draw a joined batch WITHOUT a positive or without a negative label — rounds the
     reference draws, joins and throws away (`continue`, no random number used) — when every source can tell (`_Gathering` over
-    index_batches).  None: a source cannot tell (a foreign generator) — draw round by round.  Stops at the first useful round,
-    at a finite source's end, or after `window` rounds (the caller asks again)."""
+    index_batches).  None: a source cannot tell (a foreign generator) — draw round by round.  Stops at the first useful round or
+    at a finite source's end.  A binary search per source and candidate round (the positives of an all-pairs sweep are 1 batch
+    in ~P)."""
     if not all(isinstance(g, _Gathering) for g in sources):
         return None
     lab = list(sources)
     if len(lab) == 3:
         lab[2] = lab[1]                                       # the reference's (Y1, Y2, Y2)
-    n = window
+    limit = None                                              # rounds until a finite source ends
     for g in sources:
-        r = g.index.remaining()
-        if r is not None:
-            n = min(n, r)
         if g.index.nb == 0:
             return 0                                          # let next() raise what it raises
-    if n <= 0:
-        return 0
-    pos = np.zeros(n, bool)
-    neg = np.zeros(n, bool)
-    for g in lab:
-        p_, n_ = g.index.flags_ahead(n)
-        pos |= p_
-        neg |= n_
-    useful = np.flatnonzero(pos & neg)
-    return int(useful[0]) if len(useful) else n
+        r = g.index.remaining()
+        if r is not None:
+            limit = r if limit is None else min(limit, r)
+    t = 0
+    while True:
+        steps = [g.index.to_next_positive(t) for g in lab]
+        steps = [v for v in steps if v is not None]
+        if not steps:                                         # no source ever yields a positive: every round is discarded
+            if limit is None:
+                raise RuntimeError("the balanced generator's sources hold no positive pair: the reference's loop would spin for ever")
+            return limit
+        t += min(steps)
+        if limit is not None and t >= limit:
+            return limit
+        if any(g.index.holds_negative(t) for g in lab):
+            return t
+        t += 1                                                # a round of positives only: discarded too
 
 
 def mix_balanced(sources, batch_size, transform=None):

@@ -21,3 +21,4 @@ pr = cProfile.Profile(); pr.enable()
 net.customTrainModel(gen, 1, 16, 0.2, n_steps=16 * 500, verbose=0)
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+pstats.Stats(pr).sort_stats("tottime").print_stats(16)
