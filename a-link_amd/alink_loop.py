@@ -451,21 +451,25 @@ def run_alink_mtp(flags, conversionModel, bag, ensembleNoise, lowResModel, X_dig
     return state
 
 
-def top1_identification(lowResModel, X_test):
+def top1_identification(lowResModel, X_test, chunk_pairs=8192):
     """code/ALINK_MTP.py:274-289, including its argmax over the squeezed (G, 2) score array (the
-    flattened index is compared with the person id, as the reference does)."""
+    flattened index is compared with the person id, as the reference does).  The reference scores one probe image against
+    the gallery per predict() call; here `chunk_pairs` (probe, gallery) pairs go into one call — the same pairs, the same
+    argmax per probe."""
     X_gallery = [x[0] for x in X_test]
     gal = np.array(X_gallery)
-    total_count, acc = 0, 0
-    for i in range(len(X_test)):
-        for x in X_test[i]:
-            left = np.repeat(np.asarray(x)[None], len(X_gallery), axis=0)
-            predicted_scores = np.squeeze(lowResModel.predict([left, gal]))
-            predicted_id = np.argmax(predicted_scores)
-            total_count += 1
-            if predicted_id == i:
-                acc += 1
-    return acc / float(total_count)
+    G = len(X_gallery)
+    probes = [(i, np.asarray(x)) for i in range(len(X_test)) for x in X_test[i]]
+    per_call = max(1, int(chunk_pairs) // max(G, 1))
+    acc = 0
+    for s0 in range(0, len(probes), per_call):
+        part = probes[s0:s0 + per_call]
+        left = np.repeat(np.stack([x for _, x in part]), G, axis=0)
+        right = np.concatenate([gal] * len(part), axis=0)
+        scores = np.asarray(lowResModel.predict([left, right])).reshape(len(part), -1)       # (probe, G * C): the squeezed array, flattened
+        predicted = np.argmax(scores, axis=1)
+        acc += int(sum(int(p) == i for p, (i, _) in zip(predicted, part)))
+    return acc / float(len(probes))
 
 
 def pretrain(model, dataGen, epochs, batch_size, n_steps=320000, refine=False, verbose=1):

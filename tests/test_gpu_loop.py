@@ -145,8 +145,18 @@ def test_mtp_loop_runs_and_trains_smallres(gpu, tmp_path):
     st = AL.run_alink_mtp(flags, conv, bag, nz, student, people, gen, SIZE, low, verbose=0)
     assert st.iterations == 2 and st.un_size == 72 and st.active_count > 0
     assert st.finetunes >= 1 and any(not np.array_equal(a, b) for a, b in zip(w0, student.siamese_net.get_weights()))
-    acc = AL.top1_identification(student, [np.asarray(noise.resize_images(p, low)) for p in people])
+    test_people = [np.asarray(noise.resize_images(p, low)) for p in people]
+    acc = AL.top1_identification(student, test_people)
     assert 0.0 <= acc <= 1.0
+    # the batched form against the reference's one-probe-per-call loop (code/ALINK_MTP.py:274-289), argmax quirk included
+    gal = np.array([x[0] for x in test_people])
+    hits = total = 0
+    for i, person in enumerate(test_people):
+        for x in person:
+            sc = np.squeeze(student.predict([np.repeat(x[None], len(gal), axis=0), gal]))
+            hits += int(np.argmax(sc) == i)
+            total += 1
+    assert acc == hits / float(total) and AL.top1_identification(student, test_people, chunk_pairs=7) == acc
 
 
 def test_flags_match_reference_defaults():
