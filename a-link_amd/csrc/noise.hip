@@ -747,7 +747,14 @@ int alink_noise_perlin(const float* dev_in, float* dev_out, int n_images, int si
     }
     p.nodes_total = off;
     if (n_images == 0) return ALINK_OK;
-    hipLaunchKernelGGL(perlin_kernel, dim3((size * size + 255) / 256, n_images), dim3(256), 0, (hipStream_t)stream, p);
+    for (int i0 = 0; i0 < n_images; i0 += 32768) {            // grid.y carries the image index
+        const int m = n_images - i0 < 32768 ? n_images - i0 : 32768;
+        PerlinP q = p;
+        q.in = dev_in + (size_t)i0 * size * size * C;
+        q.out = dev_out + (size_t)i0 * size * size * C;
+        q.vec = dev_vec + (size_t)i0 * p.nodes_total * 2;
+        hipLaunchKernelGGL(perlin_kernel, dim3((size * size + 255) / 256, m), dim3(256), 0, (hipStream_t)stream, q);
+    }
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
 }
@@ -788,13 +795,24 @@ int alink_noise_poisson(const float* dev_in, float* dev_out, int n_images, int64
         ALINK_HIP(hipFuncSetAttribute((const void*)unique_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(unique_count_kernel, dim3(n_images), dim3(1024), lds, st, u);
-    PoissonP p{dev_in, dev_out, per_image, seed, first_image};
-    const long long range = kWaveRange;
-    const unsigned int nblk = (unsigned int)((per_image + 4 * range - 1) / (4 * range));
-    hipLaunchKernelGGL(poisson_kernel, dim3(nblk, n_images), dim3(256), 0, st, p, sc, wpi, range);
+    // grid.y carries the image index in the sampling kernels: at most 32768 images per launch (pool-scale batches take several)
+    const unsigned int nblk = (unsigned int)((per_image + 4 * kWaveRange - 1) / (4 * kWaveRange));
     const unsigned int slices = (unsigned int)((wpi + 255) / 256);
-    hipLaunchKernelGGL(poisson_rest_kernel, dim3(slices < 8 ? slices : 8, n_images), dim3(256), 0, st, p, sc, wpi);
+    for (int i0 = 0; i0 < n_images; i0 += 32768) {
+        const int m = n_images - i0 < 32768 ? n_images - i0 : 32768;
+        UniqueP uc = u;
+        uc.in = dev_in + (size_t)i0 * per_image;
+        uc.count = sc.count + i0;
+        uc.vals_out = dev_vals ? dev_vals + i0 : nullptr;
+        hipLaunchKernelGGL(unique_count_kernel, dim3(m), dim3(1024), lds, st, uc);
+        PoissonP p{dev_in + (size_t)i0 * per_image, dev_out + (size_t)i0 * per_image, per_image, seed, first_image + (uint64_t)i0};
+        PoissonScratch sci = sc;
+        sci.count = sc.count + i0;
+        sci.any_rest = sc.any_rest + i0;
+        sci.bitmap = sc.bitmap + (size_t)i0 * wpi;
+        hipLaunchKernelGGL(poisson_kernel, dim3(nblk, m), dim3(256), 0, st, p, sci, wpi, (long long)kWaveRange);
+        hipLaunchKernelGGL(poisson_rest_kernel, dim3(slices < 8 ? slices : 8, m), dim3(256), 0, st, p, sci, wpi);
+    }
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
 }

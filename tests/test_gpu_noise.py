@@ -393,3 +393,16 @@ def test_poisson_unique_count_survives_an_overfull_hash_part(gpu):
     half[per // 2:] = half[:per - per // 2]                        # 18,816 distinct, all in one part: fits, counted by the table
     p.addNoise(rng.permutation(half).reshape(1, 112, 112, 3), None)
     assert p.last_vals.cpu().numpy()[0] == 32768.0
+
+
+def test_pool_scale_batches_take_several_launches(gpu):
+    """The sampling kernels carry the image index in grid.y (at most 65,535): a batch of 70,000 (tiny) images — a pool-scale
+    call — must go through, and equal the same images perturbed as two row ranges."""
+    from a_link_amd import noise as N
+    rng = np.random.RandomState(1)
+    x = torch.from_numpy(rng.randint(0, 256, (70000, 2, 2, 3)).astype(np.float32)).cuda()
+    whole = N.Poisson(seed=4).addNoise(x, None)
+    a = N.Poisson(seed=4).addNoise(x[:40000], None, first_row=0)
+    b = N.Poisson(seed=4).addNoise(x[40000:], None, first_row=40000)
+    assert torch.equal(whole, torch.cat([a, b])) and torch.isfinite(whole).all()
+    assert float((whole - x).abs().max()) > 0
