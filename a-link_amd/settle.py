@@ -426,12 +426,12 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
     rounds = 0
     n_settled = 0
 
-    state = {"d": 0.0, "over": 0}
+    state = {"d": 0.0}
     aud = {"m": 0, "passes": 0, "max_err": 0.0, "exceedances": 0}
 
-    def settle_all(requests, thr=None):
+    def settle_all(requests):
         """requests: [(k, pair indices)] — drop what is settled already, ask for the rest in one call.  Returns the largest
-        |exact - screened| among THESE rows (state["d"] keeps the largest ever) and counts the rows beyond `thr`."""
+        |exact - screened| among THESE rows (state["d"] keeps the largest ever)."""
         nonlocal n_settled
         worst = 0.0
         todo = []
@@ -451,8 +451,6 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
             if known.any():
                 dd = np.abs(px[known, col].astype(np.float64) - scr[k][idx][known])
                 worst = max(worst, float(dd.max()))
-                if thr is not None:
-                    state["over"] += int((dd > thr).sum())
             dis[k][idx] = px
             settled[k][idx] = True
             n_settled += len(idx)
@@ -534,28 +532,37 @@ def select_queries_settled(ensemblePredictions, disguisedScreened, batch_y, sett
                 queryIndices.append(int(j))
         # what the fine-tune set takes from the noisy passes: chunk i of the query list <- noise i
         mp = int(len(queryIndices) / float(n_noise)) if n_noise else 0
-        before = n_settled
-        settle_all([(i, queryIndices[i * mp:(i + 1) * mp]) for i in range(n_noise)])
+        sel = [(i, np.asarray(queryIndices[i * mp:(i + 1) * mp], np.int64)) for i in range(n_noise)]
+        # The determination stands under the bound measured so far — on the rows nearest the cuts.  Two more groups of rows are
+        # settled, in ONE exact call (a round is an embedding call and, across ranks, two collectives): the selected rows'
+        # assigned noise copies, and the AUDIT's uniform sample of the (pair, noise) rows never settled (module header, step 5)
         held = bound.delta
-        if n_settled != before and bound.observe(state["d"]) != held:
-            continue          # the selected rows' own errors widened the bound: resolve again
-        # the determination stands under the bound measured so far — on the rows nearest the cuts and the selected ones.
-        # AUDIT it on a uniform sample of the (pair, noise) rows never settled (module header, step 5)
-        if (audit is not None and audit <= 0) or n_noise == 0:
-            break
-        flat = np.flatnonzero(~np.concatenate(settled))                         # position k * P + j
-        if len(flat) == 0:
-            break
-        pick = _audit_pick(flat, audit_size(audit, len(flat)), audit_seed, 7919 * aud["passes"] + P)
-        state["over"] = 0
-        d_aud = settle_all([(k, pick[(pick >= k * P) & (pick < (k + 1) * P)] - k * P) for k in range(n_noise)], thr=bound.d_max)
-        aud["m"] += len(pick)
-        aud["passes"] += 1
-        aud["max_err"] = max(aud["max_err"], d_aud)
-        aud["exceedances"] += state["over"]
+        audit_on = not ((audit is not None and audit <= 0) or n_noise == 0)
+        pick_by_noise = [np.zeros(0, np.int64)] * n_noise
+        if audit_on:
+            taken = np.concatenate(settled).copy()                                   # position k * P + j
+            for i, idx in sel:
+                taken[i * P + idx] = True                                            # about to be settled as selected rows
+            flat = np.flatnonzero(~taken)
+            if len(flat):
+                pick = _audit_pick(flat, audit_size(audit, len(flat)), audit_seed, 7919 * aud["passes"] + P)
+                pick_by_noise = [pick[(pick >= k * P) & (pick < (k + 1) * P)] - k * P for k in range(n_noise)]
+        n_pick = int(sum(len(v) for v in pick_by_noise))
+        before = n_settled
+        d_before = bound.d_max
+        settle_all([(k, np.union1d(sel[k][1], pick_by_noise[k])) for k in range(n_noise)])
+        if n_settled == before and n_pick == 0:
+            break             # nothing was left to settle: points only replaced intervals, the determination stands
         rounds += 1
+        if n_pick:
+            # the audited rows' own errors (their exact predictions now sit in `dis`)
+            errs = np.concatenate([np.abs(dis[k][v, col].astype(np.float64) - scr[k][v])[~unknown[k][v]] for k, v in enumerate(pick_by_noise)])
+            aud["m"] += n_pick
+            aud["passes"] += 1
+            aud["max_err"] = max(aud["max_err"], float(errs.max()) if len(errs) else 0.0)
+            aud["exceedances"] += int((errs > d_before).sum())
         if bound.observe(state["d"]) == held:
-            break             # the sample showed nothing beyond what the bound already covers
+            break             # neither the selected rows nor the sample showed anything beyond what the bound covers
         if rounds > max_rounds:
             raise RuntimeError("select_queries_settled: the audit kept widening the bound (%d rounds, delta %.3g)" % (rounds, bound.delta))
     labels = roundoff(ens[queryIndices, col]) if queryIndices else np.zeros((0, 1), dtype=int)
