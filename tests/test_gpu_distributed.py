@@ -540,3 +540,21 @@ def test_multirank_mtp_loop_and_few_pixel_attack_equal_single_process(gpu, tmp_p
         z = np.load(path % r)
         for k in want:
             assert np.array_equal(z[k], want[k]), (r, k, z[k][:4], want[k][:4])
+
+
+def test_bench_preflight_under_a_launcher_with_one_rank(gpu):
+    """`bench.py --dry-ranks`: under torch.distributed.run with one rank every collective shape of the timed
+    legs runs on tiny known data over RCCL — all-reduce, merge_topk, the RowShards gathers, a calibration broadcast — each
+    under a watchdog, one line per rank, exit code 0, in seconds."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t = time.perf_counter()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "1", "--dry-ranks"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert "[preflight] rank 0 of 1" in r.stdout and "all_reduce, merge_topk, row_shards, broadcast_calibration ok" in r.stdout, r.stdout[-400:]
+    assert time.perf_counter() - t < 120
