@@ -89,6 +89,7 @@ class LoopState(object):
         self.iterations = 0
         self.history = []
         self.settle_info = []
+        self.recalibrations = 0          # iterations during which the feature model re-calibrated itself (split precision)
 
 
 def _np(x):
@@ -182,6 +183,8 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
         if calibration_of is not None and not shards.same_everywhere(cal0):
             raise RuntimeError("alink_iteration: the feature model's calibration state differs between ranks: calibrate on one rank "
                                "(or on a sample every rank draws identically) and distributed.broadcast_calibration() it")
+    elif calibration_of is not None:
+        cal0 = calibration_of()
     if batch_x_rows is not None:
         assert tuple(batch_x_rows) == (lo, hi), "batch_x_rows %s is not this rank's shard %s" % (tuple(batch_x_rows), (lo, hi))
         local_x = batch_x
@@ -272,6 +275,11 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
             raise RuntimeError("alink_iteration: a rank's feature model re-calibrated itself during the iteration (a batch left the "
                                "split-precision range): ranks no longer embed to the same bits.  Calibrate on noisy images like "
                                "these first, then distributed.broadcast_calibration()")
+    elif calibration_of is not None and calibration_of() != cal0:
+        # one process: the results stay the exact mode's (scales are powers of two: ~2e-7 on an embedding), but the clean pass
+        # and the rows embedded after the change used different scales — counted, so that a caller can calibrate on noisier images
+        state.recalibrations += 1
+        log("note: the feature model re-calibrated its split-precision scales during this iteration")
     state.active_count += active
     log("Active Count so far : %d" % state.active_count)
     if len(queryIndices) == 0:
@@ -378,7 +386,7 @@ def run_alink_dfw(flags, conversionModel, bag, ensembleNoise, disguisedFacesMode
                                 disguisedFacesModel, dataGen, noisy_for_student=conversionModel.process,
                                 clean_for_student=batch_x_features, image_res=image_res, col=col, verbose=verbose,
                                 noisy_for_student_screen=getattr(conversionModel, "process_screen", None),
-                                group=group, batch_x_rows=rows, calibration_of=_calibration_probe(conversionModel) if group is not None else None)
+                                group=group, batch_x_rows=rows, calibration_of=_calibration_probe(conversionModel))
         if added < 0:
             continue
         if int(flags.active_ratio * state.un_size) <= state.active_count:
