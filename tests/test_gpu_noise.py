@@ -172,6 +172,17 @@ def test_poisson_matches_oracle_at_image_scale_lambdas(gpu):
     # rows of a larger batch (first_image) draw the same
     lib_rows = N.Poisson(seed=21).addNoise(c[1:], None, first_row=1)
     assert np.array_equal(lib_rows, got[1:])
+    # the top of the float32 sampler's range: 33,075 distinct values -> vals = 65536, lam up to 255 x 65536 = 1.671e7 < 2^24
+    d = (rng.permutation(105 * 105 * 3).astype(np.float32) * np.float32(255.0 / 33074)).reshape(1, 105, 105, 3)
+    p2 = N.Poisson(seed=22)
+    got2 = p2.addNoise(d, None)
+    assert p2.last_vals.cpu().numpy()[0] == 65536.0
+    want2 = ON.philox_poisson(d, p2._seed)
+    assert np.mean(got2 != want2) < 2e-4, np.mean(got2 != want2)
+    np.testing.assert_allclose(got2, want2, rtol=0, atol=1.0 / 65536 * 4 + 1e-6)
+    rel = (got2.astype(np.float64) - d) / np.sqrt(np.maximum(d, 1e-3) / 65536.0)          # standardised: ~N(0, 1)
+    sel = d > 1.0
+    assert abs(rel[sel].mean()) < 0.03 and abs(rel[sel].std() - 1.0) < 0.03
 
 
 def test_poisson_distribution_at_image_scale(gpu):
