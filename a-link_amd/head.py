@@ -449,7 +449,10 @@ class DenseHead(KerasFitMixin):
                 break
         return history
 
-    def train_on_batch(self, x, y, class_weight=None, sample_weight=None):
+    def train_on_batch(self, x, y, class_weight=None, sample_weight=None, metrics_out=None):
+        """metrics_out (not in Keras): a device float32 tensor of >= 2 elements that receives {loss, accuracy} INSTEAD of the
+        return value — the step is then only enqueued (no synchronisation, returns None): a caller that needs the numbers
+        per epoch, not per step (customTrainModel with verbose = 0), reads a whole block of them back at once."""
         L, R = self._staged("L", x[0]), self._staged("R", x[1])
         yd = self._staged("y", y)
         sw = self._sample_weights(y, class_weight, sample_weight)
@@ -457,10 +460,12 @@ class DenseHead(KerasFitMixin):
         n = L.shape[0]
         st = self.torch.cuda.current_stream(self._tdev)        # looked up once: launch on it, then wait on it
         rc = self.lib.alink_head_train_step(self.h, L.data_ptr(), R.data_ptr(), yd.data_ptr(),
-                                            swd.data_ptr() if swd is not None else None, n, 0.0, 1, self._metrics_host_ptr,
-                                            st.cuda_stream)
+                                            swd.data_ptr() if swd is not None else None, n, 0.0, 1,
+                                            self._metrics_host_ptr if metrics_out is None else metrics_out.data_ptr(), st.cuda_stream)
         if rc:
             _abi.check(rc, "alink_head_train_step")
+        if metrics_out is not None:
+            return None
         st.synchronize()
         return self._metrics_host.tolist()
 
@@ -487,7 +492,12 @@ class DenseHead(KerasFitMixin):
                 self.set_compute_dtype("bf16")
         return dL, dR
 
-    def test_on_batch(self, x, y):
+    def test_on_batch(self, x, y, metrics_out=None):
+        if metrics_out is not None:          # enqueue only (see train_on_batch): operands in buffers that outlive the call
+            L, R, yd = self._staged("vL", x[0]), self._staged("vR", x[1]), self._staged("vy", y)
+            _abi.check(self.lib.alink_head_eval(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), L.shape[0],
+                                                C.c_void_p(metrics_out.data_ptr()), _abi.current_stream(self.device)), "alink_head_eval")
+            return None
         L, R = self._dev(x[0]), self._dev(x[1])
         yd = self._dev(y)
         _abi.check(self.lib.alink_head_eval(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), L.shape[0],

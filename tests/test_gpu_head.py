@@ -305,3 +305,30 @@ def test_device_resident_fit_equals_step_by_step_fit(gpu, bs, n):
     assert sorted(ha) == sorted(hb)
     for k in ha:
         assert ha[k] == hb[k], (k, ha[k], hb[k])
+
+
+def test_custom_train_model_with_deferred_metrics_equals_the_step_by_step_form(gpu):
+    """customTrainModel(verbose=0) on a DenseHead enqueues its steps and reads their {loss, accuracy} back in blocks; with
+    `_defer_metrics = False` every step is synchronised and read on its own (the reference's shape, code/siamese.py:99-108).  Same
+    kernels, same batches, same order of the float64 sums: logs and weights equal bit for bit — across a block boundary (300
+    steps, blocks of 256), with held-out rows and without (valRatio 0)."""
+    from a_link_amd import siamese
+
+    def gen(seed):
+        rs = np.random.RandomState(seed)
+        while True:
+            n = int(rs.randint(10, 17))
+            L, R = rs.randn(n, 512).astype(np.float32), rs.randn(n, 512).astype(np.float32)
+            yield [L, R], (rs.rand(n, 1) > 0.3).astype(int)
+
+    for val_ratio in (0.2, 0.0):
+        out = []
+        for deferred in (True, False):
+            net = siamese.SiameseNetwork((512,), "ctm", 0.1, seed=31)
+            net._defer_metrics = deferred
+            np.random.seed(5)
+            logs = net.customTrainModel(gen(1), 2, 16, val_ratio, n_steps=16 * 300, verbose=0)
+            out.append((logs, net.siamese_net.get_weights()))
+        assert out[0][0] == out[1][0], (val_ratio, out[0][0], out[1][0])
+        for a, b in zip(out[0][1], out[1][1]):
+            assert np.array_equal(a, b)
