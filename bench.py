@@ -518,6 +518,7 @@ def main():
                                      "(csrc/conv3x3_lat.hip), bit-identical to the batched kernels (parity.batch1_rows_bit_equal_to_timed_batch)" % args.dtype)
 
     sel_out = None
+    smallres_weights = None
     if args.select_dtype != "none" and args.select_dtype != args.dtype:
         # ---- the exact-selection leg (north_star: ">= 10 k embeddings/s ... with selection sets identical to the
         # reference"): the SAME images through the mode whose selection sets equal the f32 arithmetic's — split precision
@@ -918,6 +919,26 @@ def main():
             hq.predict_device(E, E, li, ri, out=po)
         torch.cuda.synchronize()
         line["pair_scores_per_s_bf16"] = 3 * (1 << 20) / (time.perf_counter() - t1)
+        # BASELINE configs[0] / BASELINE.md §4 leg 3: the SmallRes 32 x 32 siamese (reference code/siamese.py:134-184) trained END TO END,
+        # one train_on_batch of 16 pairs (tower forward + backward on both sides, head, Adadelta; dropout masks drawn on the host)
+        from a_link_amd.smallres import SmallResNet
+        srn = SmallResNet((32, 32, 3), 2048, lr=0.1, seed=1, device=local_rank)
+        rs_ = np.random.RandomState(0)
+        sL = ((rs_.randint(0, 256, (16, 32, 32, 3)) - 128.0) / 128.0).astype(np.float32)
+        sR = ((rs_.randint(0, 256, (16, 32, 32, 3)) - 128.0) / 128.0).astype(np.float32)
+        sy = np.eye(2, dtype=np.float32)[rs_.randint(0, 2, 16)]
+        np.random.seed(0)
+        for _ in range(5):
+            srn.train_on_batch([sL, sR], sy)
+        ts = []
+        for _ in range(50):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            srn.train_on_batch([sL, sR], sy)
+            ts.append(time.perf_counter() - t1)
+        line["smallres32_train_step_ms"] = 1e3 * float(np.median(ts))
+        smallres_weights = srn.get_weights()
+        del srn
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle (kind "port": our CPU restatement; the reference's MXNet /
@@ -985,6 +1006,26 @@ def main():
         for s0 in range(0, 1 << 18, 1 << 14):
             oh.predict([Ec[lc[s0:s0 + (1 << 14)]], Ec[rc_[s0:s0 + (1 << 14)]]])
         ps_dt = time.perf_counter() - t1
+        # (v) the SmallRes 32 x 32 end-to-end step on the host (torch-CPU autograd oracle), median of 20
+        sm_cpu = None
+        try:
+            from oracle import smallres as OSM
+            if smallres_weights is None:
+                from a_link_amd.smallres import SmallResNet as _SRN
+                smallres_weights = _SRN((32, 32, 3), 2048, lr=0.1, seed=1, device=local_rank).get_weights()
+            osm = OSM.SmallResModel(smallres_weights, lr=0.1)
+            rs_ = np.random.RandomState(0)
+            sL = ((rs_.randint(0, 256, (16, 32, 32, 3)) - 128.0) / 128.0).astype(np.float32)
+            sR = ((rs_.randint(0, 256, (16, 32, 32, 3)) - 128.0) / 128.0).astype(np.float32)
+            sy = np.eye(2, dtype=np.float32)[rs_.randint(0, 2, 16)]
+            tsm = []
+            for _ in range(22):
+                t1 = time.perf_counter()
+                osm.train_on_batch([sL, sR], sy)
+                tsm.append(time.perf_counter() - t1)
+            sm_cpu = 1e3 * float(np.median(tsm[2:]))
+        except Exception as e_:
+            sm_cpu = repr(e_)
         line["cpu_baseline"] = {"value": n256["value"] if n256 else best_rate, "unit": "embeddings/s", "cores": cores, "kind": "port",
                                 "sample": ("ONE N = 256 forward of the same %s network through the torch-CPU f32 oracle (BASELINE.md §4, leg 1): %.1f s; "
                                            "smaller batches tried before it: %s" % (args.model, n256["seconds"], ", ".join("batch %d: %.2f/s" % t for t in trials)))
@@ -997,6 +1038,7 @@ def main():
                                                      "sample": "%d batch-1 forwards, each L2-normalised on its own: the "
                                                                "reference's get_feature loop" % n_one},
                                 "finetune_step_ms_cpu": 1e3 * float(np.median(ts)),
+                                "smallres32_train_step_ms_cpu": sm_cpu,
                                 "pair_scores_per_s_cpu": (1 << 18) / ps_dt}
         # parity of the timed output against the oracle on the same images — 32 rows where the CPU legs above produced them
         # (8 rows at a 1.6x margin was thin), max AND mean (north_star: 1e-3 cosine)
