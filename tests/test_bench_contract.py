@@ -45,3 +45,6 @@ def test_committed_bench_line_keeps_the_contract():
     assert c4["n_gpus"] == l["n_gpus"] and len(c4["pair_rows_per_rank"]) == l["n_gpus"] and c4["ranks_end_with_identical_student_weights"] is True
     assert sum(c4["pair_rows_per_rank"]) == 3840
     assert l["exact_selection"]["dtype"] == "f16x2" and l["exact_selection"]["max_abs_diff_vs_cpu_oracle"] < 2e-5
+    # BASELINE.md §4 leg 3: the head's fine-tune step AND the SmallRes 32 x 32 end-to-end step, on the GPU and on the host
+    assert 0 < l["finetune_step_ms"] < 1 and 0 < l["smallres32_train_step_ms"] < 20
+    assert l["cpu_baseline"]["finetune_step_ms_cpu"] > l["finetune_step_ms"] and l["cpu_baseline"]["smallres32_train_step_ms_cpu"] > l["smallres32_train_step_ms"]
