@@ -35,7 +35,7 @@ __device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned int k0, unsigned int 
 }
 
 // stream ids (counter word 3) keep the draws of different kernels disjoint under one seed
-enum { ST_NORMAL = 0, ST_POISSON = 1, ST_SALTPEPPER = 2, ST_PERLIN = 3 };
+enum { ST_NORMAL = 0, ST_POISSON = 1, ST_SALTPEPPER = 2, ST_PERLIN = 3, ST_DROPOUT = 4 };
 
 __device__ __forceinline__ U4 draw(unsigned long long seed, unsigned long long idx, unsigned int sub, unsigned int st) {
     U4 c{(unsigned int)idx, (unsigned int)(idx >> 32), sub, st};
@@ -101,6 +101,18 @@ __global__ __launch_bounds__(256) void affine_noise_kernel(const AffineNoise p) 
         for (int j = 0; j < 4; ++j)
             if (i0 + j >= 0 && i0 + j < p.count) p.out[i0 + j] = apply_noise(p, p.in[i0 + j], z[j]);
     }
+}
+
+// ---- Bernoulli keep-masks (Dropout of the SmallRes tower, code/siamese.py:146,153) -----------------------------
+// mask[e] = 1 with probability `keep`: the element's 24-bit uniform (word e & 3 of Philox block e >> 2) < keep.
+__global__ __launch_bounds__(256) void keep_mask_kernel(unsigned char* __restrict__ out, long long count, float keep,
+                                                        unsigned long long seed) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i0 = g * 4;
+    if (i0 >= count) return;
+    const U4 r = draw(seed, (unsigned long long)g, 0, ST_DROPOUT);
+    const unsigned int w[4] = {r.x, r.y, r.z, r.w};
+    for (int j = 0; j < 4 && i0 + j < count; ++j) out[i0 + j] = u01(w[j]) < keep ? 1 : 0;
 }
 
 // ---- Salt & pepper (code/noise.py:54-65, tuple-index semantics of NumPy < 1.23) --------------------
@@ -686,6 +698,15 @@ int alink_noise_uniform(const float* dev_in, float* dev_out, int64_t count, floa
     if (count == 0) return ALINK_OK;
     AffineNoise p{dev_in, dev_out, count, seed, offset, lo, hi, 2, affine_vec_ok(dev_in, dev_out, offset)};
     hipLaunchKernelGGL(affine_noise_kernel, g1(((long long)(offset & 3) + count + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+int alink_keep_masks(uint8_t* dev_out, int64_t count, float keep, uint64_t seed, void* stream) {
+    ALINK_REQUIRE(dev_out && count >= 0 && keep >= 0.f && keep <= 1.f, ALINK_EINVAL, "bad argument");
+    DeviceGuard dg(device_of_pointer(dev_out));
+    if (count == 0) return ALINK_OK;
+    hipLaunchKernelGGL(keep_mask_kernel, g1((count + 3) / 4), dim3(256), 0, (hipStream_t)stream, dev_out, (long long)count, keep, seed);
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
 }

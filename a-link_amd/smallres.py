@@ -137,7 +137,8 @@ class SmallResNet(KerasFitMixin):
         return out if as_torch else out.cpu().numpy()
 
     def draw_masks(self, n):
-        """keep-masks (u8) for the 2n tower passes: Dropout(0.25) after each pool (code/siamese.py:146,153)."""
+        """keep-masks (u8) for the 2n tower passes: Dropout(0.25) after each pool (code/siamese.py:146,153) — on the host, for callers
+        that pass `masks=` explicitly (the parity tests hand the same masks to the oracle); train_on_batch draws its own on the device."""
         e1, e2 = self.mask_sizes
         return (np.random.rand(2 * n * e1 + 2 * n * e2) >= 0.25).astype(np.uint8)
 
@@ -150,8 +151,15 @@ class SmallResNet(KerasFitMixin):
             sw = np.asarray([class_weight[c] for c in np.asarray(y).argmax(axis=1)], np.float32)
         swd = self._dev(sw) if sw is not None else None
         if masks is None and self.training_dropout:
-            masks = self.draw_masks(n)
-        md = self.torch.from_numpy(np.ascontiguousarray(masks, np.uint8)).to(self.device) if masks is not None else None
+            # the keep-masks are drawn ON THE DEVICE (Philox, keyed by one 31-bit seed taken from np.random per step): drawing
+            # 2n(e1 + e2) = 304,128 uniforms with np.random on the host was 0.74 of the step's 1.68 ms.  One np.random draw per step
+            # keeps the ranks of a multi-rank loop in step (alink_loop.sync_host_randomness) like the host-drawn masks did.
+            e1, e2 = self.mask_sizes
+            md = self.torch.empty(2 * n * (e1 + e2), dtype=self.torch.uint8, device=self.device)
+            _abi.check(self.lib.alink_keep_masks(_abi.ptr(md), md.numel(), 0.75, int(np.random.randint(0, 2 ** 31 - 1)),
+                                                 _abi.current_stream(self.device)), "alink_keep_masks")
+        else:
+            md = self.torch.from_numpy(np.ascontiguousarray(masks, np.uint8)).to(self.device) if masks is not None else None
         _abi.check(self.lib.alink_smallres_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
                                                       self.prescale, _abi.ptr(md), 0.0, 1, _abi.ptr(self._metrics),
                                                       _abi.current_stream(self.device)), "alink_smallres_train_step")

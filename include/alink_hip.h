@@ -412,6 +412,10 @@ int alink_noise_speckle(const float* dev_in, float* dev_out, int64_t count, floa
  * 24-bit uniform from the same (seed, element) keying */
 int alink_noise_uniform(const float* dev_in, float* dev_out, int64_t count, float lo, float hi,
                         uint64_t seed, uint64_t offset, void* stream);
+/* Dropout keep-masks for alink_smallres_train_step (Keras Dropout(0.25) after each pool of the SmallRes tower,
+ * code/siamese.py:146,153; TensorFlow draws them with an op-level generator that cannot be reproduced — only the keep
+ * probability is contractual): dev_out[e] = 1 with probability `keep`, from the same (seed, element) Philox keying. */
+int alink_keep_masks(uint8_t* dev_out, int64_t count, float keep, uint64_t seed, void* stream);
 /* noise.SaltPepper.addIndividualNoise (code/noise.py:54-65), tuple-index semantics: per image n_salt
  * elements (r,c,ch) <- 1 then n_pepper elements <- 0, r in [0,H-2], c in [0,W-2], ch in [0,C-2]. */
 int alink_noise_saltpepper(const float* dev_in, float* dev_out, int n_images, int H, int W, int C,

@@ -64,3 +64,36 @@ def test_reference_shaped_api(gpu, tmp_path):
     m2 = siamese.SmallRes((32, 32, 3), (2048,), str(tmp_path / "lowres"), 0.1, seed=2)
     assert m2.maybeLoadFromMemory()
     assert np.array_equal(m2.predict([L, R]), m.predict([L, R]))
+
+
+def test_device_drawn_dropout_masks(gpu):
+    """alink_keep_masks (the Dropout(0.25) keep-masks of the SmallRes tower, code/siamese.py:146,153, drawn on the device since
+    round 5): keep probability 0.75 to 3 sigma over 2 M elements, a different seed gives different masks, the same seed the same;
+    and a train step that draws its own masks consumes exactly ONE np.random draw (what keeps the ranks of a multi-rank loop in
+    step) and changes the weights."""
+    import torch
+    from a_link_amd.smallres import SmallResNet
+    lib = gpu.load()
+    n = 1 << 21
+    a, b, c = (torch.empty(n, dtype=torch.uint8, device="cuda") for _ in range(3))
+    gpu.check(lib.alink_keep_masks(gpu.ptr(a), n, 0.75, 11, None))
+    gpu.check(lib.alink_keep_masks(gpu.ptr(b), n, 0.75, 11, None))
+    gpu.check(lib.alink_keep_masks(gpu.ptr(c), n, 0.75, 12, None))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and not torch.equal(a, c) and int(a.max()) == 1
+    p = float(a.float().mean())
+    assert abs(p - 0.75) < 3 * np.sqrt(0.75 * 0.25 / n)
+    assert abs(float((a.float() * c.float()).mean()) - 0.75 * 0.75) < 4e-3          # independent streams
+    net = SmallResNet((32, 32, 3), 64, lr=0.1, seed=3)
+    rng = np.random.RandomState(0)
+    L = ((rng.randint(0, 256, (4, 32, 32, 3)) - 128.) / 128.).astype(np.float32)
+    R = ((rng.randint(0, 256, (4, 32, 32, 3)) - 128.) / 128.).astype(np.float32)
+    y = np.eye(2, dtype=np.float32)[rng.randint(0, 2, 4)]
+    w0 = net.get_weights()
+    np.random.seed(3)
+    net.train_on_batch([L, R], y)
+    after = np.random.rand()
+    np.random.seed(3)
+    np.random.randint(0, 2 ** 31 - 1)
+    assert after == np.random.rand()
+    assert any(not np.array_equal(u, v) for u, v in zip(w0, net.get_weights()))
