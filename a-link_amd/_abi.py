@@ -110,7 +110,6 @@ PROTOTYPES = {
     "alink_smallres_set_params": (_i, [_vp, _vp, _sz]),
     "alink_smallres_get_params": (_i, [_vp, _vp, _sz]),
     "alink_smallres_set_lr": (_i, [_vp, _f]),
-    "alink_smallres_set_graph": (_i, [_vp, _i]),
     "alink_smallres_grads_dev": (_vp, [_vp]),
     "alink_smallres_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "alink_smallres_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _f, _i, _vp, _vp]),

@@ -120,22 +120,7 @@ struct alink_smallres {
     float* ws = nullptr;               // split-K slabs of sgemm
     size_t ws_floats = 0;
     std::vector<void*> allocs;
-    // The train step is ~45 dependent launches of small kernels (0.8 ms of launch-to-launch latency for 0.2 ms of work):
-    // captured once per (operand pointers, batch, learning rate) into a hipGraph and replayed (alink_smallres_set_graph;
-    // default on).  Callers that hand in the same staging buffers every step (a-link_amd/smallres.py does) replay from the
-    // second step on; new pointers capture a new graph (at most 8 kept).
-    struct StepGraph {
-        const float *L, *R, *y, *sw;
-        const uint8_t* masks;
-        float* metrics;
-        int n, prescale, apply;
-        float grad_scale, lr;
-        hipGraphExec_t exec;
-    };
-    bool use_graph = true;
-    std::vector<StepGraph> graphs;
     ~alink_smallres() {
-        for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
         for (void* p : allocs) (void)hipFree(p);
         if (head) alink_head_destroy(head);
     }
@@ -350,69 +335,12 @@ int alink_smallres_eval(alink_smallres_t* m, const float* dev_L, const float* de
     return alink_head_eval(m->head, m->f, m->f + (size_t)n * m->feat, dev_y, n, dev_metrics, stream);
 }
 
-static int smallres_step_launches(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
-                                  const float* dev_sw, int n, int prescale, const uint8_t* dev_masks, float grad_scale,
-                                  int apply, float* dev_metrics, void* stream);
-
-int alink_smallres_set_graph(alink_smallres_t* m, int on) {
-    ALINK_REQUIRE(m, ALINK_EINVAL, "NULL model");
-    m->use_graph = on != 0;
-    return ALINK_OK;
-}
-
 int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
                               const float* dev_sw, int n, int prescale, const uint8_t* dev_masks, float grad_scale,
                               int apply, float* dev_metrics, void* stream) {
     ALINK_REQUIRE(m && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
     DeviceGuard dg(m->device);
-    hipStream_t st = (hipStream_t)stream;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    // the legacy default stream cannot be captured; a stream the caller is already capturing simply receives the launches
-    const bool can_graph = m->use_graph && st != nullptr && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
-    if (!can_graph) return smallres_step_launches(m, dev_L, dev_R, dev_y, dev_sw, n, prescale, dev_masks, grad_scale, apply, dev_metrics, stream);
-    // the pair head re-derives packed / rounded copies of its weights behind host-side flags: raise them, so that a capture
-    // always holds those launches (they are idempotent) and a replay — which runs no host code of the head — leaves them raised
-    (void)alink_head_params_dev(m->head);
-    for (auto& g : m->graphs)
-        if (g.L == dev_L && g.R == dev_R && g.y == dev_y && g.sw == dev_sw && g.masks == dev_masks && g.metrics == dev_metrics && g.n == n &&
-            g.prescale == prescale && g.apply == apply && g.grad_scale == grad_scale && g.lr == m->lr) {
-            ALINK_HIP(hipGraphLaunch(g.exec, st));
-            (void)alink_head_params_dev(m->head);
-            return ALINK_OK;
-        }
-    hipGraph_t graph = nullptr;
-    ALINK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    const int rc = smallres_step_launches(m, dev_L, dev_R, dev_y, dev_sw, n, prescale, dev_masks, grad_scale, apply, dev_metrics, stream);
-    const hipError_t ee = hipStreamEndCapture(st, &graph);
-    if (rc || ee != hipSuccess || !graph) {
-        if (graph) (void)hipGraphDestroy(graph);
-        (void)hipGetLastError();
-        if (rc) return rc;
-        m->use_graph = false;                       // capture is not available here: plain launches from now on
-        return smallres_step_launches(m, dev_L, dev_R, dev_y, dev_sw, n, prescale, dev_masks, grad_scale, apply, dev_metrics, stream);
-    }
-    hipGraphExec_t exec = nullptr;
-    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess) {
-        (void)hipGetLastError();
-        m->use_graph = false;
-        return smallres_step_launches(m, dev_L, dev_R, dev_y, dev_sw, n, prescale, dev_masks, grad_scale, apply, dev_metrics, stream);
-    }
-    if (m->graphs.size() >= 8) {
-        (void)hipGraphExecDestroy(m->graphs.front().exec);
-        m->graphs.erase(m->graphs.begin());
-    }
-    m->graphs.push_back({dev_L, dev_R, dev_y, dev_sw, dev_masks, dev_metrics, n, prescale, apply, grad_scale, m->lr, exec});
-    ALINK_HIP(hipGraphLaunch(exec, st));
-    (void)alink_head_params_dev(m->head);
-    return ALINK_OK;
-}
-
-static int smallres_step_launches(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
-                                  const float* dev_sw, int n, int prescale, const uint8_t* dev_masks, float grad_scale,
-                                  int apply, float* dev_metrics, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int rc = tower_pair_fwd(m, dev_L, dev_R, n, prescale, dev_masks, st, true);
     if (rc) return rc;

@@ -49,8 +49,6 @@ class SmallResNet(KerasFitMixin):
         self.set_weights(ws)
         self._metrics = torch.zeros(2, dtype=torch.float32, device=self.device)
         self.prescale = 1 if prescale else 0
-        self._stage = {}          # persistent device buffers the step's operands are copied into: the train step's hipGraph is
-                                  # keyed by its operand pointers (alink_smallres_set_graph) and replays only for the same ones
 
     def __del__(self):
         try:
@@ -144,38 +142,24 @@ class SmallResNet(KerasFitMixin):
         e1, e2 = self.mask_sizes
         return (np.random.rand(2 * n * e1 + 2 * n * e2) >= 0.25).astype(np.uint8)
 
-    def _staged(self, key, a, dtype=None):
-        """`a` (host array or tensor) copied into a device buffer whose address is the same from step to step"""
-        torch = self.torch
-        dtype = dtype or torch.float32
-        if not isinstance(a, torch.Tensor):
-            a = torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint8 if dtype is torch.uint8 else np.float32))
-        buf = self._stage.get((key, tuple(a.shape)))
-        if buf is None:
-            buf = self._stage[(key, tuple(a.shape))] = torch.empty(tuple(a.shape), dtype=dtype, device=self.device)
-        buf.copy_(a)
-        return buf
-
     def train_on_batch(self, x, y, class_weight=None, sample_weight=None, masks=None):
-        n = len(y)
+        L, R, yd = self._dev(x[0]), self._dev(x[1]), self._dev(y)
+        n = L.shape[0]
         assert n <= MAXN, "train batches larger than %d pairs are not supported" % MAXN
-        L, R, yd = self._staged("L", x[0]), self._staged("R", x[1]), self._staged("y", y)
         sw = sample_weight
         if sw is None and class_weight is not None:
             sw = np.asarray([class_weight[c] for c in np.asarray(y).argmax(axis=1)], np.float32)
-        swd = self._staged("sw", sw) if sw is not None else None
+        swd = self._dev(sw) if sw is not None else None
         if masks is None and self.training_dropout:
             # the keep-masks are drawn ON THE DEVICE (Philox, keyed by one 31-bit seed taken from np.random per step): drawing
             # 2n(e1 + e2) = 304,128 uniforms with np.random on the host was 0.74 of the step's 1.68 ms.  One np.random draw per step
             # keeps the ranks of a multi-rank loop in step (alink_loop.sync_host_randomness) like the host-drawn masks did.
             e1, e2 = self.mask_sizes
-            md = self._stage.get(("masks", n))
-            if md is None:
-                md = self._stage[("masks", n)] = self.torch.empty(2 * n * (e1 + e2), dtype=self.torch.uint8, device=self.device)
+            md = self.torch.empty(2 * n * (e1 + e2), dtype=self.torch.uint8, device=self.device)
             _abi.check(self.lib.alink_keep_masks(_abi.ptr(md), md.numel(), 0.75, int(np.random.randint(0, 2 ** 31 - 1)),
                                                  _abi.current_stream(self.device)), "alink_keep_masks")
         else:
-            md = self._staged("masks_given", np.ascontiguousarray(masks, np.uint8), self.torch.uint8) if masks is not None else None
+            md = self.torch.from_numpy(np.ascontiguousarray(masks, np.uint8)).to(self.device) if masks is not None else None
         _abi.check(self.lib.alink_smallres_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
                                                       self.prescale, _abi.ptr(md), 0.0, 1, _abi.ptr(self._metrics),
                                                       _abi.current_stream(self.device)), "alink_smallres_train_step")

@@ -347,9 +347,6 @@ size_t alink_smallres_num_params(const alink_smallres_t* m);
 int alink_smallres_set_params(alink_smallres_t* m, const float* host, size_t count);
 int alink_smallres_get_params(const alink_smallres_t* m, float* host, size_t count);
 int alink_smallres_set_lr(alink_smallres_t* m, float lr);
-/* 1 (default): alink_smallres_train_step replays its ~45 dependent launches as ONE hipGraph, captured per (operand pointers,
- * batch size, learning rate) — hand in the same buffers every step; 0: plain launches (A/B, debugging). */
-int alink_smallres_set_graph(alink_smallres_t* m, int on);
 float* alink_smallres_grads_dev(alink_smallres_t* m);      /* flat tower+head gradients (all-reduce) */
 /* predict: probs (n,2).  n <= 256 per call. */
 int alink_smallres_forward(alink_smallres_t* m, const float* dev_L, const float* dev_R, int n, int prescale,

@@ -22,7 +22,3 @@ Ld, Rd, yd = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda(), torch.from_
 md = torch.from_numpy(m).cuda()
 net.training_dropout = False
 print("train_on_batch (device arrays, no dropout)     %.3f ms" % med(lambda: net.train_on_batch([Ld, Rd], yd)))
-
-net2 = SmallResNet((32, 32, 3), 2048, lr=0.1, seed=1)
-net2.lib.alink_smallres_set_graph(net2.h, 0)
-print("train_on_batch (host arrays, masks drawn), plain launches %.3f ms" % med(lambda: net2.train_on_batch([L, R], y)))
