@@ -558,3 +558,34 @@ def test_bench_preflight_under_a_launcher_with_one_rank(gpu):
     assert r.returncode == 0, r.stderr[-800:]
     assert "[preflight] rank 0 of 1" in r.stdout and "all_reduce, merge_topk, row_shards, broadcast_calibration ok" in r.stdout, r.stdout[-400:]
     assert time.perf_counter() - t < 120
+
+
+def test_settled_pool_pass_survives_a_self_recalibration(gpu):
+    """the exact handles re-calibrate themselves when a batch leaves the split-precision range, which changes the last
+    bits of everything embedded afterwards — inside committee_pool_topk_settled the gallery (embedded first) and the rows settled
+    later would mix two sets of scales.  Here the exact members are calibrated on images 64x DARKER than the pool: the screening
+    view's pool pass (or the first exact batch) leaves the range, the scales drop mid-pass; the function must notice
+    (info["recalibrated"]), run the pass again under the new scales, and return what the all-exact pass returns under those scales."""
+    from a_link_amd import distributed as D
+    from a_link_amd.backbone import IRBackbone
+    from a_link_amd.head import DenseHead
+    pool, gallery, params = _settle_case()
+    exa, heads = [], []
+    for m, p in enumerate(params[:2]):
+        e = IRBackbone(p, image_size=(32, 32), max_batch=64, dtype="f16x2")
+        e.calibrate((pool[:32].astype(np.float32) / 64.0))           # far darker than what is to come: 64x smaller activations
+        exa.append(e)
+        h = DenseHead(512, lr=0.1, seed=10 + m)
+        ws = h.get_weights()
+        ws[4] = ws[4] * np.float32(40.0)
+        h.set_weights(ws)
+        heads.append(h)
+    before = [e.state()["scale_exponents"] for e in exa]
+    pd, gd = torch.from_numpy(pool).cuda(), torch.from_numpy(gallery).cuda()
+    info = {}
+    v, i = D.committee_pool_topk_settled([e.screening_view() for e in exa], exa, heads, pd, gd, 48, shard_offset=0, info=info, min_sample=8, audit=8)
+    after = [e.state()["scale_exponents"] for e in exa]
+    assert info["recalibrated"] is True and after != before and all(a <= b for aa, bb in zip(after, before) for a, b in zip(aa, bb))
+    want_v, want_i = D.committee_pool_topk(exa, heads, pd, gd, 48, shard_offset=0)           # all-exact under the scales it ended with
+    assert [e.state()["scale_exponents"] for e in exa] == after
+    assert torch.equal(i, want_i) and torch.equal(v, want_v)
