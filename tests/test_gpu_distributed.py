@@ -563,7 +563,7 @@ def test_bench_preflight_under_a_launcher_with_one_rank(gpu):
 def test_settled_pool_pass_survives_a_self_recalibration(gpu):
     """the exact handles re-calibrate themselves when a batch leaves the split-precision range, which changes the last
     bits of everything embedded afterwards — inside committee_pool_topk_settled the gallery (embedded first) and the rows settled
-    later would mix two sets of scales.  Here the exact members are calibrated on images 4096x DARKER than the pool: the screening
+    later would mix two sets of scales.  Here the exact members are calibrated on ordinary images and the pool is 64x BRIGHTER: the screening
     view's pool pass (or the first exact batch) leaves the range, the scales drop mid-pass; the function must notice
     (info["recalibrated"]), run the pass again under the new scales, and return what the all-exact pass returns under those scales."""
     from a_link_amd import distributed as D
@@ -573,7 +573,7 @@ def test_settled_pool_pass_survives_a_self_recalibration(gpu):
     exa, heads = [], []
     for m, p in enumerate(params[:2]):
         e = IRBackbone(p, image_size=(32, 32), max_batch=64, dtype="f16x2")
-        e.calibrate((pool[:32].astype(np.float32) / 4096.0))         # far darker than what is to come: the pool's activations leave these scales' range
+        e.calibrate(pool[:32])                                      # ordinary pixels; the pool below is 64x brighter: its activations leave these scales' range
         exa.append(e)
         h = DenseHead(512, lr=0.1, seed=10 + m)
         ws = h.get_weights()
@@ -581,7 +581,7 @@ def test_settled_pool_pass_survives_a_self_recalibration(gpu):
         h.set_weights(ws)
         heads.append(h)
     before = [e.state()["scale_exponents"] for e in exa]
-    pd, gd = torch.from_numpy(pool).cuda(), torch.from_numpy(gallery).cuda()
+    pd, gd = torch.from_numpy(pool).cuda().float() * 64.0, torch.from_numpy(gallery).cuda().float()
     info = {}
     v, i = D.committee_pool_topk_settled([e.screening_view() for e in exa], exa, heads, pd, gd, 48, shard_offset=0, info=info, min_sample=8, audit=8)
     after = [e.state()["scale_exponents"] for e in exa]
