@@ -308,6 +308,13 @@ def _shards_worker(rank, world, port, q):
         np.random.seed(rank)
         AL.sync_host_randomness(nzs, sh)
         ok &= nzs[0].stream_state() == (100, 0) and sh.same_everywhere(float(np.random.rand()))
+        # ranks whose feature models carry different calibration states must not start an iteration: every rank raises
+        try:
+            AL.alink_iteration(AL.LoopState(), AL.Flags(), None, np.zeros((4, 1)), None, None, [], None, None, None, None, SIZE,
+                               group=dist.group.WORLD, calibration_of=lambda: {"scale_exponents": [rank]})
+            ok = False
+        except RuntimeError as e:
+            ok &= "calibration state differs between ranks" in str(e)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
