@@ -129,6 +129,7 @@ PROTOTYPES = {
     "alink_resize_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "alink_pgd_step": (_i, [_vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _vp]),
     "alink_perturb_images": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "alink_perturb_images_multi": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "alink_arcface_margin_workspace_bytes": (_sz, [_i, _i, _i]),
     "alink_arcface_margin_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "alink_contrastive_loss": (_i, [_vp, _vp, _vp, _i64, _i, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -629,19 +629,29 @@ __global__ __launch_bounds__(256) void resize_kernel(const ResizeP p) {
 // the output is laid out [2][n][Hc/2][W][3] — all top halves, then all bottom halves — which is what
 // noise.PredictionWrappedModel.predict (code/noise.py:158-168) slices before embedding.
 struct PerturbP {
-    const float* img;      // [Hc][W][3]
+    const float* img;      // [n_img][Hc][W][3]
+    const int* img_of;     // image of candidates [g * group, (g + 1) * group): img_of[g]; nullptr: image 0 for all
     const double* xs;      // [n][5k]
     float* out;
-    int n, k, Hc, W, split;
+    int n, k, Hc, W, split, group;
 };
 
 __global__ __launch_bounds__(256) void perturb_kernel(const PerturbP p) {
     const int cand = blockIdx.x, tid = threadIdx.x;
     const long long per = (long long)p.Hc * p.W * 3, half = per / 2;
+    const float* img = p.img + (p.img_of ? (size_t)p.img_of[cand / p.group] * per : 0);
     float* top = p.split ? p.out + (size_t)cand * half : p.out + (size_t)cand * per;
     float* bot = p.split ? p.out + ((size_t)p.n + cand) * half : top + half;
-    for (long long i = tid; i < half; i += 256) { top[i] = p.img[i]; bot[i] = p.img[half + i]; }
-    if ((per & 1) && tid == 0) bot[half] = p.img[per - 1];      // odd Hc never splits (host refuses)
+    if ((half & 3) == 0 && ((((uintptr_t)img) | ((uintptr_t)p.out)) & 15) == 0) {      // 16-byte lanes (112-wide pairs: always)
+        const float4* s0 = (const float4*)img;
+        const float4* s1 = (const float4*)(img + half);
+        float4* d0 = (float4*)top;
+        float4* d1 = (float4*)bot;
+        for (long long i = tid; i < half / 4; i += 256) { d0[i] = s0[i]; d1[i] = s1[i]; }
+    } else {
+        for (long long i = tid; i < half; i += 256) { top[i] = img[i]; bot[i] = img[half + i]; }
+        if ((per & 1) && tid == 0) bot[half] = img[per - 1];      // odd Hc never splits (host refuses)
+    }
     __syncthreads();
     if (tid == 0) {
         const double* x = p.xs + (size_t)cand * 5 * p.k;
@@ -912,11 +922,16 @@ int alink_resize_bilinear(const float* dev_in, float* dev_out, int n, int H, int
 
 int alink_perturb_images(const float* dev_img, const double* dev_xs, int n, int k, int Hc, int W, int split,
                          float* dev_out, void* stream) {
-    ALINK_REQUIRE(dev_img && dev_xs && dev_out && n >= 0 && k >= 0 && Hc > 0 && W > 0, ALINK_EINVAL, "bad argument");
+    return alink_perturb_images_multi(dev_img, nullptr, 1, dev_xs, n, k, Hc, W, split, dev_out, stream);
+}
+
+int alink_perturb_images_multi(const float* dev_imgs, const int* dev_img_of, int group, const double* dev_xs, int n, int k,
+                               int Hc, int W, int split, float* dev_out, void* stream) {
+    ALINK_REQUIRE(dev_imgs && dev_xs && dev_out && n >= 0 && k >= 0 && Hc > 0 && W > 0 && group > 0, ALINK_EINVAL, "bad argument");
     DeviceGuard dg(device_of_pointer(dev_out));
     ALINK_REQUIRE(!split || (Hc % 2) == 0, ALINK_EINVAL, "split needs an even number of rows, got %d", Hc);
     if (n == 0) return ALINK_OK;
-    PerturbP p{dev_img, dev_xs, dev_out, n, k, Hc, W, split};
+    PerturbP p{dev_imgs, dev_img_of, dev_xs, dev_out, n, k, Hc, W, split, group};
     hipLaunchKernelGGL(perturb_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, p);
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;

@@ -121,14 +121,57 @@ class DifferentialEvolutionSolver(object):
     def _budget(self, n):
         return int(max(0, min(n, self.maxfun - self._nfev + 1)))
 
-    def _calculate_population_energies(self):
-        n = self._budget(len(self.population))
-        self.population_energies = np.array(self.func(self._scale_parameters(self.population[:n]), *self.args))
+    # ---- ask / tell: the two halves of an evaluation --------------------------------------------------
+    # The reference's loop is func(whole population) inside the solver (code/differential_evolution.py:630-645, 692-715).
+    # ask() returns the scaled candidates the solver wants evaluated next — the initial population first, then one
+    # generation's trials — and tell() takes their energies and does the bookkeeping.  __next__ / solve() are
+    # tell(func(ask())); attack.PixelAttacker.attack_all advances K solvers with ONE batched objective launch per step
+    # through the same two calls, so a search's trajectory does not depend on how many searches share the launch.
+    # aux (optional, one row per candidate): carried along with the members exactly like their parameters — aux[0] is
+    # always the row that belongs to the best member (what the attack's success test needs: the member's two class scores).
+    def ask(self):
+        if np.all(np.isinf(self.population_energies)):
+            n = self._budget(len(self.population))
+            self._pending = ("init", n, None)
+            return self._scale_parameters(self.population[:n])
+        if self.dither is not None:
+            self.scale = self.random_number_generator.rand() * (self.dither[1] - self.dither[0]) + self.dither[0]
+        n = self._budget(self.num_population_members)
+        trials = self._trials_compat(n) if self.rng_compat else self._trials_fast(n)
+        self._pending = ("gen", n, trials)
+        return self._scale_parameters(trials)
+
+    def tell(self, energies, aux=None):
+        kind, n, trials = self._pending
+        self._pending = None
         self._nfev += n
-        best = np.argmin(self.population_energies)
+        if kind == "init":
+            self.population_energies = np.array(energies)
+            best = np.argmin(self.population_energies)
+            e = self.population_energies
+            e[0], e[best] = e[best], e[0]
+            self.population[[0, best], :] = self.population[[best, 0], :]
+            if aux is not None:
+                self.aux = np.array(aux)
+                self.aux[[0, best]] = self.aux[[best, 0]]
+            return
+        energies = np.asarray(energies)
+        # member-wise greedy selection; position 0 also tracks the best trial seen so far in this sweep
         e = self.population_energies
-        e[0], e[best] = e[best], e[0]
-        self.population[[0, best], :] = self.population[[best, 0], :]
+        for c in np.nonzero(energies < e[:n])[0]:
+            if energies[c] < e[c]:                     # e[0] may have dropped since the vector compare
+                self.population[c] = trials[c]
+                e[c] = energies[c]
+                if aux is not None:
+                    self.aux[c] = aux[c]
+                if energies[c] < e[0]:
+                    e[0] = energies[c]
+                    self.population[0] = trials[c]
+                    if aux is not None:
+                        self.aux[0] = aux[c]
+
+    def _calculate_population_energies(self):
+        self.tell(self.func(self.ask(), *self.args))
 
     # ---- one generation ---------------------------------------------------------------------------
     def _base_and_diff(self, kind, cand, s):
@@ -215,45 +258,44 @@ class DifferentialEvolutionSolver(object):
     def __next__(self):
         if np.all(np.isinf(self.population_energies)):
             self._calculate_population_energies()
-        if self.dither is not None:
-            self.scale = self.random_number_generator.rand() * (self.dither[1] - self.dither[0]) + self.dither[0]
-        n = self._budget(self.num_population_members)
-        trials = self._trials_compat(n) if self.rng_compat else self._trials_fast(n)
-        energies = np.asarray(self.func(self._scale_parameters(trials), *self.args))
-        self._nfev += n
-        # member-wise greedy selection; position 0 also tracks the best trial seen so far in this sweep
-        e = self.population_energies
-        for c in np.nonzero(energies < e[:n])[0]:
-            if energies[c] < e[c]:                     # e[0] may have dropped since the vector compare
-                self.population[c] = trials[c]
-                e[c] = energies[c]
-                if energies[c] < e[0]:
-                    e[0] = energies[c]
-                    self.population[0] = trials[c]
+        self.tell(self.func(self.ask(), *self.args))
         return self.x, self.population_energies[0]
 
     next = __next__
 
+    def after_generation(self, callback_says=None):
+        """The reference's tests after a generation (code/differential_evolution.py:563-585), in its order: the callback's
+        verdict (callback_says: what callback(best x, convergence=) returned, when the caller has evaluated it itself),
+        then the spread of the energies.  Returns None to go on, else the stop message key."""
+        if callback_says is None and self.callback:
+            with np.errstate(divide="ignore"):
+                conv = self.tol / self.convergence
+            callback_says = self.callback(self._scale_parameters(self.population[0]), convergence=conv)
+        if callback_says is True:
+            return "callback"
+        if np.std(self.population_energies) <= self.atol + self.tol * np.abs(np.mean(self.population_energies)):
+            return "success"
+        return None
+
+    def result(self, nit, stop):
+        """stop: "callback" | "success" | "maxiter" (what ended the search)"""
+        return OptimizeResult(x=self.x, fun=self.population_energies[0], nfev=self._nfev, nit=nit,
+                              message=MESSAGES[stop], success=(stop == "success"))
+
     def solve(self):
-        nit, warning_flag = 0, False
-        status_message = MESSAGES["success"]
+        nit, stop = 0, "success"
         if np.all(np.isinf(self.population_energies)):
             self._calculate_population_energies()
         for nit in range(1, self.maxiter + 1):
             next(self)
             if self.disp:
                 print("differential_evolution step %d: f(x)= %g" % (nit, self.population_energies[0]))
-            with np.errstate(divide="ignore"):
-                conv = self.tol / self.convergence
-            if self.callback and self.callback(self._scale_parameters(self.population[0]), convergence=conv) is True:
-                warning_flag, status_message = True, MESSAGES["callback"]
-                break
-            if np.std(self.population_energies) <= self.atol + self.tol * np.abs(np.mean(self.population_energies)):
+            stop = self.after_generation()
+            if stop:
                 break
         else:
-            status_message, warning_flag = MESSAGES["maxiter"], True
-        result = OptimizeResult(x=self.x, fun=self.population_energies[0], nfev=self._nfev, nit=nit,
-                                message=status_message, success=(warning_flag is not True))
+            stop = "maxiter"
+        result = self.result(nit, stop)
         if self.polish:
             from scipy.optimize import minimize
             one = (lambda x, *a: float(np.asarray(self.func(np.asarray(x)[None, :], *a)).ravel()[0]))

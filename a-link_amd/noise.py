@@ -250,12 +250,15 @@ class AdversarialNoise(Noise):
     rank that attacks rows lo : hi of the batch (rows=(lo, total)) finds what the whole-batch call finds for them —
     the search is 0.5 s per pair at the defaults, the part of an A2-LINK iteration that most needs every GPU."""
 
-    def __init__(self, model, sess, feature_model, seed=None, device=None, pixel_count=40, maxiter=50, popsize=250, search="exact"):
+    def __init__(self, model, sess, feature_model, seed=None, device=None, pixel_count=40, maxiter=50, popsize=250, search="exact",
+                 lockstep=32):
         super(AdversarialNoise, self).__init__(model, sess, feature_model, seed=seed, device=device)
         from . import attack
         self.e2e_model = PredictionWrappedModel(model, feature_model)
         # search="screen": the search's candidates go through the feature model's 16-bit screening form (attack._DevicePairScorer)
-        self.attacker = attack.PixelAttacker(self.e2e_model, search=search)
+        # lockstep: searches advanced together on the device (attack._LockstepEngine; 0 = one pair after another, the
+        # reference's shape) — the attacked images do not depend on it
+        self.attacker = attack.PixelAttacker(self.e2e_model, search=search, lockstep=lockstep)
         self.search = dict(pixel_count=pixel_count, maxiter=maxiter, popsize=popsize)
 
     def addPairNoise(self, image_pairs, target_labels, rows=None):

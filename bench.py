@@ -132,6 +132,21 @@ def _timed(fn, reps, barrier, dist):
     return float(t.item()), r
 
 
+def _timed_once(fn, barrier, dist):
+    """one timed call (already warm), max over ranks"""
+    import torch
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    r = fn()
+    torch.cuda.synchronize()
+    barrier()
+    t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), r
+
+
 def _preflight(dist, rank, world, local_rank, quiet=False):
     """Every collective shape the timed legs use, on tiny known data, each under a watchdog: a rank that cannot reach its peers
     fails HERE, within seconds and with the step's name, instead of hanging the timed run.  Returns 0 / raises."""
@@ -233,6 +248,8 @@ def main():
                     "all-exact and screen-then-settle)")
     ap.add_argument("--config3-shard", type=int, default=12500, help="pool images per GPU in the config-3 leg (BASELINE configs[2]: 100k / 8)")
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 leg (one A-LINK iteration, IR-100 teacher: all-exact and screen-then-settle)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (the A2-LINK few-pixel attack, K pairs' searches in lock-step)")
+    ap.add_argument("--config5-pairs", type=int, default=16, help="pairs per GPU the config-5 leg attacks in its 16-bit search modes (half as many in the exact mode)")
     ap.add_argument("--no-configs1", action="store_true", help="skip the configs[1] leg (IR-50, one 256-image batch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-small", action="store_true", help="skip the N = 256 CPU forward (~30 s of host time): batches <= 128 only")
@@ -848,6 +865,72 @@ def main():
                                   "identical_means": "oracle-query count, number of fine-tunes and the student's weights afterwards equal the all-exact iteration's bit for bit (compared in this run)"},
                 "oracle_queries": st_e.active_count, "finetunes": st_e.finetunes,
                 "note": "whole iteration on the wall clock (max over ranks): noise kernels, embeddings, heads, host-side selection, collectives, fine-tune"}
+
+    if not args.no_config5 and not args.no_extras:
+        # ---- BASELINE configs[4] ("A2-LINK: adversarial-noise batch"): the reference's adversarial noise is the black-box few-pixel
+        # attack (code/noise.py:171-188 -> code/attack.py:91-103: 40 pixels, population 200, 50 generations = 20,400 backbone forwards per
+        # pair), `adversarial` is in its default --noise list (code/ALINK_arc.py:41).  attack_all advances the pairs' searches in
+        # LOCK-STEP (a-link_amd/attack.py: 400 x K images per launch, the success test read off the generation's own scores, host
+        # bookkeeping hidden behind the other lane).  Timed: every search run to maxiter (early_stop=False — the cost of an attack that
+        # does not succeed, the worst case) in the three search arithmetics; beside each the SAME handle's plain in-batch embedding rate
+        # in this run, whose fraction is what the lock-step engine leaves on the table.  Each rank attacks its own pairs (no collective).
+        from a_link_amd import attack as ATK, noise as NZ5, siamese as S5
+        conv5 = S5.ArcFace((112, 112), "synthetic:r100:1:normalized", dtype="f16x2", screen_dtype="auto")
+        conv5.model.model.calibrate(x[:64])
+        stu5 = S5.SiameseNetwork((512,), "/tmp/alink_student5", 0.1, seed=1)
+        wrapped5 = NZ5.PredictionWrappedModel(stu5, conv5)
+        rs5 = np.random.RandomState(77 + rank)
+        n5 = max(2, args.config5_pairs)
+        imgs5 = [rs5.randint(0, 256, (224, 112, 3)).astype(np.float32) for _ in range(n5)]
+        tg5 = [[0, 1]] * n5
+        sd5 = [1000 * rank + i for i in range(n5)]
+        c5 = {}
+        for mode5, npairs in (("screen", n5), ("bf16", n5), ("exact", max(2, n5 // 2))):
+            att5 = ATK.PixelAttacker(wrapped5, search=mode5)
+            bb5 = ATK._device_parts(wrapped5, mode5)[0]
+            att5.attack_all(imgs5[:2], tg5[:2], (224, 112), seeds=sd5[:2], maxiter=2, early_stop=False)          # warm-up
+            t5, got5 = _timed_once(lambda: att5.attack_all(imgs5[:npairs], tg5[:npairs], (224, 112), seeds=sd5[:npairs], early_stop=False), barrier, dist)
+            if mode5 == "screen":
+                first5 = got5[0]
+            ev5 = sum(int(r_.nfev) for r_ in att5.last_results)
+            o5 = torch.empty((B, 512), dtype=torch.float32, device="cuda")
+            bb5.embed_device(x, out=o5)
+            tb5, _ = _timed_once(lambda: [bb5.embed_device(x, out=o5) for _ in range(3)], barrier, dist)
+            inb = world * 3 * B / tb5
+            fps = world * 2 * ev5 / t5
+            c5[mode5] = {"search_dtype": bb5.dtype, "pairs_per_gpu": npairs, "lockstep": att5.lockstep, "s_per_pair": t5 / npairs,
+                         "generations_per_pair": float(np.mean([r_.nit for r_ in att5.last_results])),
+                         "backbone_forwards_per_pair": 2 * ev5 / npairs, "backbone_forwards_per_s": fps,
+                         "same_handle_in_batch_embeddings_per_s": inb, "frac_of_in_batch_rate": fps / inb,
+                         "frac_mfma_peak_algorithmic": fps * gflop_per_emb / 1e3 / (MFMA_PEAK_TFLOPS * world)}
+            del o5
+        # one pair after another (the reference's shape, rounds 1-5 of this package): one pair with a success test that never stops
+        # the search (the same 50 generations as above: its image must equal the lock-step run's for that pair), then two pairs
+        # with the real test on (searches stop early) against the lock-step form
+        seq5 = ATK.PixelAttacker(wrapped5, search="screen", lockstep=0)
+        seq5.attack_success = lambda *a_, **k_: None
+        seq5.attack_all(imgs5[:1], tg5[:1], (224, 112), seeds=sd5[:1], maxiter=2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        w5 = seq5.attack_all(imgs5[:1], tg5[:1], (224, 112), seeds=sd5[:1])
+        tseq = time.perf_counter() - t1
+        same5 = bool(np.array_equal(w5[0], first5))
+        w5 = ATK.PixelAttacker(wrapped5, search="screen", lockstep=0).attack_all(imgs5[:2], tg5[:2], (224, 112), seeds=sd5[:2])
+        g5 = ATK.PixelAttacker(wrapped5, search="screen").attack_all(imgs5[:2], tg5[:2], (224, 112), seeds=sd5[:2])
+        same5 = same5 and bool(np.array_equal(np.stack(w5), np.stack(g5)))
+        assert same5 or not args.strict, "lock-step few-pixel attack differs from the sequential one"
+        if rank == 0:
+            line["config5"] = dict(c5, **{
+                "workload": "A2-LINK adversarial noise = the few-pixel differential-evolution attack at the reference's defaults (40 pixels, "
+                            "population 200, 50 generations + the initial population = 20,400 IR-100 forwards per 112x112 pair), every search run "
+                            "to maxiter; pairs' searches advanced in lock-step, 2 lanes x 16 searches = 6,400 images per launch chain",
+                "n_gpus": world,
+                "one_pair_after_another_screen": {"pairs": 1, "s_per_pair": tseq, "backbone_forwards_per_s": (20400 + 100) / tseq,
+                                                  "note": "lockstep=0: a 400-image launch, a synchronisation and a 2-image success-test forward per generation"},
+                "lockstep_images_identical_to_one_after_another": same5,
+                "identical_means": "attacked image of pair 0 after 50 generations, and of two pairs whose searches stop on success, equal the one-after-another form's bit for bit (compared in this run)",
+                "per_iteration_note": "a config-4-sized iteration has 3,840 pairs: x s_per_pair / n_gpus"})
+        del conv5, stu5, wrapped5
 
     if rank == 0 and not args.no_extras and args.dtype == "f32":
         # ---- float32 mode: every convolution and the FC on gemm32_kernel (v_mfma_f32_32x32x2_f32); no per-launch

@@ -451,6 +451,11 @@ int alink_resize_bilinear(const float* dev_in, float* dev_out, int n, int H, int
  * bottom halves as two contiguous batches (noise.PredictionWrappedModel.predict, code/noise.py:158-168). */
 int alink_perturb_images(const float* dev_img, const double* dev_xs, int n, int k, int Hc, int W,
                          int split, float* dev_out, void* stream);
+/* The same for the candidates of SEVERAL searches in one launch (PixelAttacker.attack_all, code/attack.py:91-103, advances
+ * K pairs' differential-evolution searches in lock-step): dev_imgs is a table [n_img][Hc][W][3] of stacked pair images,
+ * candidates [g * group, (g + 1) * group) perturb image dev_img_of[g] (int32, device; NULL: image 0 for all). */
+int alink_perturb_images_multi(const float* dev_imgs, const int* dev_img_of, int group, const double* dev_xs, int n,
+                               int k, int Hc, int W, int split, float* dev_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * EXTENSIONS — named by BASELINE.json's north_star, ABSENT from the reference: the reference

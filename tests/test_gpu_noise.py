@@ -417,3 +417,68 @@ def test_pool_scale_batches_take_several_launches(gpu):
     b = N.Poisson(seed=4).addNoise(x[40000:], None, first_row=40000)
     assert torch.equal(whole, torch.cat([a, b])) and torch.isfinite(whole).all()
     assert float((whole - x).abs().max()) > 0
+
+
+@pytest.mark.parametrize("search", ["exact", "screen", "screen_f16x2"])
+def test_lockstep_attack_equals_the_sequential_attack(gpu, search):
+    """PixelAttacker.attack_all (code/attack.py:91-103) advances K pairs' differential-evolution searches together — one
+    perturb + one backbone launch chain + one scoring launch for the candidates of all of them, the success test
+    (code/attack.py:47-63) read off the generation's own scores instead of a batch-1 forward.  Attacked images, best
+    parameters, energies and generation counts must equal, bit for bit, what the one-pair-after-another form (lockstep=0:
+    solve() with a real callback forward per generation) finds, for K in {1, 4, 16}, with searches that stop after the first
+    generation, in the middle and at maxiter."""
+    from a_link_amd import attack as A, noise as N, siamese
+    size = (32, 32)
+    if search == "exact":
+        conv = siamese.ArcFace(size, "synthetic:r18:3", dtype="bf16", screen_dtype=None)
+    elif search == "screen":
+        conv = siamese.ArcFace(size, "synthetic:r18:3", screen_dtype="f16")
+    else:                                               # the one-product form of the split-precision handle itself
+        conv = siamese.ArcFace(size, "synthetic:r18:3", screen_dtype="f16x2/1")
+    student = siamese.SiameseNetwork((512,), "s", 0.1, seed=3)
+    ws = student.siamese_net.get_weights()
+    ws[4] = ws[4] * np.float32(6.0)                     # spread the scores: some pairs flip within a few generations
+    student.siamese_net.set_weights(ws)
+    wrapped = N.PredictionWrappedModel(student, conv)
+    n = 7
+    rng = np.random.RandomState(5)
+    imgs = [rng.randint(0, 256, (64, 32, 3)).astype(np.float32) for _ in range(n)]
+    clean = wrapped.predict(np.stack(imgs))
+    # targets: pairs 0, 1 ask for the class the clean pair already has (success after generation 1), the rest for the other one
+    tcs = [int(np.argmax(clean[i])) if i < 2 else 1 - int(np.argmax(clean[i])) for i in range(n)]
+    targets = [[1 - t, t] for t in tcs]
+    seeds = [100 + 7 * i for i in range(n)]
+    kw = dict(dimensions=(64, 32), pixel_count=3, maxiter=6, popsize=30, seeds=seeds)
+    mode = "screen" if search != "exact" else "exact"
+    seq = A.PixelAttacker(wrapped, search=mode)
+    want, want_res = [], []
+    for i in range(n):
+        want.append(seq.attack(imgs[i], 1 - tcs[i], tcs[i], 3, (64, 32), maxiter=6, popsize=30, seed=seeds[i]))
+        want_res.append(seq.last_result)
+    nits = [int(r.nit) for r in want_res]
+    assert min(nits) == 1 and max(nits) == 6, nits                          # an early stop and a search that runs out
+    assert np.array_equal(np.stack(seq.attack_all(imgs, targets, lockstep=0, **kw)), np.stack(want))
+    for K in (1, 4, 16):
+        att = A.PixelAttacker(wrapped, search=mode, lockstep=K)
+        got = att.attack_all(imgs, targets, **kw)
+        assert np.array_equal(np.stack(got), np.stack(want)), (search, K)
+        for r, w in zip(att.last_results, want_res):
+            assert np.array_equal(r.x, w.x) and r.fun == w.fun and r.nit == w.nit and r.nfev == w.nfev and r.message == w.message, (search, K)
+    # early_stop=False (a timing aid): every search runs to maxiter
+    att = A.PixelAttacker(wrapped, search=mode, lockstep=4)
+    att.attack_all(imgs, targets, early_stop=False, **kw)
+    assert [int(r.nit) for r in att.last_results] == [6] * n
+    # through the noise class, with its per-row seeds: rows of a shard equal rows of the whole, whatever the lock-step width
+    L = np.stack([im[:32] for im in imgs])
+    R = np.stack([im[32:] for im in imgs])
+    labels = np.array(tcs)
+    nk = dict(pixel_count=3, maxiter=3, popsize=30, search=mode)
+    whole = N.AdversarialNoise(student, None, conv, seed=9, lockstep=0, **nk).addPairNoise([L, R], labels)
+    for K, cuts in ((32, (0, 7)), (3, (0, 2, 7))):
+        parts = [[], []]
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            got = N.AdversarialNoise(student, None, conv, seed=9, lockstep=K, **nk).addPairNoise([L[lo:hi], R[lo:hi]], labels[lo:hi], rows=(lo, n))
+            for s_ in (0, 1):
+                parts[s_] += list(got[s_])
+        for s_ in (0, 1):
+            assert np.array_equal(np.stack(parts[s_]), np.stack(whole[s_])), (search, K)
