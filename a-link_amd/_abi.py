@@ -103,6 +103,7 @@ PROTOTYPES = {
     "alink_head_apply_update": (_i, [_vp, _vp]),
     "alink_head_set_graph": (_i, [_vp, _i]),
     "alink_head_eval": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "alink_head_custom_train_steps": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "alink_head_input_grads": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "alink_smallres_create": (_vp, [_i, _i, _i, _f, _f, _f]),
     "alink_smallres_destroy": (None, [_vp]),

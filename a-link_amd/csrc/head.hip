@@ -56,6 +56,7 @@ struct alink_head {
     float *d_dm = nullptr, *d_z1 = nullptr, *d_z2 = nullptr, *d_dz1 = nullptr, *d_dz2 = nullptr,
           *d_dz3 = nullptr, *d_p = nullptr;
     float* d_tiny = nullptr;     // per-row-group partials of the tiny-batch train step
+    unsigned* d_counter = nullptr;   // row groups finished (tiny_eval), 0 between launches
     std::vector<void*> allocs;
     // hipGraph cache of the fine-tune step (a launch-bound chain of 8-9 small kernels): one executable
     // graph per distinct (operand pointers, n, grad_scale, apply); replayed while the caller keeps
@@ -490,16 +491,18 @@ __global__ __launch_bounds__(512) void dense_fwd_tiled_kernel(const float* __res
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ b, float* __restrict__ z,
                                                              int n, int K, int C, int relu_in,
-                                                             const float* __restrict__ Rm, float* __restrict__ dm_out, int q) {
+                                                             const float* __restrict__ Rm, float* __restrict__ dm_out, int q,
+                                                             const int* __restrict__ li = nullptr, const int* __restrict__ ri = nullptr) {
+    // li / ri (first layer only): row r of the batch is row li[r] of `a` against row ri[r] of `Rm` (a table of features)
     __shared__ float part[8][64];
     const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane, r = blockIdx.y;
     const int kper = K >> 3;
-    const float* ar = a + (size_t)r * K + ks * kper;
+    const float* ar = a + (size_t)(li ? li[r] : r) * K + ks * kper;
     const float* wp = w + (size_t)(ks * kper) * C + c;
     float s = 0.f;
     if (Rm) {
-        const float* rr = Rm + (size_t)r * K + ks * kper;
+        const float* rr = Rm + (size_t)(ri ? ri[r] : r) * K + ks * kper;
         if (blockIdx.x == 0)
             for (int k = lane; k < kper; k += 64) dm_out[(size_t)r * K + ks * kper + k] = qa(fabsf(ar[k] - rr[k]), q);
         if (c < C) {
@@ -868,7 +871,7 @@ bool g_use_tiny = true;
 //                                                                                   (h1/64 x D/32 blocks)
 // No parameter is read in C except by the thread that updates it (W1 is last read in A, W2 / W3 / b* in
 // B), so the in-place update races with nothing.
-constexpr int TINY_N = 32;      // rows the tiny path takes
+constexpr int TINY_N = 64;      // rows the tiny path takes (32 until round 6: customTrainModel's balanced batches are 16..48 rows)
 constexpr int TINY_RG = 4;      // rows per workgroup in A and B
 constexpr int TINY_KB = 32;     // W1 rows (k) per workgroup in C
 constexpr int TINY_PART = 2 + 64 * 2 + 2 + 4;   // floats one row group leaves: loss, acc, dW3, db3, [132] = rows that count
@@ -954,7 +957,8 @@ template <bool Q>
 __global__ __launch_bounds__(512) void tiny_dense1_kernel(const float* __restrict__ L, const float* __restrict__ R,
                                                          const void* __restrict__ w1, const float* __restrict__ b1,
                                                          float* __restrict__ z1, float* __restrict__ dm, int n, int D,
-                                                         int h1) {
+                                                         int h1, const int* __restrict__ li = nullptr,
+                                                         const int* __restrict__ ri = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float tiny_lds[];
     float* a_s = tiny_lds;                        // [TINY_RG][D]
     float* red = a_s + TINY_RG * D;               // [8][TINY_RG][64]
@@ -968,7 +972,8 @@ __global__ __launch_bounds__(512) void tiny_dense1_kernel(const float* __restric
         const int r = (i * 4) / D, k = (i * 4) - r * D, row = r0 + r;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row < n) {
-            const f32x4 l = *(const f32x4*)(L + (size_t)row * D + k), q = *(const f32x4*)(R + (size_t)row * D + k);
+            const f32x4 l = *(const f32x4*)(L + (size_t)(li ? li[row] : row) * D + k),
+                        q = *(const f32x4*)(R + (size_t)(ri ? ri[row] : row) * D + k);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = qa<Q>(fabsf(l[j] - q[j]));
             if (blockIdx.x == 0) *(f32x4*)(dm + (size_t)row * D + k) = v;
@@ -990,6 +995,8 @@ struct TinyLoss {
     float *z2, *probs, *dz2, *dz3, *dz1, *part;
     int n, h1, od, want_grads;
     float grad_scale;
+    float* eval_metrics;      // want_grads == 0: {loss, accuracy} written by the LAST row group to finish (fixed summation order)
+    unsigned* counter;        // ... which is found by this counter (left at 0 again)
 };
 
 // h2 == 64.  One workgroup per TINY_RG rows.
@@ -1134,7 +1141,27 @@ __global__ __launch_bounds__(512) void tiny_dense2_loss_kernel(const TinyLoss p)
         part[1] = as;
         part[132] = cnts[0];
     }
-    if (!p.want_grads) return;
+    if (!p.want_grads) {
+        // test_on_batch: no third launch — the row group that finishes last adds the groups' partials in group order
+        if (p.eval_metrics) {
+            __shared__ int last;
+            if (tid == 0) {
+                __threadfence();
+                last = atomicAdd(p.counter, 1u) == gridDim.x - 1 ? 1 : 0;
+            }
+            __syncthreads();
+            if (last && tid == 0) {
+                __threadfence();
+                const volatile float* pv = p.part;
+                float ls = 0.f, as = 0.f;
+                for (unsigned g = 0; g < gridDim.x; ++g) { ls += pv[(size_t)g * TINY_PART]; as += pv[(size_t)g * TINY_PART + 1]; }
+                p.eval_metrics[0] = ls * (p.grad_scale > 0.f ? p.grad_scale : 1.f / cnts[0]);
+                p.eval_metrics[1] = as / (float)n;
+                *p.counter = 0u;
+            }
+        }
+        return;
+    }
     float* dz2s = red;                             // [TINY_RG][64], the reduction scratch is free again
     if (tid < TINY_RG * 64) {
         // dZ2[row][c] = (z2 > 0) * sum_j dz3[row][j] * w3[c][j]
@@ -1412,7 +1439,7 @@ bool tiny_ok(const alink_head* h, int n) {
 
 // the three launches; gradients are always left in d_grads, parameters updated when `apply`
 int tiny_train(alink_head* h, const float* L, const float* R, const float* y, const float* sw, int n,
-               float grad_scale, bool apply, float* metrics, hipStream_t st) {
+               float grad_scale, bool apply, float* metrics, hipStream_t st, const int* li = nullptr, const int* ri = nullptr) {
     const int D = h->D, h1 = h->h1;
     float* P = h->d_params;
     const bool Q = h->qmode != 0;
@@ -1420,9 +1447,9 @@ int tiny_train(alink_head* h, const float* L, const float* R, const float* y, co
     const void* WB = Q ? (const void*)h->d_pq : (const void*)P;      // where the WEIGHTS are read from (oW1 == 0)
     const int ngroups = (n + TINY_RG - 1) / TINY_RG;
     if (Q) hipLaunchKernelGGL(tiny_dense1_kernel<true>, dim3(h1 / 64, ngroups), dim3(512), tiny_lds_bytes(D), st, L, R, WB,
-                              P + h->ob1, h->d_z1, h->d_dm, n, D, h1);
+                              P + h->ob1, h->d_z1, h->d_dm, n, D, h1, li, ri);
     else   hipLaunchKernelGGL(tiny_dense1_kernel<false>, dim3(h1 / 64, ngroups), dim3(512), tiny_lds_bytes(D), st, L, R, WB,
-                              P + h->ob1, h->d_z1, h->d_dm, n, D, h1);
+                              P + h->ob1, h->d_z1, h->d_dm, n, D, h1, li, ri);
     TinyLoss lp{};
     lp.wbase = WB; lp.oW2 = h->oW2; lp.oW3 = h->oW3;
     lp.z1 = h->d_z1; lp.b2 = P + h->ob2; lp.b3 = P + h->ob3; lp.y = y;
@@ -1442,12 +1469,38 @@ int tiny_train(alink_head* h, const float* L, const float* R, const float* y, co
     return ALINK_OK;
 }
 
+// test_on_batch on n <= TINY_N rows: launches A and B of the step above (no gradients), metrics from B's last row group
+int tiny_eval(alink_head* h, const float* L, const float* R, const float* y, int n, float* metrics, hipStream_t st,
+              const int* li = nullptr, const int* ri = nullptr) {
+    const int D = h->D, h1 = h->h1;
+    float* P = h->d_params;
+    const bool Q = h->qmode != 0;
+    if (Q) { const int rc = ensure_q(h, st, false); if (rc) return rc; }
+    const void* WB = Q ? (const void*)h->d_pq : (const void*)P;
+    const int ngroups = (n + TINY_RG - 1) / TINY_RG;
+    if (Q) hipLaunchKernelGGL(tiny_dense1_kernel<true>, dim3(h1 / 64, ngroups), dim3(512), tiny_lds_bytes(D), st, L, R, WB,
+                              P + h->ob1, h->d_z1, h->d_dm, n, D, h1, li, ri);
+    else   hipLaunchKernelGGL(tiny_dense1_kernel<false>, dim3(h1 / 64, ngroups), dim3(512), tiny_lds_bytes(D), st, L, R, WB,
+                              P + h->ob1, h->d_z1, h->d_dm, n, D, h1, li, ri);
+    TinyLoss lp{};
+    lp.wbase = WB; lp.oW2 = h->oW2; lp.oW3 = h->oW3;
+    lp.z1 = h->d_z1; lp.b2 = P + h->ob2; lp.b3 = P + h->ob3; lp.y = y;
+    lp.sw = nullptr; lp.z2 = h->d_z2; lp.probs = h->d_p; lp.dz2 = h->d_dz2; lp.dz3 = h->d_dz3; lp.dz1 = h->d_dz1;
+    lp.part = h->d_tiny; lp.n = n; lp.h1 = h1; lp.od = h->od; lp.want_grads = 0; lp.grad_scale = 0.f;
+    lp.eval_metrics = metrics; lp.counter = h->d_counter;
+    if (Q) hipLaunchKernelGGL(tiny_dense2_loss_kernel<true>, dim3(ngroups), dim3(512), tiny_lds_bytes(h1, true), st, lp);
+    else   hipLaunchKernelGGL(tiny_dense2_loss_kernel<false>, dim3(ngroups), dim3(512), tiny_lds_bytes(h1, true), st, lp);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
 // forward (+ optional backward) on a small batch with the VALU kernels
 // The step is a chain of dependent small kernels (each ~7 us of pure latency at batch 16), so the chain
 // is kept short: |l - r| inside the first Dense, the two independent middle gradients in one launch,
 // and (fused_update) the first-layer weight gradient together with the whole Adadelta update: 5 launches.
 int small_pass(alink_head* h, const float* L, const float* R, const float* y, const float* sw, int n,
-               float grad_scale, bool want_grads, float* metrics, hipStream_t st, bool fused_update = false) {
+               float grad_scale, bool want_grads, float* metrics, hipStream_t st, bool fused_update = false,
+               const int* li = nullptr, const int* ri = nullptr) {
     ALINK_REQUIRE(n > 0 && n <= h->cap, ALINK_EINVAL, "batch of %d rows outside 1..%d", n, h->cap);
     const int D = h->D, h1 = h->h1, h2 = h->h2;
     float* P = h->d_params;
@@ -1456,9 +1509,10 @@ int small_pass(alink_head* h, const float* L, const float* R, const float* y, co
     if (q) { const int rc = ensure_q(h, st, true); if (rc) return rc; }
     const float* WF = q ? h->d_pqf : P;            // weights: the bf16 values widened to f32 in bf16 mode; biases: master
     hipLaunchKernelGGL(dense_fwd_tiled_kernel, dim3((h1 + 63) / 64, n), dim3(512), 0, st, L, WF + h->oW1,
-                       P + h->ob1, h->d_z1, n, D, h1, 0, R, h->d_dm, q);
+                       P + h->ob1, h->d_z1, n, D, h1, 0, R, h->d_dm, q, li, ri);
     hipLaunchKernelGGL(dense_fwd_tiled_kernel, dim3((h2 + 63) / 64, n), dim3(512), 0, st, h->d_z1, WF + h->oW2,
-                       P + h->ob2, h->d_z2, n, h1, h2, 1, (const float*)nullptr, (float*)nullptr, q);
+                       P + h->ob2, h->d_z2, n, h1, h2, 1, (const float*)nullptr, (float*)nullptr, q, (const int*)nullptr,
+                       (const int*)nullptr);
     HeadLoss lp{};
     lp.q = q;
     lp.z2 = h->d_z2; lp.w3 = WF + h->oW3; lp.b3 = P + h->ob3; lp.y = y; lp.sw = sw; lp.probs = h->d_p;
@@ -1531,6 +1585,7 @@ alink_head_t* alink_head_create_ex(int d_in, int h1, int h2, int out_dim, float 
     rc |= head_alloc(h, &h->d_dz3, (size_t)h->cap * 2);
     rc |= head_alloc(h, &h->d_p, (size_t)h->cap * 2);
     rc |= head_alloc(h, &h->d_tiny, (size_t)(TINY_N / TINY_RG) * TINY_PART);
+    rc |= head_alloc(h, (float**)&h->d_counter, 4);
     if (rc) { delete h; return nullptr; }
     return h;
 }
@@ -1764,7 +1819,38 @@ int alink_head_eval(alink_head_t* h, const float* dev_L, const float* dev_R, con
                     float* dev_metrics, void* stream) {
     ALINK_REQUIRE(h && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
     DeviceGuard dg(h->device);
+    if (tiny_ok(h, n)) return tiny_eval(h, dev_L, dev_R, dev_y, n, dev_metrics, (hipStream_t)stream);
     return small_pass(h, dev_L, dev_R, dev_y, nullptr, n, 0.f, false, dev_metrics, (hipStream_t)stream);
+}
+
+int alink_head_custom_train_steps(alink_head_t* h, const float* dev_table, const int32_t* dev_idx, const float* dev_vals,
+                                  const int64_t* host_desc, int steps, int with_weights, float* dev_metrics, void* stream) {
+    ALINK_REQUIRE(h && dev_table && dev_idx && dev_vals && host_desc && dev_metrics && steps >= 0, ALINK_EINVAL, "NULL argument");
+    DeviceGuard dg(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    for (int s = 0; s < steps; ++s) {
+        const int64_t io = host_desc[4 * s], fo = host_desc[4 * s + 1], n = host_desc[4 * s + 2], nh = host_desc[4 * s + 3];
+        ALINK_REQUIRE(io >= 0 && fo >= 0 && nh >= 0 && n > nh && n - nh <= h->cap && nh <= h->cap, ALINK_EINVAL,
+                      "step %d: %lld rows, %lld held out (at most %d each)", s, (long long)n, (long long)nh, h->cap);
+        const int nu = (int)(n - nh);
+        const int32_t *li = dev_idx + io, *ri = li + n;
+        const float* y = dev_vals + fo;
+        const float* sw = with_weights ? y + (size_t)n * h->od : nullptr;
+        float* m = dev_metrics + 4 * (size_t)s;
+        // train_on_batch on the rows that were not held out (the same kernels alink_head_train_step launches for a batch of this size)
+        int rc = tiny_ok(h, nu) ? tiny_train(h, dev_table, dev_table, y + (size_t)nh * h->od, sw, nu, 0.f, true, m, st, li + nh, ri + nh)
+                                : small_pass(h, dev_table, dev_table, y + (size_t)nh * h->od, sw, nu, 0.f, true, m, st, true, li + nh, ri + nh);
+        if (rc) return rc;
+        h->packed_dirty = h->pqf_dirty = true;
+        if (!tiny_ok(h, nu)) h->pq_dirty = true;
+        // test_on_batch on the held-out rows, with the parameters that step left
+        if (nh > 0) {
+            rc = tiny_ok(h, (int)nh) ? tiny_eval(h, dev_table, dev_table, y, (int)nh, m + 2, st, li, ri)
+                                     : small_pass(h, dev_table, dev_table, y, nullptr, (int)nh, 0.f, false, m + 2, st, false, li, ri);
+            if (rc) return rc;
+        }
+    }
+    return ALINK_OK;
 }
 
 }  // extern "C"

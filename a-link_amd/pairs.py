@@ -156,7 +156,9 @@ def balance_rows(y):
     m = min(len(g) for g in groups)
     if m == 0:
         return None
-    return np.concatenate([np.random.choice(g, m, replace=False) for g in groups])
+    # np.random.choice(g, m, replace=False) IS g[np.random.permutation(len(g))[:m]] (numpy/random/mtrand.pyx, the legacy
+    # RandomState.choice without p) minus its argument checks: the same draws (tests/test_pairs_generators.py)
+    return np.concatenate([g[np.random.permutation(len(g))[:m]] for g in groups])
 
 
 class Pending:
@@ -224,40 +226,157 @@ def _rounds_to_skip(sources):
         t += 1                                                # a round of positives only: discarded too
 
 
-def mix_balanced(sources, batch_size, transform=None):
+class BalancedMix(object):
     """`sources`: generators of ([left, right], Y).  Per round: draw one batch from every source (stop
     when one is exhausted), join, balance classes, optionally transform the two sides, accumulate until
     batch_size rows are waiting.  With three sources the joined labels are (Y1, Y2, Y2): the reference
     repeats the second label block for the third source (code/readDFW.py:185) — kept.
     Rounds whose joined labels lack a class are dropped by the reference AFTER drawing and joining them, without touching
     the random stream; with this module's own sources they are passed over by index arithmetic instead (_rounds_to_skip):
-    the same batches, the same np.random.choice calls, ~100x less host time at DFW scale (tools/custom_train_time.py)."""
-    waiting = Pending()
-    while True:
-        k = _rounds_to_skip(sources)
+    the same batches, the same np.random.choice calls, ~100x less host time at DFW scale (tools/custom_train_time.py).
+
+    An iterator like the generator function it replaces (`next(gen)`, `gen.next()`, `for batch in gen`).  When every source
+    is one of this module's own (rows of a table gathered by index) and nothing transforms the sides, the mix is INDEXABLE:
+    `next_indices()` yields the coming batch as (li, ri, y) — rows of `table()`, the sources' tables one after another —
+    without touching a feature; `next()` is then that gather.  SiameseNetwork.customTrainModel keeps the table on the
+    device and ships only the indices (siamese.py)."""
+
+    def __init__(self, sources, batch_size, transform=None):
+        self.sources, self.batch_size, self.transform = list(sources), int(batch_size), transform
+        self.waiting = Pending()
+        own = all(isinstance(g, _Gathering) for g in self.sources)
+        self.indexable = bool(own and transform is None and len(self.sources) > 0 and
+                              len(set((tuple(g.rows.shape[1:]), str(g.rows.dtype), type(g.rows)) for g in self.sources)) == 1)
+        if self.indexable:
+            self._bases = np.concatenate(([0], np.cumsum([len(g.rows) for g in self.sources])))[:-1].astype(np.int64)
+        self._table = None
+        self._sched = None
+
+    def __iter__(self):
+        return self
+
+    def table(self):
+        """every source's rows, one table after another (what next_indices() points into)"""
+        if self._table is None:
+            self._table = _cat([g.rows for g in self.sources])
+        return self._table
+
+    def _skip_ahead(self):
+        k = _rounds_to_skip(self.sources)
         while k:                                               # k is None for foreign generators
-            for g in sources:
+            for g in self.sources:
                 g.index.skip(k)
-            k = _rounds_to_skip(sources)
-        try:
-            drawn = [next(g) for g in sources]
-        except StopIteration:
-            return
-        labels = [d[1] for d in drawn]
-        if len(labels) == 3:
-            labels[2] = labels[1]
-        y = np.concatenate(labels, axis=0)
-        sides = [_cat([d[0][s] for d in drawn]) for s in (0, 1)]
-        keep = balance_rows(y)
-        if keep is None:
-            continue
-        sides = [_take(s, keep) for s in sides]
-        if transform is not None:
-            sides = transform(sides)
-        waiting.add(sides[0], sides[1], y[keep])
-        if waiting.n >= batch_size:
-            left, right, yy = waiting.flush()
-            yield ([left, right], yy)
+            k = _rounds_to_skip(self.sources)
+
+    # -- the index form: the rounds worth drawing are found in bulk, a window of rounds at a time -------------------------------
+    def _useful_rounds(self):
+        """Offsets (in rounds from now) of the coming rounds whose joined labels hold both classes, ascending — what
+        _rounds_to_skip finds one round at a time, for a whole window by array arithmetic (the sources advance in lock-step:
+        round t draws batch (k_i + t) mod nb_i of source i).  Cached until the sources move by other means."""
+        ks = tuple(g.index.k for g in self.sources)
+        c = self._sched
+        if c is not None and c[0] == tuple(k - c[3] for k in ks) and c[3] < c[2]:
+            return c
+        idx = [g.index for g in self.sources]
+        lab = [idx[0], idx[1]] if len(idx) == 3 else list(idx)        # the reference's (Y1, Y2, Y2)
+        if any(ix.nb == 0 for ix in idx):
+            return None
+        limit = None
+        for ix in idx:
+            r = ix.remaining()
+            if r is not None:
+                limit = r if limit is None else min(limit, r)
+        T = 4096
+        while True:
+            span = T if limit is None else min(T, limit)
+            t = np.arange(span, dtype=np.int64)
+            pos = np.zeros(span, bool)
+            neg = np.zeros(span, bool)
+            for ix in lab:
+                b = (ix.k + t) % ix.nb
+                pos |= ix.has_pos[b]
+                neg |= ix.has_neg[b]
+            useful = np.flatnonzero(pos & neg)
+            if len(useful) or (limit is not None and span >= limit):
+                break
+            if not any(len(ix.pos_at) for ix in lab):
+                raise RuntimeError("the balanced generator's sources hold no positive pair: the reference's loop would spin for ever")
+            if T >= (1 << 26):
+                raise RuntimeError("no round of the balanced generator holds both classes in %d rounds" % T)
+            T *= 4
+        # [source positions the offsets count from, useful offsets, rounds scanned, rounds consumed, next entry, end of a finite source]
+        self._sched = [ks, useful, span, 0, 0, limit is not None and span >= limit]
+        return self._sched
+
+    def next_indices(self):
+        """the next batch as (li, ri, y): int64 rows of table(), y of shape (n, 1).  StopIteration when a finite source ends."""
+        if not self.indexable:
+            raise TypeError("this mix is not indexable (a foreign source generator, or a transform of the sides)")
+        w = self.waiting
+        srcs = self.sources
+        while True:
+            c = self._useful_rounds()
+            if c is None:
+                for g in srcs:
+                    next(g.index)                               # a source without a full batch: raises what it raises
+                raise StopIteration
+            ks, useful, span, done, j, ends = c
+            if j >= len(useful):                                # nothing useful left in the window: pass over its rest
+                for g in srcs:
+                    g.index.skip(span - done)
+                c[3] = span
+                if ends:
+                    for g in srcs:
+                        next(g.index)                           # the exhausted source raises StopIteration
+                continue
+            t = int(useful[j])
+            if t > done:
+                for g in srcs:
+                    g.index.skip(t - done)
+            c[3], c[4] = t + 1, j + 1
+            drawn = [next(g.index) for g in srcs]
+            if len(drawn) == 3:
+                y = np.concatenate((drawn[0][2], drawn[1][2], drawn[1][2]), axis=0)
+            else:
+                y = np.concatenate([d[2] for d in drawn], axis=0)
+            keep = balance_rows(y)
+            if keep is None:
+                continue
+            li = np.concatenate([d[0] + b for d, b in zip(drawn, self._bases)])
+            ri = np.concatenate([d[1] + b for d, b in zip(drawn, self._bases)])
+            w.add(li[keep], ri[keep], y[keep])
+            if w.n >= self.batch_size:
+                return w.flush()
+
+    def __next__(self):
+        if self.indexable:
+            li, ri, yy = self.next_indices()
+            t = self.table()
+            return ([_take(t, li), _take(t, ri)], yy)
+        waiting = self.waiting
+        while True:
+            self._skip_ahead()
+            drawn = [next(g) for g in self.sources]
+            labels = [d[1] for d in drawn]
+            if len(labels) == 3:
+                labels[2] = labels[1]
+            y = np.concatenate(labels, axis=0)
+            sides = [_cat([d[0][s] for d in drawn]) for s in (0, 1)]
+            keep = balance_rows(y)
+            if keep is None:
+                continue
+            sides = [_take(s, keep) for s in sides]
+            if self.transform is not None:
+                sides = self.transform(sides)
+            waiting.add(sides[0], sides[1], y[keep])
+            if waiting.n >= self.batch_size:
+                left, right, yy = waiting.flush()
+                return ([left, right], yy)
+
+    next = __next__                                            # the reference calls gen.next() (Python 2)
+
+
+mix_balanced = BalancedMix
 
 
 # ---- the reference's names and signatures ---------------------------------------------------------------

@@ -36,6 +36,7 @@ def _inverse_frequency_weights(y):
 class SiameseNetwork:
     _identity_preprocess = True
     _defer_metrics = True          # customTrainModel(verbose=0): steps enqueued, metrics read back in blocks (A/B switch for the test)
+    _index_steps = True            # ... and, over this package's own generators, batches shipped as row indices (A/B switch)
 
     # what customTrainModel / finetune feed the head: this class one-hot labels with inverse-frequency class
     # weights (code/siamese.py:56,95-103); the baseline scorer of siamese3.py overrides both
@@ -95,6 +96,8 @@ class SiameseNetwork:
         # sums) instead of synchronised one by one — 20,000 steps an epoch at the reference's settings
         deferred = (not verbose) and isinstance(net, DenseHead) and self._defer_metrics
         block = 256
+        if deferred and self._index_steps and self._indexable(dataGen, preprocess):
+            return self._custom_train_indexed(dataGen, epochs, steps_per_epoch, valRatio, block)
         for epoch in range(epochs):
             sums = np.zeros(4)                                   # tr loss, tr acc, vl loss, vl acc
             M, k = (net.torch.zeros((block, 4), dtype=net.torch.float32, device=net.device), 0) if deferred else (None, 0)
@@ -134,6 +137,185 @@ class SiameseNetwork:
             flush()
             if verbose:
                 print("\n")
+            logs.append(tuple(sums / steps_per_epoch))
+        return logs
+
+    # -- customTrainModel over this package's own generators: the feature table stays on the device --------------------
+    def _indexable(self, dataGen, preprocess):
+        from .pairs import BalancedMix
+        net = self.siamese_net
+        if not (isinstance(dataGen, BalancedMix) and dataGen.indexable and net.dp_group is None):
+            return False
+        if preprocess and type(self).preprocess is not SiameseNetwork.preprocess:
+            return False
+        if type(net).train_on_batch is not DenseHead.train_on_batch or type(net).test_on_batch is not DenseHead.test_on_batch:
+            return False                                       # an instrumented / overridden step must see every call
+        t = dataGen.table()
+        return t.ndim == 2 and t.shape[1] == net.d_in and len(t) < 2 ** 31
+
+    def _custom_train_indexed(self, dataGen, epochs, steps_per_epoch, valRatio, block):
+        """The loop of customTrainModel (code/siamese.py:91-110) with every feature resident on the device: the generator's
+        table goes up once, a step is planned on the host as INDEX arithmetic only (the generator's balanced batch as rows of
+        the table, np.random.permutation, the hold-out split, the inverse-frequency class weights — the same calls on the
+        same random stream as the step-by-step form), `block` steps travel as one int32 + one float32 buffer and are
+        enqueued by ONE call (alink_head_custom_train_steps); the metrics of a block are read back while the next one runs.
+        Same kernels on the same rows in the same order: logs and weights equal the step-by-step form's bit for bit
+        (tests/test_gpu_head.py)."""
+        import ctypes as C
+        from . import _abi
+        net = self.siamese_net
+        torch = net.torch
+        tab = dataGen.table()
+        cached = getattr(dataGen, "_device_table", None)
+        if cached is None or cached[0] != net.device:
+            td = tab.to(net.device, torch.float32).contiguous() if hasattr(tab, "detach") else \
+                torch.from_numpy(np.ascontiguousarray(tab, dtype=np.float32)).to(net.device)
+            cached = dataGen._device_table = (net.device, td)
+        td = cached[1]
+        od = net.out_dim
+        base_targets = type(self)._targets is SiameseNetwork._targets
+        base_weights = type(self)._step_class_weight is SiameseNetwork._step_class_weight
+        cap_i, cap_f = block * 2 * 256, block * (od + 1) * 256
+        sets = []
+        for _ in range(2):
+            sets.append({"i_host": torch.empty(cap_i, dtype=torch.int32).pin_memory(), "f_host": torch.empty(cap_f, dtype=torch.float32).pin_memory(),
+                         "i_dev": torch.empty(cap_i, dtype=torch.int32, device=net.device), "f_dev": torch.empty(cap_f, dtype=torch.float32, device=net.device),
+                         "M": torch.zeros((block, 4), dtype=torch.float32, device=net.device), "steps": 0, "up": torch.cuda.Event()})
+        for st in sets:
+            st["i_np"], st["f_np"] = st["i_host"].numpy(), st["f_host"].numpy()
+        stream = torch.cuda.current_stream(net._tdev)
+        logs = []
+
+        # The launches of a block (5 per step) cost the host about as much as planning the block does: they run on a worker
+        # thread (ctypes drops the GIL for the call) while this thread plans the next block.  One worker, jobs in order: the
+        # stream sees the blocks in step order; a set's metrics are read only after its job has been handed over.
+        import queue
+        import threading
+        jobs = queue.Queue()
+        failure = []
+
+        def launcher():
+            while True:
+                job = jobs.get()
+                if job is None:
+                    return
+                st, d, k, weights = job
+                try:
+                    _abi.check(net.lib.alink_head_custom_train_steps(net.h, td.data_ptr(), st["i_dev"].data_ptr(), st["f_dev"].data_ptr(),
+                                                                     d.ctypes.data_as(C.c_void_p), k, 1 if weights else 0,
+                                                                     st["M"].data_ptr(), stream.cuda_stream), "alink_head_custom_train_steps")
+                except Exception as e:                           # surfaces in the main thread at the next collect()
+                    failure.append(e)
+                finally:
+                    st["launched"].set()
+        worker = threading.Thread(target=launcher, daemon=True)
+        worker.start()
+        for st in sets:
+            st["launched"] = threading.Event()
+            st["launched"].set()
+
+        def collect(st, sums):
+            st["launched"].wait()
+            if failure:
+                raise failure[0]
+            if st["steps"]:
+                for row in st["M"][:st["steps"]].cpu().numpy().astype(np.float64):
+                    sums[:2] += row[:2]
+                    sums[2:] += row[2:]
+                st["steps"] = 0
+
+        def run(st, desc, k, io, fo, weights):
+            """enqueue the k steps planned into set `st`"""
+            if not k:
+                return
+            st["i_dev"][:io].copy_(st["i_host"][:io], non_blocking=True)
+            st["f_dev"][:fo].copy_(st["f_host"][:fo], non_blocking=True)
+            st["up"].record(stream)
+            st["M"].zero_()
+            st["launched"].clear()
+            jobs.put((st, np.ascontiguousarray(desc[:k], dtype=np.int64), k, weights))
+            st["steps"] = k
+
+        try:
+            return self._indexed_epochs(dataGen, epochs, steps_per_epoch, valRatio, block, sets, collect, run, od, cap_i, cap_f,
+                                        base_targets, base_weights)
+        finally:
+            jobs.put(None)
+            worker.join()
+            for st in sets:
+                st["launched"].wait()
+
+    def _indexed_epochs(self, dataGen, epochs, steps_per_epoch, valRatio, block, sets, collect, run, od, cap_i, cap_f,
+                        base_targets, base_weights):
+        logs = []
+        turn = 0
+        for epoch in range(epochs):
+            sums = np.zeros(4)
+            done = 0
+            while done < steps_per_epoch:
+                st = sets[turn % 2]
+                turn += 1
+                collect(st, sums)                               # the block this set carried two turns ago (in step order)
+                st["up"].synchronize()                          # its upload has left the pinned buffers
+                nb = min(block, steps_per_epoch - done)
+                inp, fnp = st["i_np"], st["f_np"]
+                desc = np.empty((nb, 4), np.int64)
+                io = fo = k = 0
+                weights = None
+                ended = None
+                while k < nb:
+                    try:
+                        li, ri, y = dataGen.next_indices()
+                    except StopIteration as e:                  # a finite source ended: the steps drawn so far still run
+                        ended = e
+                        break
+                    n = len(y)
+                    order = np.random.permutation(n)
+                    n_held = int(n * valRatio)
+                    yo = y[order]
+                    flat = yo[n_held:, 0]
+                    if base_weights:
+                        c1 = int(np.count_nonzero(flat == 1))
+                        c0 = int(np.count_nonzero(flat == 0))
+                        if c0 and c1:
+                            p0, p1 = (n - n_held) // c0, (n - n_held) // c1
+                            tot = float(p0 + p1)
+                            sw = np.where(flat == 1, p1 / tot, p0 / tot).astype(np.float32)
+                        else:                                   # an absent class: the reference's inf / nan weights, the slow way
+                            sw = DenseHead._sample_weights(self._targets(yo[n_held:]), self._step_class_weight(yo[n_held:]), None)
+                    else:
+                        sw = DenseHead._sample_weights(self._targets(yo[n_held:]), self._step_class_weight(yo[n_held:]), None)
+                    if weights is None:
+                        weights = sw is not None
+                    elif weights != (sw is not None):
+                        raise ValueError("class weights for some steps of a block and not for others")
+                    need_f = n * od + (n - n_held if weights else 0)
+                    if io + 2 * n > cap_i or fo + need_f > cap_f or n - n_held > 4096 or n_held > 4096:
+                        raise ValueError("a generator batch of %d rows is too large for the indexed customTrainModel "
+                                         "(set _index_steps = False)" % n)
+                    inp[io:io + n] = li[order]
+                    inp[io + n:io + 2 * n] = ri[order]
+                    if base_targets:                            # to_categorical(y, 2): [1 - y, y]
+                        t2 = fnp[fo:fo + 2 * n].reshape(n, 2)
+                        t2[:, 1] = yo[:, 0]
+                        t2[:, 0] = 1 - yo[:, 0]
+                    else:
+                        fnp[fo:fo + n * od] = np.asarray(self._targets(yo), dtype=np.float32).reshape(-1)
+                    if weights:
+                        fnp[fo + n * od:fo + need_f] = sw
+                    desc[k] = (io, fo, n, n_held)
+                    io += 2 * n
+                    fo += need_f
+                    k += 1
+                run(st, desc, k, io, fo, bool(weights))
+                done += k
+                if ended is not None:
+                    for s_ in sets:
+                        collect(s_, sums)
+                    raise ended
+            # end of the epoch: both sets in step order (the older one first)
+            collect(sets[turn % 2], sums)
+            collect(sets[(turn + 1) % 2], sums)
             logs.append(tuple(sums / steps_per_epoch))
         return logs
 

@@ -329,6 +329,17 @@ int alink_head_input_grads(alink_head_t* h, const float* dev_L, const float* dev
 /* Keras test_on_batch: {loss, binary_accuracy} without touching parameters. */
 int alink_head_eval(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
                     int n, float* dev_metrics, void* stream);
+/* The inner loop of SiameseNetwork.customTrainModel (code/siamese.py:91-110) for `steps` consecutive steps, enqueued by ONE
+ * call: per step train_on_batch on the rows that were not held out, then test_on_batch on the held-out ones — the batches
+ * given as ROW INDICES into a device-resident feature table (dev_table, rows of d_in floats: left row li[r] against right row
+ * ri[r]), so that no feature crosses the host boundary during an epoch (the reference stacks 2 x n x d_in floats per step).
+ * host_desc: 4 int64 per step {offset into dev_idx, offset into dev_vals, n, n_held}; at dev_idx + offset: li[n] then ri[n]
+ * (int32), the n_held held-out rows FIRST; at dev_vals + offset: y[n][out_dim] in the same row order, then (with_weights)
+ * sample_weight[n - n_held] of the trained rows.  dev_metrics: 4 floats per step {train loss, train accuracy, held-out loss,
+ * held-out accuracy}; the last two untouched when n_held = 0.  The same kernels, on the same rows in the same order, as
+ * alink_head_train_step + alink_head_eval called once per step on gathered rows (bit-identical parameters and metrics). */
+int alink_head_custom_train_steps(alink_head_t* h, const float* dev_table, const int32_t* dev_idx, const float* dev_vals,
+                                  const int64_t* host_desc, int steps, int with_weights, float* dev_metrics, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SmallRes: the end-to-end-trained low-resolution siamese CNN (code/siamese.py:134-184):

@@ -332,3 +332,49 @@ def test_custom_train_model_with_deferred_metrics_equals_the_step_by_step_form(g
         assert out[0][0] == out[1][0], (val_ratio, out[0][0], out[1][0])
         for a, b in zip(out[0][1], out[1][1]):
             assert np.array_equal(a, b)
+
+
+def test_custom_train_model_over_index_batches_equals_the_step_by_step_form(gpu):
+    """customTrainModel over this package's own balanced generator (pairs.getGenerator, code/readDFW.py:180-209) keeps the
+    generator's feature table on the device and ships a step as row indices, `block` steps per call
+    (alink_head_custom_train_steps); `_index_steps = False` gathers the rows on the host and uploads them step by step, and
+    `_defer_metrics = False` also synchronises every step (the reference's shape, code/siamese.py:91-110).  The same batches,
+    the same random stream, the same kernels: logs and weights equal bit for bit — across block boundaries (600 steps, blocks of
+    256), batches above and below the 32-row limit of the three-launch step, with and without held-out rows, for the two-column
+    scorer with class weights and the baseline scripts' one-column scorer without (code/siamese3.py:64-86); and a finite
+    generator that ends mid-epoch raises StopIteration after the same steps."""
+    from a_link_amd import pairs, siamese, siamese3
+    rng = np.random.RandomState(0)
+    feats = [rng.randn(rng.randint(2, 6), 512).astype(np.float32) for _ in range(40)]
+
+    def make(infinite=True, bs=16):
+        return pairs.getGenerator(pairs.getNormalGenerator(feats, bs, infinite=infinite), pairs.getNormalGenerator(feats, bs, infinite=infinite),
+                                  pairs.getImposterGenerator(feats, feats, bs, infinite=infinite), 16)
+
+    for cls, val_ratio, bs in ((siamese.SiameseNetwork, 0.2, 16), (siamese.SiameseNetwork, 0.0, 16), (siamese3.SiameseNetwork, 0.2, 16),
+                               (siamese.SiameseNetwork, 0.2, 64)):
+        out = []
+        for indexed, deferred in ((True, True), (False, True), (False, False)):
+            net = cls((512,), "ctm", 0.1, seed=31)
+            net._index_steps, net._defer_metrics = indexed, deferred
+            gen = make(bs=bs)
+            assert gen.indexable
+            np.random.seed(5)
+            logs = net.customTrainModel(gen, 2, 16, val_ratio, n_steps=16 * 300, verbose=0)
+            out.append((logs, net.siamese_net.get_weights(), np.random.get_state()[1][:8].tolist()))
+        for other in out[1:]:
+            assert out[0][0] == other[0], (cls, val_ratio, out[0][0], other[0])
+            assert out[0][2] == other[2]                              # the random stream was consumed identically
+            for a, b in zip(out[0][1], other[1]):
+                assert np.array_equal(a, b)
+    # a finite generator: StopIteration after the steps it had batches for
+    ends = []
+    for indexed in (True, False):
+        net = siamese.SiameseNetwork((512,), "ctm", 0.1, seed=31)
+        net._index_steps = indexed
+        np.random.seed(6)
+        with pytest.raises(StopIteration):
+            net.customTrainModel(make(infinite=False), 1, 16, 0.2, n_steps=16 * 100000, verbose=0)
+        ends.append(net.siamese_net.get_weights())
+    for a, b in zip(*ends):
+        assert np.array_equal(a, b)
