@@ -12,6 +12,8 @@ struct GemmP {
     const float* A;
     const float* B;
     float* C;
+    const float* A2;          // A_CONV / A_CONVT: images a_split, a_split + 1, ... of the gathered tensor live in this second buffer
+    int a_split;              //   (the two sides of a siamese batch, handed over as two arrays); nullptr: one buffer
     int M, N, K;              // C[M][N] = A[M][K] . B[K][N]
     int lda, ldb, ldc;        // leading dimensions of the plain layouts
     int amode, bmode;
@@ -28,6 +30,7 @@ struct GemmP {
     int relu;
     int accumulate;           // C += result (after the epilogue terms) instead of C = result
     int splitk, kper;         // grid.z slabs of kper (multiple of 16) reduction steps
+    unsigned ci_magic;        // set by launch_gemm32: ceil(2^32 / Ci) (0 for Ci = 1): k / Ci as one multiply-high in the loaders
 };
 
 void       gemm32_plan_split(GemmP& p, int max_split);

@@ -113,14 +113,23 @@ struct alink_smallres {
     float *d_p = nullptr, *d_g = nullptr, *d_a = nullptr, *d_d = nullptr;   // tower params / grads / Adadelta
     // activations for up to 2*MAXN tower passes
     float *a1 = nullptr, *a2 = nullptr, *p1 = nullptr, *a3 = nullptr, *a4 = nullptr, *p2 = nullptr, *f = nullptr;
-    float *da = nullptr, *db = nullptr;                                       // backward ping-pong
     float *dfeat = nullptr;
+    // activation gradients, one buffer per tensor (round 6: a ping-pong pair until then — the weight gradients now run on
+    // a side stream beside the input-gradient chain, so a dz must stay put until its weight gradient has read it)
+    float *gf = nullptr, *gp2 = nullptr, *ga4 = nullptr, *ga3 = nullptr, *gp1 = nullptr, *ga2 = nullptr, *ga1 = nullptr;
+    hipStream_t side = nullptr;        // weight gradients (independent of the dz chain once their dz exists)
+    hipEvent_t ev_dz[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, ev_side = nullptr, ev_prev = nullptr;   // ev_prev: the dense layer's input gradient has read W
+    float* ws2 = nullptr;              // split-K slabs of the side stream's GEMMs
     uint8_t *arg1 = nullptr, *arg2 = nullptr;
     float* d_all_grads = nullptr;      // [tower grads | head grads] contiguous copy for all-reduce
     float* ws = nullptr;               // split-K slabs of sgemm
     size_t ws_floats = 0;
     std::vector<void*> allocs;
     ~alink_smallres() {
+        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        for (hipEvent_t e : ev_dz) if (e) (void)hipEventDestroy(e);
+        if (ev_side) (void)hipEventDestroy(ev_side);
+        if (ev_prev) (void)hipEventDestroy(ev_prev);
         for (void* p : allocs) (void)hipFree(p);
         if (head) alink_head_destroy(head);
     }
@@ -138,20 +147,20 @@ int sr_alloc(alink_smallres* m, V** p, size_t count) {
 
 const int CI[4] = {3, 32, 32, 64}, CO[4] = {32, 32, 64, 64}, PAD[4] = {1, 0, 1, 0};
 
-int run_gemm(alink_smallres* m, GemmP& g, int max_split, hipStream_t st) {
+int run_gemm(alink_smallres* m, GemmP& g, int max_split, hipStream_t st, float* ws = nullptr) {
     gemm32_plan_split(g, max_split);
     ALINK_REQUIRE(gemm32_workspace_floats(g) <= m->ws_floats, ALINK_ENOMEM, "sgemm workspace too small (%zu floats)",
                   gemm32_workspace_floats(g));
-    ALINK_HIP(launch_gemm32(g, m->ws, st));
+    ALINK_HIP(launch_gemm32(g, ws ? ws : m->ws, st));
     return ALINK_OK;
 }
 
 // out = relu(conv3x3(in, w[layer]) + b[layer]); in is [nb][H][W][Ci]
 int conv_fwd(alink_smallres* m, const float* in, float* out, int layer, int nb, int H, int W, int prescale,
-             hipStream_t st) {
+             hipStream_t st, const float* in2 = nullptr, int split = 0) {
     const int Ci = CI[layer], Co = CO[layer], pad = PAD[layer];
     GemmP g{};
-    g.A = in; g.B = m->d_p + m->oW[layer]; g.C = out;
+    g.A = in; g.A2 = in2; g.a_split = split; g.B = m->d_p + m->oW[layer]; g.C = out;
     g.Ho = H + 2 * pad - 2; g.Wo = W + 2 * pad - 2;
     g.M = nb * g.Ho * g.Wo; g.N = Co; g.K = 9 * Ci; g.ldb = Co; g.ldc = Co;
     g.amode = A_CONV; g.bmode = B_ROW; g.H = H; g.W = W; g.Ci = Ci; g.pad = pad; g.prescale = prescale;
@@ -159,13 +168,16 @@ int conv_fwd(alink_smallres* m, const float* in, float* out, int layer, int nb, 
     return run_gemm(m, g, 1, st);
 }
 
-// tower forward on `nb` images; masks == nullptr -> inference (no dropout)
-int tower_fwd(alink_smallres* m, const float* img, int nb, int prescale, const uint8_t* mask1, const uint8_t* mask2,
+// tower forward on the nb = 2n images of a siamese batch — images 0 .. n-1 from `L`, n .. 2n-1 from `R` (R == nullptr: nb
+// images from L) — in ONE pass (until round 6: one pass per side; the two sides share every weight, and a layer's launch on
+// 2n images costs what it costs on n: none of them fills the chip); masks == nullptr -> inference (no dropout)
+int tower_fwd(alink_smallres* m, const float* L, const float* R, int n, int prescale, const uint8_t* mask1, const uint8_t* mask2,
               hipStream_t st) {
     const float* P = m->d_p;
     const float keep_scale = 1.f / (1.f - 0.25f);
+    const int nb = R ? 2 * n : n;
     int rc;
-    if ((rc = conv_fwd(m, img, m->a1, 0, nb, m->H, m->W, prescale, st))) return rc;
+    if ((rc = conv_fwd(m, L, m->a1, 0, nb, m->H, m->W, prescale, st, R, n))) return rc;
     if ((rc = conv_fwd(m, m->a1, m->a2, 1, nb, m->H, m->W, 0, st))) return rc;
     hipLaunchKernelGGL(pool_fwd_kernel, g1((long long)nb * m->P1h * m->P1w * 32), dim3(256), 0, st, m->a2, m->p1,
                        m->arg1, mask1, keep_scale, nb, m->H1, m->W1, 32);
@@ -186,15 +198,15 @@ int tower_fwd(alink_smallres* m, const float* img, int nb, int prescale, const u
 // dW[layer], db[layer] (contiguous in the gradient buffer) from the layer input `in` [nb][H][W][Ci]
 // and dz [nb][Ho][Wo][Co]; `accumulate` adds to what is there (second siamese branch of conv1)
 int wgrad(alink_smallres* m, const float* in, const float* dz, int layer, int nb, int H, int W, int prescale,
-          int accumulate, hipStream_t st) {
+          int accumulate, hipStream_t st, float* ws = nullptr, const float* in2 = nullptr, int split = 0) {
     const int Ci = CI[layer], Co = CO[layer], pad = PAD[layer];
     GemmP g{};
-    g.A = in; g.B = dz; g.C = m->d_g + m->oW[layer];
+    g.A = in; g.A2 = in2; g.a_split = split; g.B = dz; g.C = m->d_g + m->oW[layer];
     g.Ho = H + 2 * pad - 2; g.Wo = W + 2 * pad - 2;
     g.M = 9 * Ci + 1; g.N = Co; g.K = nb * g.Ho * g.Wo; g.ldb = Co; g.ldc = Co;      // row 9 Ci = bias gradient
     g.amode = A_CONVT; g.bmode = B_ROW; g.H = H; g.W = W; g.Ci = Ci; g.pad = pad; g.prescale = prescale;
     g.accumulate = accumulate;
-    return run_gemm(m, g, 128, st);
+    return run_gemm(m, g, 128, st, ws);
 }
 
 // din [nb][H][W][Ci] = conv-transpose of dz [nb][Ho][Wo][Co] with w[layer], masked by relu'(act) if act
@@ -232,7 +244,7 @@ alink_smallres_t* alink_smallres_create(int img_h, int img_w, int feat, float lr
     if (!m->head) { delete m; return nullptr; }
     const size_t nb = 2 * MAXN;
     int rc = 0;
-    rc |= sr_alloc(m, &m->d_p, m->ntower); rc |= sr_alloc(m, &m->d_g, m->ntower);
+    rc |= sr_alloc(m, &m->d_p, m->ntower);
     rc |= sr_alloc(m, &m->d_a, m->ntower); rc |= sr_alloc(m, &m->d_d, m->ntower);
     rc |= sr_alloc(m, &m->a1, nb * img_h * img_w * 32);
     rc |= sr_alloc(m, &m->a2, nb * m->H1 * m->W1 * 32);
@@ -242,15 +254,27 @@ alink_smallres_t* alink_smallres_create(int img_h, int img_w, int feat, float lr
     rc |= sr_alloc(m, &m->p2, nb * m->flat);
     rc |= sr_alloc(m, &m->f, nb * feat);
     rc |= sr_alloc(m, &m->dfeat, nb * feat);
-    const size_t big = nb * (size_t)img_h * img_w * 32;
-    rc |= sr_alloc(m, &m->da, big > nb * feat ? big : nb * feat);
-    rc |= sr_alloc(m, &m->db, big > nb * feat ? big : nb * feat);
+    rc |= sr_alloc(m, &m->gf, nb * feat);
+    rc |= sr_alloc(m, &m->gp2, nb * m->flat);
+    rc |= sr_alloc(m, &m->ga4, nb * m->H3 * m->W3 * 64);
+    rc |= sr_alloc(m, &m->ga3, nb * m->P1h * m->P1w * 64);
+    rc |= sr_alloc(m, &m->gp1, nb * m->P1h * m->P1w * 32);
+    rc |= sr_alloc(m, &m->ga2, nb * m->H1 * m->W1 * 32);
+    rc |= sr_alloc(m, &m->ga1, nb * img_h * img_w * 32);
     rc |= sr_alloc(m, &m->arg1, nb * m->P1h * m->P1w * 32);
     rc |= sr_alloc(m, &m->arg2, nb * m->P2h * m->P2w * 64);
+    // the tower's gradients are written where the data-parallel caller reads them: [tower | head] in one buffer
     rc |= sr_alloc(m, &m->d_all_grads, m->ntower + alink_head_num_params(m->head));
+    m->d_g = m->d_all_grads;
     m->ws_floats = (size_t)16 << 20;
     rc |= sr_alloc(m, &m->ws, m->ws_floats);
+    rc |= sr_alloc(m, &m->ws2, m->ws_floats);
     if (rc) { delete m; return nullptr; }
+    bool ok = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess;
+    for (hipEvent_t& e : m->ev_dz) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&m->ev_prev, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { set_error("SmallRes: side stream / events could not be created"); delete m; return nullptr; }
     return m;
 }
 
@@ -291,36 +315,13 @@ int alink_smallres_mask_sizes(const alink_smallres_t* m, int* a, int* b) {
     return ALINK_OK;
 }
 
-// both inputs through the tower: features of L in f[0:n], of R in f[n:2n].  L and R are separate
-// buffers, so the tower runs on each (activation buffers hold 2n images: R's pass uses the upper half).
-static int tower_pair_fwd(alink_smallres* m, const float* L, const float* R, int n, int prescale,
-                          const uint8_t* masks, hipStream_t st, bool keep_both) {
-    // Run L then R with activation base pointers shifted so both sets of activations survive for the
-    // backward pass.  Implemented by temporarily offsetting the activation pointers.
-    alink_smallres s = *m;   // shallow copy of pointers (no ownership: allocs vector cleared below)
-    s.allocs.clear();
-    s.head = nullptr;
-    const uint8_t *m1 = nullptr, *m2 = nullptr;
-    const size_t e1 = (size_t)m->P1h * m->P1w * 32, e2 = (size_t)m->P2h * m->P2w * 64;
-    if (masks) { m1 = masks; m2 = masks + 2 * (size_t)n * e1; }
-    int rc = tower_fwd(&s, L, n, prescale, m1, m2, st);
-    if (rc) return rc;
-    (void)keep_both;
-    s.a1 += (size_t)n * m->H * m->W * 32;  s.a2 += (size_t)n * m->H1 * m->W1 * 32;
-    s.p1 += (size_t)n * e1;                s.a3 += (size_t)n * m->P1h * m->P1w * 64;
-    s.a4 += (size_t)n * m->H3 * m->W3 * 64; s.p2 += (size_t)n * m->flat;
-    s.f += (size_t)n * m->feat;            s.arg1 += (size_t)n * e1;  s.arg2 += (size_t)n * e2;
-    rc = tower_fwd(&s, R, n, prescale, m1 ? m1 + (size_t)n * e1 : nullptr, m2 ? m2 + (size_t)n * e2 : nullptr, st);
-    return rc;
-}
-
 int alink_smallres_forward(alink_smallres_t* m, const float* dev_L, const float* dev_R, int n, int prescale,
                            float* dev_probs, void* stream) {
     ALINK_REQUIRE(m && dev_L && dev_R && dev_probs, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
     DeviceGuard dg(m->device);
     hipStream_t st = (hipStream_t)stream;
-    int rc = tower_pair_fwd(m, dev_L, dev_R, n, prescale, nullptr, st, false);
+    int rc = tower_fwd(m, dev_L, dev_R, n, prescale, nullptr, nullptr, st);       // features of L in f[0:n], of R in f[n:2n]
     if (rc) return rc;
     return alink_head_forward(m->head, m->f, m->f + (size_t)n * m->feat, nullptr, nullptr, n, dev_probs, stream);
 }
@@ -330,10 +331,13 @@ int alink_smallres_eval(alink_smallres_t* m, const float* dev_L, const float* de
     ALINK_REQUIRE(m && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
     DeviceGuard dg(m->device);
-    int rc = tower_pair_fwd(m, dev_L, dev_R, n, prescale, nullptr, (hipStream_t)stream, false);
+    int rc = tower_fwd(m, dev_L, dev_R, n, prescale, nullptr, nullptr, (hipStream_t)stream);
     if (rc) return rc;
     return alink_head_eval(m->head, m->f, m->f + (size_t)n * m->feat, dev_y, n, dev_metrics, stream);
 }
+
+static bool g_smallres_overlap = true;
+void alink_debug_set_smallres_overlap(int on) { g_smallres_overlap = on != 0; }      // include/alink_hip_debug.h
 
 int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
                               const float* dev_sw, int n, int prescale, const uint8_t* dev_masks, float grad_scale,
@@ -342,59 +346,90 @@ int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const flo
     ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
     DeviceGuard dg(m->device);
     hipStream_t st = (hipStream_t)stream;
-    int rc = tower_pair_fwd(m, dev_L, dev_R, n, prescale, dev_masks, st, true);
+    const size_t e1 = (size_t)m->P1h * m->P1w * 32;
+    const uint8_t* m1 = dev_masks;
+    const uint8_t* m2 = dev_masks ? dev_masks + 2 * (size_t)n * e1 : nullptr;
+    int rc = tower_fwd(m, dev_L, dev_R, n, prescale, m1, m2, st);
     if (rc) return rc;
     float* fL = m->f;
     float* fR = m->f + (size_t)n * m->feat;
     if ((rc = alink_head_train_step(m->head, fL, fR, dev_y, dev_sw, n, grad_scale, 0, dev_metrics, stream))) return rc;
     if ((rc = alink_head_input_grads(m->head, fL, fR, n, m->dfeat, m->dfeat + (size_t)n * m->feat, stream))) return rc;
-    // the shared tower sees 2n images: [L ; R] are contiguous in every activation buffer, so ONE
-    // backward pass over 2n images accumulates both branches' weight gradients.  The image buffers
-    // are separate, so conv1's weight gradient is taken per branch.
-    const size_t e1 = (size_t)m->P1h * m->P1w * 32, e2 = (size_t)m->P2h * m->P2w * 64;
-    const uint8_t* m1 = dev_masks;
-    const uint8_t* m2 = dev_masks ? dev_masks + 2 * (size_t)n * e1 : nullptr;
-    (void)e2;
-    // run the backward on 2n images but stop before conv1's weight gradient (needs the two image buffers)
-    {
-        const float* P = m->d_p;
-        float* G = m->d_g;
-        const int nb = 2 * n;
-        const float keep_scale = 1.f / (1.f - 0.25f);
-        hipLaunchKernelGGL(relu_mask_kernel, g1((long long)nb * m->feat), dim3(256), 0, st, m->f, m->dfeat, m->da,
-                           (long long)nb * m->feat);
-        {   // gW[flat][feat] = p2^T . dz ; gb = column sums
-            GemmP g{};
-            g.A = m->p2; g.B = m->da; g.C = G + m->oDW; g.M = m->flat; g.N = m->feat; g.K = nb;
-            g.lda = m->flat; g.ldb = m->feat; g.ldc = m->feat; g.amode = A_COL; g.bmode = B_ROW;
-            if ((rc = run_gemm(m, g, 1, st))) return rc;
-            ALINK_HIP(launch_colsum(m->da, G + m->oDB, nb, m->feat, st));
-        }
-        {   // d(p2)[nb][flat] = dz . W^T
-            GemmP g{};
-            g.A = m->da; g.B = P + m->oDW; g.C = m->db; g.M = nb; g.N = m->flat; g.K = m->feat;
-            g.lda = m->feat; g.ldb = m->feat; g.ldc = m->flat; g.amode = A_ROW; g.bmode = B_COLT;
-            if ((rc = run_gemm(m, g, 16, st))) return rc;
-        }
-        hipLaunchKernelGGL(pool_bwd_kernel, g1((long long)nb * m->H3 * m->W3 * 64), dim3(256), 0, st, m->db, m->arg2, m2,
-                           keep_scale, m->a4, m->da, nb, m->H3, m->W3, 64);
-        if ((rc = wgrad(m, m->a3, m->da, 3, nb, m->P1h, m->P1w, 0, 0, st))) return rc;
-        if ((rc = dgrad(m, m->da, m->db, m->a3, 3, nb, m->P1h, m->P1w, st))) return rc;
-        if ((rc = wgrad(m, m->p1, m->db, 2, nb, m->P1h, m->P1w, 0, 0, st))) return rc;
-        if ((rc = dgrad(m, m->db, m->da, nullptr, 2, nb, m->P1h, m->P1w, st))) return rc;
-        hipLaunchKernelGGL(pool_bwd_kernel, g1((long long)nb * m->H1 * m->W1 * 32), dim3(256), 0, st, m->da, m->arg1, m1,
-                           keep_scale, m->a2, m->db, nb, m->H1, m->W1, 32);
-        if ((rc = wgrad(m, m->a1, m->db, 1, nb, m->H, m->W, 0, 0, st))) return rc;
-        if ((rc = dgrad(m, m->db, m->da, m->a1, 1, nb, m->H, m->W, st))) return rc;
-        if ((rc = wgrad(m, dev_L, m->da, 0, n, m->H, m->W, prescale, 0, st))) return rc;
-        if ((rc = wgrad(m, dev_R, m->da + (size_t)n * m->H * m->W * 32, 0, n, m->H, m->W, prescale, 1, st))) return rc;
-        ALINK_HIP(hipGetLastError());
+    // The shared tower saw 2n images ([L ; R] contiguous in every activation buffer): ONE backward pass over 2n images
+    // gives both branches' weight gradients.  Two chains from here: the input gradients (dz of a layer from the dz of
+    // the next) on the caller's stream, and the weight gradients — each needs only its layer's input and dz — on a side
+    // stream beside it (round 6; ws2 = that stream's own split-K slabs).
+    const bool two = g_smallres_overlap;
+    hipStream_t sw = two ? m->side : st;
+    float* wsw = two ? m->ws2 : m->ws;
+    auto fork = [&](int i) -> int {        // the side stream may start what needs the dz just produced
+        if (!two) return ALINK_OK;
+        ALINK_HIP(hipEventRecord(m->ev_dz[i], st));
+        ALINK_HIP(hipStreamWaitEvent(m->side, m->ev_dz[i], 0));
+        return ALINK_OK;
+    };
+    const float* P = m->d_p;
+    float* G = m->d_g;
+    const int nb = 2 * n;
+    const float keep_scale = 1.f / (1.f - 0.25f);
+    hipLaunchKernelGGL(relu_mask_kernel, g1((long long)nb * m->feat), dim3(256), 0, st, m->f, m->dfeat, m->gf,
+                       (long long)nb * m->feat);
+    if ((rc = fork(0))) return rc;
+    {   // gW[flat][feat] = p2^T . dz ; gb = column sums
+        GemmP g{};
+        g.A = m->p2; g.B = m->gf; g.C = G + m->oDW; g.M = m->flat; g.N = m->feat; g.K = nb;
+        g.lda = m->flat; g.ldb = m->feat; g.ldc = m->feat; g.amode = A_COL; g.bmode = B_ROW;
+        if ((rc = run_gemm(m, g, 1, sw, wsw))) return rc;
+        ALINK_HIP(launch_colsum(m->gf, G + m->oDB, nb, m->feat, sw));
     }
-    // contiguous gradient copy [tower | head] for the data-parallel all-reduce
-    ALINK_HIP(hipMemcpyAsync(m->d_all_grads, m->d_g, m->ntower * sizeof(float), hipMemcpyDeviceToDevice, st));
+    {   // d(p2)[nb][flat] = dz . W^T
+        GemmP g{};
+        g.A = m->gf; g.B = P + m->oDW; g.C = m->gp2; g.M = nb; g.N = m->flat; g.K = m->feat;
+        g.lda = m->feat; g.ldb = m->feat; g.ldc = m->flat; g.amode = A_ROW; g.bmode = B_COLT;
+        if ((rc = run_gemm(m, g, 16, st))) return rc;
+    }
+    const bool early = two && apply;
+    if (early) {
+        // The wide Dense layer is 99 % of the parameters (flat x feat = 4.7 M of 4.8 M at 32 x 32 / 2048) and its update 20 us
+        // of HBM traffic: it starts on the side stream as soon as its gradient exists and the input gradient above has read
+        // the old W — beside the dz chain instead of after it.
+        ALINK_HIP(hipEventRecord(m->ev_prev, st));
+        ALINK_HIP(hipStreamWaitEvent(m->side, m->ev_prev, 0));
+        const size_t nd = m->ntower - m->oDW;
+        hipLaunchKernelGGL(adadelta2_kernel, g1((long long)nd), dim3(256), 0, m->side, m->d_p + m->oDW, m->d_g + m->oDW,
+                           m->d_a + m->oDW, m->d_d + m->oDW, nd, m->lr, m->rho, m->eps);
+    }
+    hipLaunchKernelGGL(pool_bwd_kernel, g1((long long)nb * m->H3 * m->W3 * 64), dim3(256), 0, st, m->gp2, m->arg2, m2,
+                       keep_scale, m->a4, m->ga4, nb, m->H3, m->W3, 64);
+    if ((rc = fork(1))) return rc;
+    if ((rc = wgrad(m, m->a3, m->ga4, 3, nb, m->P1h, m->P1w, 0, 0, sw, wsw))) return rc;
+    if ((rc = dgrad(m, m->ga4, m->ga3, m->a3, 3, nb, m->P1h, m->P1w, st))) return rc;
+    if ((rc = fork(2))) return rc;
+    if ((rc = wgrad(m, m->p1, m->ga3, 2, nb, m->P1h, m->P1w, 0, 0, sw, wsw))) return rc;
+    if ((rc = dgrad(m, m->ga3, m->gp1, nullptr, 2, nb, m->P1h, m->P1w, st))) return rc;
+    hipLaunchKernelGGL(pool_bwd_kernel, g1((long long)nb * m->H1 * m->W1 * 32), dim3(256), 0, st, m->gp1, m->arg1, m1,
+                       keep_scale, m->a2, m->ga2, nb, m->H1, m->W1, 32);
+    if ((rc = fork(3))) return rc;
+    if ((rc = wgrad(m, m->a1, m->ga2, 1, nb, m->H, m->W, 0, 0, sw, wsw))) return rc;
+    if ((rc = dgrad(m, m->ga2, m->ga1, m->a1, 1, nb, m->H, m->W, st))) return rc;
+    // conv1's weight gradient gathers from the two image buffers (the last link of the dz chain: on the caller's stream)
+    if ((rc = wgrad(m, dev_L, m->ga1, 0, nb, m->H, m->W, prescale, 0, st, nullptr, dev_R, n))) return rc;
+    ALINK_HIP(hipGetLastError());
+    if (two) {                             // join: everything after this sees every gradient
+        ALINK_HIP(hipEventRecord(m->ev_side, m->side));
+        ALINK_HIP(hipStreamWaitEvent(st, m->ev_side, 0));
+    }
+    if (apply) {
+        // the update takes the tower's gradients where they are and the head's from its own buffer: nothing is copied
+        const size_t nu = early ? m->oDW : m->ntower;        // (the Dense layer's share is already under way)
+        hipLaunchKernelGGL(adadelta2_kernel, g1((long long)nu), dim3(256), 0, st, m->d_p, m->d_g, m->d_a, m->d_d,
+                           nu, m->lr, m->rho, m->eps);
+        ALINK_HIP(hipGetLastError());
+        return alink_head_apply_update(m->head, stream);
+    }
+    // gradients only (a data-parallel caller all-reduces the contiguous buffer, then alink_smallres_apply_update)
     ALINK_HIP(hipMemcpyAsync(m->d_all_grads + m->ntower, alink_head_grads_dev(m->head),
                              alink_head_num_params(m->head) * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (apply) return alink_smallres_apply_update(m, stream);
     return ALINK_OK;
 }
 

@@ -48,6 +48,10 @@ class SmallResNet(KerasFitMixin):
                np.zeros(32, np.float32), glorot_uniform(rng, 32, 2), np.zeros(2, np.float32)]
         self.set_weights(ws)
         self._metrics = torch.zeros(2, dtype=torch.float32, device=self.device)
+        # {loss, accuracy} of a step land in pinned host memory, written by the kernel itself (as DenseHead's do): a step ends with
+        # one stream wait instead of a device-to-host copy
+        self._metrics_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        self._tdev = torch.device(self.device)
         self.prescale = 1 if prescale else 0
 
     def __del__(self):
@@ -160,11 +164,12 @@ class SmallResNet(KerasFitMixin):
                                                  _abi.current_stream(self.device)), "alink_keep_masks")
         else:
             md = self.torch.from_numpy(np.ascontiguousarray(masks, np.uint8)).to(self.device) if masks is not None else None
+        st = self.torch.cuda.current_stream(self._tdev)
         _abi.check(self.lib.alink_smallres_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
-                                                      self.prescale, _abi.ptr(md), 0.0, 1, _abi.ptr(self._metrics),
-                                                      _abi.current_stream(self.device)), "alink_smallres_train_step")
-        m = self._metrics.cpu().numpy()
-        return [float(m[0]), float(m[1])]
+                                                      self.prescale, _abi.ptr(md), 0.0, 1, C.c_void_p(self._metrics_host.data_ptr()),
+                                                      C.c_void_p(st.cuda_stream)), "alink_smallres_train_step")
+        st.synchronize()
+        return self._metrics_host.tolist()
 
     def test_on_batch(self, x, y):
         L, R, yd = self._dev(x[0]), self._dev(x[1]), self._dev(y)

@@ -57,6 +57,10 @@ void alink_debug_set_tiny_step(int on);
 /* 0: the bf16 compute mode's predict on the f32-input kernel with in-flight rounding instead of head_fwd_bf16_kernel */
 void alink_debug_set_head_bf16_mfma(int on);
 
+/* ---- SmallRes (csrc/smallres.hip) -------------------------------------------------------------------------------------- */
+/* 0: the weight gradients of a train step on the caller's stream, after their dz, instead of a side stream beside the dz chain */
+void alink_debug_set_smallres_overlap(int on);
+
 /* ---- diagnostics ------------------------------------------------------------------------------------------------------ */
 /* alink_embed returns after this many convolution launches (0 = the whole chain): per-layer timing by difference.
  * CHANGES THE RESULT (the embedding is garbage): tools only. */
