@@ -52,6 +52,7 @@ class SmallResNet(KerasFitMixin):
         # one stream wait instead of a device-to-host copy
         self._metrics_host = torch.zeros(2, dtype=torch.float32).pin_memory()
         self._tdev = torch.device(self.device)
+        self._mask_buf = {}
         self.prescale = 1 if prescale else 0
 
     def __del__(self):
@@ -159,7 +160,9 @@ class SmallResNet(KerasFitMixin):
             # 2n(e1 + e2) = 304,128 uniforms with np.random on the host was 0.74 of the step's 1.68 ms.  One np.random draw per step
             # keeps the ranks of a multi-rank loop in step (alink_loop.sync_host_randomness) like the host-drawn masks did.
             e1, e2 = self.mask_sizes
-            md = self.torch.empty(2 * n * (e1 + e2), dtype=self.torch.uint8, device=self.device)
+            md = self._mask_buf.get(n)                   # (a step's masks are consumed by that step, in stream order)
+            if md is None:
+                md = self._mask_buf[n] = self.torch.empty(2 * n * (e1 + e2), dtype=self.torch.uint8, device=self.device)
             _abi.check(self.lib.alink_keep_masks(_abi.ptr(md), md.numel(), 0.75, int(np.random.randint(0, 2 ** 31 - 1)),
                                                  _abi.current_stream(self.device)), "alink_keep_masks")
         else:

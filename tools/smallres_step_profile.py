@@ -26,14 +26,17 @@ def main():
     R = torch.from_numpy(((rs.randint(0, 256, (16, res, res, 3)) - 128.0) / 128.0).astype(np.float32)).cuda()
     y = torch.from_numpy(np.eye(2, dtype=np.float32)[rs.randint(0, 2, 16)]).cuda()
     np.random.seed(0)
-    for _ in range(10):
-        srn.train_on_batch([L, R], y)
-    ts = []
-    for _ in range(steps):
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        srn.train_on_batch([L, R], y)
-        ts.append(time.perf_counter() - t)
+    side = len(sys.argv) > 4 and sys.argv[4] == "side"          # A/B: the step on a stream of its own instead of torch's default (the NULL stream)
+    ctx = torch.cuda.stream(torch.cuda.Stream()) if side else torch.cuda.stream(torch.cuda.current_stream())
+    with ctx:
+        for _ in range(10):
+            srn.train_on_batch([L, R], y)
+        ts = []
+        for _ in range(steps):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            srn.train_on_batch([L, R], y)
+            ts.append(time.perf_counter() - t)
     P = torch.from_numpy(((rs.randint(0, 256, (256, res, res, 3)) - 128.0) / 128.0).astype(np.float32)).cuda()
     srn.predict([P, P])
     torch.cuda.synchronize()
