@@ -121,6 +121,7 @@ PROTOTYPES = {
     "alink_noise_speckle": (_i, [_vp, _vp, _i64, _f, _u64, _u64, _vp]),
     "alink_noise_uniform": (_i, [_vp, _vp, _i64, _f, _f, _u64, _u64, _vp]),
     "alink_keep_masks": (_i, [_vp, _i64, _f, _u64, _vp]),
+    "alink_keep_masks_at": (_i, [_vp, _i64, _f, _u64, _u64, _vp]),
     "alink_noise_saltpepper": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u64, _vp]),
     "alink_noise_poisson_scratch_bytes": (_sz, [_i, _i64]),
     "alink_noise_poisson": (_i, [_vp, _vp, _i, _i64, _u64, _u64, _vp, _sz, _vp, _vp]),

@@ -415,7 +415,9 @@ def run_alink_mtp(flags, conversionModel, bag, ensembleNoise, lowResModel, X_dig
                   verbose=1, state=None, group=None):
     """The framework loop of ALINK_MTP.py (code/ALINK_MTP.py:150-266): the teacher committee scores
     high-res features, the student (SmallRes) sees noisy LOW-res pixels and is fine-tuned on them.
-    group: as in run_alink_dfw (the student's train steps run replicated: every rank holds the same SmallRes)."""
+    group: as in run_alink_dfw; the student's fine-tune goes through distributed.dp_train_on_batch like the head's (SmallResNet
+    has the same four-method side of it): replicated at the reference's batch of 16 (every rank holds the same SmallRes and draws
+    the same mask seed), sharded with one exchange of the 20 MB gradient buffer from SmallResNet.DP_SHARD_MIN_ROWS rows."""
     from . import noise as _noise
     log = print if verbose else (lambda *a, **k: None)
     state = state or LoopState()

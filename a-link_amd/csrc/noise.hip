@@ -105,14 +105,18 @@ __global__ __launch_bounds__(256) void affine_noise_kernel(const AffineNoise p) 
 
 // ---- Bernoulli keep-masks (Dropout of the SmallRes tower, code/siamese.py:146,153) -----------------------------
 // mask[e] = 1 with probability `keep`: the element's 24-bit uniform (word e & 3 of Philox block e >> 2) < keep.
+// `first`: the element out[0] stands for — a rank that trains rows lo : hi of a batch draws those rows' masks exactly
 __global__ __launch_bounds__(256) void keep_mask_kernel(unsigned char* __restrict__ out, long long count, float keep,
-                                                        unsigned long long seed) {
-    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long i0 = g * 4;
-    if (i0 >= count) return;
-    const U4 r = draw(seed, (unsigned long long)g, 0, ST_DROPOUT);
+                                                        unsigned long long seed, unsigned long long first) {
+    const unsigned long long b = (first >> 2) + (unsigned long long)blockIdx.x * 256 + threadIdx.x;      // Philox block
+    const unsigned long long e0 = b * 4;
+    if (e0 >= first + (unsigned long long)count) return;
+    const U4 r = draw(seed, b, 0, ST_DROPOUT);
     const unsigned int w[4] = {r.x, r.y, r.z, r.w};
-    for (int j = 0; j < 4 && i0 + j < count; ++j) out[i0 + j] = u01(w[j]) < keep ? 1 : 0;
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long e = e0 + j;
+        if (e >= first && e < first + (unsigned long long)count) out[e - first] = u01(w[j]) < keep ? 1 : 0;
+    }
 }
 
 // ---- Salt & pepper (code/noise.py:54-65, tuple-index semantics of NumPy < 1.23) --------------------
@@ -713,10 +717,15 @@ int alink_noise_uniform(const float* dev_in, float* dev_out, int64_t count, floa
 }
 
 int alink_keep_masks(uint8_t* dev_out, int64_t count, float keep, uint64_t seed, void* stream) {
+    return alink_keep_masks_at(dev_out, count, keep, seed, 0, stream);
+}
+
+int alink_keep_masks_at(uint8_t* dev_out, int64_t count, float keep, uint64_t seed, uint64_t first, void* stream) {
     ALINK_REQUIRE(dev_out && count >= 0 && keep >= 0.f && keep <= 1.f, ALINK_EINVAL, "bad argument");
     DeviceGuard dg(device_of_pointer(dev_out));
     if (count == 0) return ALINK_OK;
-    hipLaunchKernelGGL(keep_mask_kernel, g1((count + 3) / 4), dim3(256), 0, (hipStream_t)stream, dev_out, (long long)count, keep, seed);
+    hipLaunchKernelGGL(keep_mask_kernel, g1(((long long)(first & 3) + count + 3) / 4), dim3(256), 0, (hipStream_t)stream, dev_out,
+                       (long long)count, keep, seed, (unsigned long long)first);
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
 }

@@ -264,7 +264,7 @@ alink_smallres_t* alink_smallres_create(int img_h, int img_w, int feat, float lr
     rc |= sr_alloc(m, &m->arg1, nb * m->P1h * m->P1w * 32);
     rc |= sr_alloc(m, &m->arg2, nb * m->P2h * m->P2w * 64);
     // the tower's gradients are written where the data-parallel caller reads them: [tower | head] in one buffer
-    rc |= sr_alloc(m, &m->d_all_grads, m->ntower + alink_head_num_params(m->head));
+    rc |= sr_alloc(m, &m->d_all_grads, m->ntower + alink_head_num_params(m->head) + 4);      // + 4 spare floats (a data-parallel step's metrics travel with the gradients)
     m->d_g = m->d_all_grads;
     m->ws_floats = (size_t)16 << 20;
     rc |= sr_alloc(m, &m->ws, m->ws_floats);

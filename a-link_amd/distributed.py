@@ -144,59 +144,60 @@ DP_SHARD_MIN_ROWS = 2048
 
 
 def dp_train_on_batch(head, x, y, class_weight=None, sample_weight=None, group=None, mode="auto", exchange="gather"):
-    """Keras train_on_batch on a DenseHead in a one-process-per-GPU job: x=[L,R], y one-hot — the FULL batch on
-    every rank.  mode "replicated": every rank runs the whole step (bit-identical weights, zero communication);
-    "sharded": each rank runs its slice with the GLOBAL normaliser, ONE all-reduce carries gradients + metrics,
-    every rank applies the same Adadelta update (equal to the single-GPU step up to f32 summation order);
-    "auto": replicated below DP_SHARD_MIN_ROWS rows.
-    exchange (sharded mode): "gather" = ONE all-gather of every rank's 1.18 MB gradient buffer over the direct xGMI links
-    and a sum in rank order on every rank (one-shot, latency of one hop, the same bits on every rank whatever algorithm
-    the library would pick for a reduction: SURVEY.md §5 — a ring is the wrong shape for a message this small);
-    "allreduce" = torch.distributed.all_reduce (RCCL's own choice)."""
+    """Keras train_on_batch in a one-process-per-GPU job, for a DenseHead (the siamese fine-tune step, reference
+    code/siamese.py:52-58) or a SmallResNet (the end-to-end student of code/ALINK_MTP.py:121,255, code/siamese.py:134-170 —
+    SURVEY.md §8e: "all-reduce(sum) of head / SmallRes gradients"): x=[L,R], y one-hot — the FULL batch on every rank.
+    mode "replicated": every rank runs the whole step (bit-identical weights, zero communication);
+    "sharded": each rank runs its slice with the GLOBAL normaliser (and, for SmallRes, the dropout masks of its GLOBAL
+    rows), ONE exchange carries gradients + metrics, every rank applies the same Adadelta update (equal to the single-GPU
+    step up to f32 summation order);
+    "auto": replicated below the model's DP_SHARD_MIN_ROWS rows.
+    exchange (sharded mode): "gather" = ONE all-gather of every rank's flat gradient buffer (1.18 MB head-512, 20.2 MB
+    SmallRes 32 x 32 / 2048) over the direct xGMI links and a sum in rank order on every rank (one-shot, latency of one hop,
+    the same bits on every rank whatever algorithm the library would pick for a reduction: SURVEY.md §5);
+    "allreduce" = torch.distributed.all_reduce (RCCL's own choice); "host" = staged through the host (gloo).
+    The model's side of it is four methods — grads_tensor(with_metrics=True), dp_begin, dp_local_grads, dp_apply (head.py,
+    smallres.py) — so that the control flow here is what the CPU tests run over the oracle's arithmetic."""
     if mode == "auto":
-        mode = "replicated" if len(y) < DP_SHARD_MIN_ROWS else "sharded"
+        mode = "replicated" if len(y) < getattr(head, "DP_SHARD_MIN_ROWS", DP_SHARD_MIN_ROWS) else "sharded"
     if mode == "replicated":
         return head.train_on_batch(x, y, class_weight=class_weight, sample_weight=sample_weight)
     if mode != "sharded":
         raise ValueError("mode must be auto, replicated or sharded")
     import torch
-    from . import _abi
     dist = _dist()
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     n = len(y)
-    sw = head._sample_weights(y, class_weight, sample_weight)
+    from .head import DenseHead
+    sw = DenseHead._sample_weights(y, class_weight, sample_weight)
     w_all = np.ones(n, np.float32) if sw is None else np.asarray(sw, np.float32)
     denom = float((w_all != 0).sum())                        # Keras: mean(w*l) / mean(w != 0)
     lo, hi = shard_range(n, rank, world)
-    # gradients and {loss, accuracy-sum} travel in ONE all-reduce: the metrics live in the spare floats
+    # gradients and {loss, accuracy-sum} travel in ONE exchange: the metrics live in the spare floats
     # that follow the flat gradient buffer
     gm = head.grads_tensor(with_metrics=True)
     m = gm[-4:]
     m.zero_()
-    st = _abi.current_stream(head.device)
+    ctx = head.dp_begin(n, group)                            # what every rank must agree on before its slice (SmallRes: the mask seed)
     if hi > lo:
-        take = lambda a: a[lo:hi] if hasattr(a, "shape") else np.asarray(a)[lo:hi]
-        L, R = head._dev(take(x[0])), head._dev(take(x[1]))
-        yd, swd = head._dev(take(y)), (None if sw is None else head._dev(w_all[lo:hi]))
-        _abi.check(head.lib.alink_head_train_step(head.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd),
-                                                  hi - lo, 1.0 / denom, 0, _abi.ptr(m), st))
+        head.dp_local_grads(x, y, None if sw is None else w_all, lo, hi, n, 1.0 / denom, m, ctx)
         m[1] *= (hi - lo)                                    # accuracy: local mean -> local sum
     else:
         gm.zero_()
-    if exchange == "gather" and world > 1:
+    if exchange == "gather" and world > 1 and gm.is_cuda:
         every = torch.empty((world, gm.numel()), dtype=gm.dtype, device=gm.device)
         dist.all_gather_into_tensor(every, gm, group=group)
         torch.sum(every, dim=0, out=gm)                      # fixed (rank) order
     elif exchange in ("gather", "allreduce"):
         dist.all_reduce(gm, group=group)
     elif exchange == "host":
-        # a backend without device collectives (gloo): the 1.18 MB buffer is staged through the host
+        # a backend without device collectives (gloo): the buffer is staged through the host
         hbuf = gm.cpu()
         dist.all_reduce(hbuf, group=group)
         gm.copy_(hbuf)
     else:
         raise ValueError("exchange must be gather, allreduce or host")
-    _abi.check(head.lib.alink_head_apply_update(head.h, st))
+    head.dp_apply()
     out = m[:2].cpu().numpy()
     return [float(out[0]), float(out[1] / n)]
 

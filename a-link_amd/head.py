@@ -469,6 +469,22 @@ class DenseHead(KerasFitMixin):
         st.synchronize()
         return self._metrics_host.tolist()
 
+    # -- the model's side of distributed.dp_train_on_batch (sharded mode) -------------------------------------------
+    def dp_begin(self, n, group):
+        return None
+
+    def dp_local_grads(self, x, y, w_all, lo, hi, n, grad_scale, m, ctx):
+        """gradients (left in grads_tensor()) and {loss x grad_scale sum, accuracy mean} (into m) of rows lo : hi"""
+        take = lambda a: a[lo:hi] if hasattr(a, "shape") else np.asarray(a)[lo:hi]
+        L, R = self._dev(take(x[0])), self._dev(take(x[1]))
+        yd, swd = self._dev(take(y)), (None if w_all is None else self._dev(w_all[lo:hi]))
+        _abi.check(self.lib.alink_head_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd),
+                                                  hi - lo, grad_scale, 0, _abi.ptr(m), _abi.current_stream(self.device)),
+                   "alink_head_train_step")
+
+    def dp_apply(self):
+        _abi.check(self.lib.alink_head_apply_update(self.h, _abi.current_stream(self.device)), "alink_head_apply_update")
+
     def input_gradients(self, L, R, y):
         """EXTENSION (FGSM / PGD): d(loss)/dL, d(loss)/dR of the Keras loss of this batch (mean over the
         batch), parameters untouched.  L, R: (n, d_in) CUDA float32; y: (n, out_dim) targets."""

@@ -174,6 +174,67 @@ class SmallResNet(KerasFitMixin):
         st.synchronize()
         return self._metrics_host.tolist()
 
+    # -- data-parallel step (distributed.dp_train_on_batch) --------------------------------------------
+    # Rows from which the step is SHARDED in mode "auto".  One 16-pair step is 0.35 ms on one MI355X (profiles/r06d_*); its flat
+    # gradient buffer is 20.2 MB at 32 x 32 / 2048 — an 8-rank exchange moves 7 x 20 MB into every rank over 7 xGMI links
+    # (~150 GB/s each: >= 0.15 ms before any latency) plus the sum.  Replicas fed the same batch and the same mask seed stay
+    # bit-identical, so below ~8 steps' worth of rows per rank replication wins; the threshold is that estimate — no multi-GPU
+    # node was available to measure it — and `mode="sharded"` forces the exchange at any size.
+    DP_SHARD_MIN_ROWS = 128
+
+    def grads_tensor(self, with_metrics=False):
+        """torch alias of the flat [tower | head] gradient buffer (for torch.distributed collectives); with_metrics appends
+        the 4 spare floats that follow it (slot 0 / 1: loss, accuracy of a data-parallel step)."""
+        torch = self.torch
+        n = self.lib.alink_smallres_num_params(self.h) + (4 if with_metrics else 0)
+
+        class _CAI(object):
+            pass
+        holder = _CAI()
+        holder.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(self.lib.alink_smallres_grads_dev(self.h)), False),
+                                           "version": 2, "strides": None}
+        t = torch.as_tensor(holder, device=self.device)
+        t._alink_owner = self
+        return t
+
+    def dp_begin(self, n, group):
+        """the step's dropout seed: every rank draws one (np.random stays in step on all ranks, as in the replicated form)
+        and rank 0's is the one used"""
+        seed = int(np.random.randint(0, 2 ** 31 - 1)) if self.training_dropout else -1
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            box = [seed]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            seed = int(box[0])
+        return seed
+
+    def _masks_of_rows(self, lo, hi, n, seed):
+        """the keep-masks the whole-batch step (train_on_batch: one stream of 2n(e1 + e2) elements, [L ; R] image order per
+        pool) draws for pair rows lo : hi, in the layout of a batch of hi - lo pairs"""
+        e1, e2 = self.mask_sizes
+        k = hi - lo
+        md = self.torch.empty(2 * k * (e1 + e2), dtype=self.torch.uint8, device=self.device)
+        st = _abi.current_stream(self.device)
+        parts = ((0, lo * e1, k * e1), (k * e1, (n + lo) * e1, k * e1),                       # pool 1: L rows, R rows
+                 (2 * k * e1, 2 * n * e1 + lo * e2, k * e2), (2 * k * e1 + k * e2, 2 * n * e1 + (n + lo) * e2, k * e2))
+        for dst, first, count in parts:
+            _abi.check(self.lib.alink_keep_masks_at(_abi.ptr(md[dst:dst + count]), count, 0.75, seed, first, st), "alink_keep_masks_at")
+        return md
+
+    def dp_local_grads(self, x, y, w_all, lo, hi, n, grad_scale, m, ctx):
+        take = lambda a: a[lo:hi] if hasattr(a, "shape") else np.asarray(a)[lo:hi]
+        L, R, yd = self._dev(take(x[0])), self._dev(take(x[1])), self._dev(take(y))
+        swd = None if w_all is None else self._dev(w_all[lo:hi])
+        k = hi - lo
+        assert k <= MAXN, "a rank's slice of more than %d pairs is not supported" % MAXN
+        md = self._masks_of_rows(lo, hi, n, ctx) if (self.training_dropout and ctx is not None and ctx >= 0) else None
+        _abi.check(self.lib.alink_smallres_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), k,
+                                                      self.prescale, _abi.ptr(md), grad_scale, 0, _abi.ptr(m),
+                                                      _abi.current_stream(self.device)), "alink_smallres_train_step")
+
+    def dp_apply(self):
+        _abi.check(self.lib.alink_smallres_apply_update(self.h, _abi.current_stream(self.device)), "alink_smallres_apply_update")
+
     def test_on_batch(self, x, y):
         L, R, yd = self._dev(x[0]), self._dev(x[1]), self._dev(y)
         tot, seen = np.zeros(2), 0

@@ -358,7 +358,8 @@ size_t alink_smallres_num_params(const alink_smallres_t* m);
 int alink_smallres_set_params(alink_smallres_t* m, const float* host, size_t count);
 int alink_smallres_get_params(const alink_smallres_t* m, float* host, size_t count);
 int alink_smallres_set_lr(alink_smallres_t* m, float lr);
-float* alink_smallres_grads_dev(alink_smallres_t* m);      /* flat tower+head gradients (all-reduce) */
+float* alink_smallres_grads_dev(alink_smallres_t* m);      /* flat tower+head gradients (all-reduce), followed by 4 spare floats:
+                                                            * a data-parallel caller points dev_metrics at them (as for alink_head_grads_dev) */
 /* predict: probs (n,2).  n <= 256 per call. */
 int alink_smallres_forward(alink_smallres_t* m, const float* dev_L, const float* dev_R, int n, int prescale,
                            float* dev_probs, void* stream);
@@ -427,6 +428,9 @@ int alink_noise_uniform(const float* dev_in, float* dev_out, int64_t count, floa
  * code/siamese.py:146,153; TensorFlow draws them with an op-level generator that cannot be reproduced — only the keep
  * probability is contractual): dev_out[e] = 1 with probability `keep`, from the same (seed, element) Philox keying. */
 int alink_keep_masks(uint8_t* dev_out, int64_t count, float keep, uint64_t seed, void* stream);
+/* ... elements first, first + 1, ... of that stream of masks: a rank that trains rows lo : hi of a pair batch draws exactly the
+ * masks the whole-batch step draws for those rows (the data-parallel SmallRes step) */
+int alink_keep_masks_at(uint8_t* dev_out, int64_t count, float keep, uint64_t seed, uint64_t first, void* stream);
 /* noise.SaltPepper.addIndividualNoise (code/noise.py:54-65), tuple-index semantics: per image n_salt
  * elements (r,c,ch) <- 1 then n_pepper elements <- 0, r in [0,H-2], c in [0,W-2], ch in [0,C-2]. */
 int alink_noise_saltpepper(const float* dev_in, float* dev_out, int n_images, int H, int W, int C,

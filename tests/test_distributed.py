@@ -202,3 +202,138 @@ def test_world_size_8_gloo_short_and_empty_shards():
     assert len(res) == 8
     for r, ok in res:
         assert all(ok), (r, ok)
+
+
+# ---- the data-parallel step's control flow over the ORACLE's SmallRes arithmetic (world 2 and 3, gloo) -------------------------
+class _OracleSmallRes(object):
+    """oracle.smallres under the product's distributed.dp_train_on_batch: the four methods a model gives it (grads_tensor,
+    dp_begin, dp_local_grads, dp_apply) restated on the CPU — gradients of a slice with the global normaliser, dropout masks
+    drawn for the WHOLE batch from the step's seed and cut to the slice's rows, one flat buffer [params | 4 metric floats]"""
+    DP_SHARD_MIN_ROWS = 6
+
+    def __init__(self, ws, lr=0.1):
+        from oracle import smallres as OS
+        self.OS = OS
+        self.m = OS.SmallResModel(ws, lr=lr)
+        self.sizes = [int(np.prod(w.shape)) for w in self.m.ws]
+        self.flat = torch.zeros(sum(self.sizes) + 4, dtype=torch.float32)
+        self.shapes = ((7, 7, 32), (2, 2, 64))                  # 16 x 16 inputs: after pool 1 / pool 2
+        self.training_dropout = True
+
+    def _masks(self, n, seed):
+        e1, e2 = (int(np.prod(s)) for s in self.shapes)
+        return (np.random.RandomState(seed).rand(2 * n * e1 + 2 * n * e2) >= 0.25).astype(np.uint8)
+
+    def _rows(self, masks, n, lo, hi):
+        e1, e2 = (int(np.prod(s)) for s in self.shapes)
+        m1, m2 = masks[:2 * n * e1].reshape(2 * n, e1), masks[2 * n * e1:].reshape(2 * n, e2)
+        return np.concatenate([m1[lo:hi].ravel(), m1[n + lo:n + hi].ravel(), m2[lo:hi].ravel(), m2[n + lo:n + hi].ravel()])
+
+    def train_on_batch(self, x, y, class_weight=None, sample_weight=None):
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+        n = len(y)
+        out, _ = self.m.train_on_batch(x, y, sample_weight=sample_weight, masks=self._masks(n, seed), mask_shapes=self.shapes)
+        return out
+
+    def grads_tensor(self, with_metrics=False):
+        return self.flat if with_metrics else self.flat[:-4]
+
+    def dp_begin(self, n, group):
+        import torch.distributed as dist
+        box = [int(np.random.randint(0, 2 ** 31 - 1))]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return box[0]
+
+    def dp_local_grads(self, x, y, w_all, lo, hi, n, grad_scale, m, seed):
+        OS = self.OS
+        t = [torch.tensor(w, requires_grad=True) for w in self.m.ws]
+        p = OS.forward(t, x[0][lo:hi], x[1][lo:hi], self._rows(self._masks(n, seed), n, lo, hi), self.shapes)
+        yt = torch.as_tensor(np.asarray(y[lo:hi], np.float32))
+        pc = torch.clamp(p, 1e-7, 1 - 1e-7)
+        z = torch.log(pc / (1 - pc))
+        l = (torch.clamp(z, min=0) - z * yt + torch.log1p(torch.exp(-z.abs()))).mean(dim=1)
+        w = torch.ones(hi - lo) if w_all is None else torch.as_tensor(w_all[lo:hi])
+        loss = (l * w).sum() * grad_scale                       # this slice's share of the global weighted mean
+        loss.backward()
+        self.flat[:-4] = torch.cat([g.grad.reshape(-1) for g in t])
+        m[0] = float(loss.detach())
+        m[1] = float((torch.round(p.detach()) == yt).float().mean())
+
+    def dp_apply(self):
+        gs, o = [], 0
+        for w, k in zip(self.m.ws, self.sizes):
+            gs.append(self.flat[o:o + k].numpy().reshape(w.shape).copy())
+            o += k
+        self.m.ws = self.m.opt.step(self.m.ws, gs)
+
+
+def _oracle_smallres_weights(seed=0):
+    rs = np.random.RandomState(seed)
+    shapes = [(3, 3, 3, 32), (32,), (3, 3, 32, 32), (32,), (3, 3, 32, 64), (64,), (3, 3, 64, 64), (64,), (2 * 2 * 64, 24), (24,),
+              (24, 16), (16,), (16, 8), (8,), (8, 2), (2,)]
+    return [(rs.randn(*s) * (0.2 if len(s) > 1 else 0.01)).astype(np.float32) for s in shapes]
+
+
+def _smallres_dp_case():
+    rs = np.random.RandomState(4)
+    n = 7
+    L, R = rs.rand(n, 16, 16, 3).astype(np.float32), rs.rand(n, 16, 16, 3).astype(np.float32)
+    y = np.eye(2, dtype=np.float32)[rs.randint(0, 2, n)]
+    sw = np.ones(n, np.float32)
+    sw[1] = 0.0
+    sw[4] = 3.0
+    return L, R, y, sw
+
+
+def _smallres_dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import a_link_amd  # noqa: F401
+        from a_link_amd import distributed as D
+        L, R, y, sw = _smallres_dp_case()
+        net = _OracleSmallRes(_oracle_smallres_weights())
+        np.random.seed(3)
+        ms = [D.dp_train_on_batch(net, [L, R], y, sample_weight=sw, mode="auto", exchange="allreduce") for _ in range(2)]   # 7 rows >= 6: sharded
+        ms.append(D.dp_train_on_batch(net, [L[:2], R[:2]], y[:2], mode="sharded", exchange="host"))     # world 3: the last rank's shard is empty
+        ms.append(D.dp_train_on_batch(net, [L[:5], R[:5]], y[:5], mode="auto"))                          # 5 rows < 6: replicated
+        q.put((rank, np.concatenate([w.ravel() for w in net.m.ws]), np.asarray(ms, np.float64)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_smallres_dp_step_control_flow_over_gloo(world):
+    """distributed.dp_train_on_batch for an end-to-end model with dropout (reference code/siamese.py:134-170):
+    slices with the global normaliser, the slice's rows of the WHOLE batch's masks under rank 0's seed, one exchange of
+    [gradients | metrics], the same update everywhere — over the oracle's autograd arithmetic on 2 and 3 ranks: every rank
+    ends with the same weights, equal to the single-process steps to f64-level summation differences, with the same metrics;
+    a batch below the model's DP_SHARD_MIN_ROWS takes the replicated form."""
+    import socket
+    import torch.multiprocessing as mp
+    L, R, y, sw = _smallres_dp_case()
+    ref = _OracleSmallRes(_oracle_smallres_weights())
+    np.random.seed(3)
+    want_m = [ref.train_on_batch([L, R], y, sample_weight=sw) for _ in range(2)]
+    want_m.append(ref.train_on_batch([L[:2], R[:2]], y[:2]))
+    want_m.append(ref.train_on_batch([L[:5], R[:5]], y[:5]))
+    want_w = np.concatenate([w.ravel() for w in ref.m.ws])
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_smallres_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r, w, m in got:
+        assert np.array_equal(w, got[0][1]), r
+        assert np.abs(w - want_w).max() < 5e-6, (r, np.abs(w - want_w).max())
+        assert np.abs(m - np.asarray(want_m, np.float64)).max() < 2e-5, (r, m, want_m)      # f32 partial sums of a loss ~1.4 in a different order

@@ -589,3 +589,110 @@ def test_settled_pool_pass_survives_a_self_recalibration(gpu):
     want_v, want_i = D.committee_pool_topk(exa, heads, pd, gd, 48, shard_offset=0)           # all-exact under the scales it ended with
     assert [e.state()["scale_exponents"] for e in exa] == after
     assert torch.equal(i, want_i) and torch.equal(v, want_v)
+
+
+# ---- SmallRes data-parallel step ("all-reduce(sum) of head / SmallRes gradients") -----------------------------
+def _smallres_case():
+    rs = np.random.RandomState(3)
+    n = 9
+    L = ((rs.randint(0, 256, (n, 32, 32, 3)) - 128.0) / 128.0).astype(np.float32)
+    R = ((rs.randint(0, 256, (n, 32, 32, 3)) - 128.0) / 128.0).astype(np.float32)
+    y = np.eye(2, dtype=np.float32)[rs.randint(0, 2, n)]
+    sw = np.ones(n, np.float32)
+    sw[2] = 0.0
+    sw[5] = 2.5
+    return L, R, y, sw
+
+
+def _smallres_worker(rank, world, port, path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import a_link_amd  # noqa: F401
+        from a_link_amd import distributed as D
+        from a_link_amd.smallres import SmallResNet
+        L, R, y, sw = _smallres_case()
+        out = {}
+        for mode in ("sharded", "replicated", "sharded_nodrop"):
+            net = SmallResNet((32, 32, 3), 256, lr=0.1, seed=5, device=0)
+            net.training_dropout = mode != "sharded_nodrop"
+            np.random.seed(11)                                    # every rank holds the same host random state (alink_loop keeps it so)
+            ms = []
+            for step in range(3):
+                ms.append(D.dp_train_on_batch(net, [L, R], y, sample_weight=sw, mode=mode.split("_")[0], exchange="host"))
+            ms.append(D.dp_train_on_batch(net, [L[:1], R[:1]], y[:1], mode=mode.split("_")[0], exchange="host"))     # rank 1's shard is empty
+            out[mode + "_w"] = np.concatenate([w.ravel() for w in net.get_weights()])
+            out[mode + "_m"] = np.asarray(ms, np.float64)
+        np.savez(path % rank, **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_smallres_sharded_step_world_size_2(gpu, tmp_path):
+    """distributed.dp_train_on_batch on the end-to-end SmallRes student (reference code/siamese.py:134-170, trained by
+    code/ALINK_MTP.py:121,255) with TWO ranks sharing cuda:0 (gloo carries the 2.4 MB exchange at feat = 256): each rank
+    runs forward + backward on ITS rows with the global normaliser and the dropout masks of its GLOBAL rows, the flat
+    [tower | head] gradient buffers are summed, both ranks apply the same Adadelta update.  9 pairs (rank 0: 5, rank 1: 4)
+    with a zero and a 2.5 sample weight, three steps, then a 1-pair batch (rank 1's shard empty).  Sharded = the
+    single-process steps to f32 summation order (weights 2e-6, metrics 2e-6) with dropout ON — which proves the masks of a
+    slice are the whole batch's masks for those rows; replicated = the single-process steps bit for bit; both ranks end
+    with the same bits."""
+    import socket
+    import torch.multiprocessing as mp
+    from a_link_amd.smallres import SmallResNet
+    L, R, y, sw = _smallres_case()
+    want = {}
+    for drop in (True, False):
+        net = SmallResNet((32, 32, 3), 256, lr=0.1, seed=5, device=0)
+        net.training_dropout = drop
+        np.random.seed(11)
+        ms = [net.train_on_batch([L, R], y, sample_weight=sw) for _ in range(3)]
+        ms.append(net.train_on_batch([L[:1], R[:1]], y[:1]))
+        want[drop] = (np.concatenate([w.ravel() for w in net.get_weights()]), np.asarray(ms, np.float64))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    path = str(tmp_path / "sr%d.npz")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_smallres_worker, args=(r, 2, port, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    z = [np.load(path % r) for r in range(2)]
+    for mode, drop, tol in (("sharded", True, 2e-6), ("replicated", True, 0.0), ("sharded_nodrop", False, 2e-6)):
+        assert np.array_equal(z[0][mode + "_w"], z[1][mode + "_w"]), mode                  # the ranks agree to the bit
+        for r in range(2):
+            dw = np.abs(z[r][mode + "_w"] - want[drop][0]).max()
+            dm = np.abs(z[r][mode + "_m"] - want[drop][1]).max()
+            assert dw <= tol and dm <= max(tol, 0.0 if tol == 0.0 else 2e-6), (mode, r, dw, dm)
+
+
+def test_smallres_masks_of_a_slice_are_the_batch_masks_of_its_rows(gpu):
+    """SmallResNet._masks_of_rows (alink_keep_masks_at): the keep-masks a rank draws for pair rows lo : hi of an n-pair batch
+    are, element for element, what train_on_batch's one stream of 2n(e1 + e2) masks holds for those rows — for slices that
+    start at any row, an empty one, and a first element that is no multiple of 4 (the Philox block size)."""
+    from a_link_amd.smallres import SmallResNet
+    net = SmallResNet((20, 20, 3), 64, lr=0.1, seed=1, device=0)          # e1 = 9*9*32, e2 = 3*3*64: odd multiples
+    e1, e2 = net.mask_sizes
+    lib = gpu.load()
+    n, seed = 7, 12345
+    whole = torch.empty(2 * n * (e1 + e2), dtype=torch.uint8, device="cuda")
+    gpu.check(lib.alink_keep_masks(gpu.ptr(whole), whole.numel(), 0.75, seed, None))
+    w = whole.cpu().numpy()
+    m1, m2 = w[:2 * n * e1].reshape(2 * n, e1), w[2 * n * e1:].reshape(2 * n, e2)
+    assert 0.70 < w.mean() < 0.80
+    for lo, hi in ((0, 7), (0, 3), (3, 7), (2, 3), (6, 7)):
+        got = net._masks_of_rows(lo, hi, n, seed).cpu().numpy()
+        k = hi - lo
+        want = np.concatenate([m1[lo:hi].ravel(), m1[n + lo:n + hi].ravel(), m2[lo:hi].ravel(), m2[n + lo:n + hi].ravel()])
+        assert got.shape == want.shape == (2 * k * (e1 + e2),) and np.array_equal(got, want), (lo, hi)
+    # an unaligned first element on its own
+    part = torch.empty(1001, dtype=torch.uint8, device="cuda")
+    gpu.check(lib.alink_keep_masks_at(gpu.ptr(part), 1001, 0.75, seed, 4321 + 2, None))
+    assert np.array_equal(part.cpu().numpy(), w[4323:4323 + 1001])
