@@ -51,8 +51,12 @@ class Flags(object):
     blind_strategy = False
     # not a flag of the reference: embed the noisy pair occurrences (2 P n_noise images per iteration, the bulk of its
     # work) in the feature model's 16-bit SCREENING mode and re-embed in the exact mode only the pairs whose side of a
-    # cut is uncertain (settle.py) — same query set, same fine-tune data; needs a feature model with `process_screen`
-    screen_settle = True
+    # cut is uncertain (settle.py); needs a feature model with `process_screen`.  OFF by default (round 6): the reference's
+    # semantics are exact (every embedding in one arithmetic, code/ALINK_arc.py:154-167) and so is the default here;
+    # --screen_settle buys ~2.2x on an iteration under a MEASURED and sample-audited error bound — the same query set and
+    # fine-tune data on every workload measured, a statistical guarantee, not a theorem.  When it is on the
+    # loop prints each iteration's audit.
+    screen_settle = False
     # not a flag of the reference: keyword options for settle.select_queries_settled (safety, delta0, min_sample, audit, ...)
     settle_options = None
 
@@ -218,7 +222,7 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
         full = shards.all_rows(np.stack(local_preds, axis=1))             # (P, n_noise, C)
         return [np.ascontiguousarray(full[:, jj]) for jj in range(n_noise)]
 
-    if noisy_for_student_screen is not None and getattr(flags, "screen_settle", True):
+    if noisy_for_student_screen is not None and getattr(flags, "screen_settle", False):
         from . import settle
         pixels = noisy_data
         noisy_data = [[noisy_for_student_screen(p) for p in part] for part in pixels]
@@ -264,6 +268,12 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
         if shards is not None:
             info = dict(info, rank=shards.rank, world=shards.world, rows_of_this_rank=hi - lo)
         state.settle_info.append(info)
+        if verbose:
+            aud = info.get("audit") or {}
+            print("screen-then-settle: %.1f %% of the (pair, noise) rows re-embedded exactly, error bound %.2e; audit: %s sampled, "
+                  "largest error seen %s, %s beyond the bound%s" % (100.0 * info.get("fraction_settled", 0.0), info.get("delta", float("nan")),
+                                                                     aud.get("m", 0), aud.get("max_err", "n/a"), aud.get("exceedances", "n/a"),
+                                                                     " (bound widened, pass repeated)" if info.get("widened") else ""))
     else:
         noisy_data = [[noisy_for_student(p) for p in part] for part in noisy_data]
         disguisedPredictions = all_noises([predict_rows([noisy_data[0][jj], noisy_data[1][jj]]) for jj in range(n_noise)])

@@ -331,6 +331,52 @@ def _committee_pool_topk_settled(screen_backbones, exact_backbones, heads, pool_
     return torch.from_numpy(np.ascontiguousarray(vals)).to(out_dev), torch.from_numpy(np.ascontiguousarray(gidx)).to(out_dev)
 
 
+_PLACEMENT_CHECKED = set()
+_PLACEMENT_CALLS = [0]           # collective call counter: a generation in the store keys (no rank reads an earlier check's entry)
+
+
+def check_rank_placement(group=None, identity=None):
+    """One process per GPU means ONE: a caller that forgets torch.cuda.set_device(LOCAL_RANK) puts every rank on cuda:0, and RCCL
+    then fails late (or hangs) inside the first collective.  Under the "nccl" backend every rank publishes (hostname, current
+    device) and ALL ranks raise the same error when two of them share a device — before any collective touches the card.  The
+    identities travel through the job's rendezvous store where there is one (no communicator involved), else through
+    all_gather_object.  Once per (group, world size); a no-op under "gloo" (CPU tests, two test processes sharing a card) unless
+    `identity` is given."""
+    dist = _dist()
+    world = dist.get_world_size(group)
+    if identity is None:
+        if dist.get_backend(group) != "nccl":
+            return
+        import socket
+        import torch
+        identity = (socket.gethostname(), int(torch.cuda.current_device()))
+    key = (id(group) if group is not None else None, world)
+    if key in _PLACEMENT_CHECKED:
+        return
+    rank = dist.get_rank(group)
+    _PLACEMENT_CALLS[0] += 1
+    gen = _PLACEMENT_CALLS[0]
+    every = None
+    if group is None or group is getattr(dist.group, "WORLD", None):
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            store.set("alink_placement/%d/%d" % (gen, rank), "%s\t%s" % (identity[0], identity[1]))
+            every = [tuple(store.get("alink_placement/%d/%d" % (gen, r)).decode().split("\t")) for r in range(world)]
+        except Exception:
+            every = None
+    if every is None:
+        every = [None] * world
+        dist.all_gather_object(every, (str(identity[0]), str(identity[1])), group=group)
+    seen = {}
+    for r, ident in enumerate(every):
+        seen.setdefault((str(ident[0]), str(ident[1])), []).append(r)
+    shared = sorted((k, v) for k, v in seen.items() if len(v) > 1)
+    if shared:
+        raise RuntimeError("one process per GPU: " + "; ".join("ranks %s are all on device %s of host %s" % (v, k[1], k[0]) for k, v in shared)
+                           + " — call torch.cuda.set_device(LOCAL_RANK) before building models or groups")
+    _PLACEMENT_CHECKED.add(key)
+
+
 class RowShards(object):
     """P rows (the pairs of one A-LINK mini-batch) split contiguously over the ranks of `group` (shard_range).  Every
     method is a collective: all ranks call it with the same global arguments.  Payloads are small (predictions: 8 B per
@@ -343,6 +389,7 @@ class RowShards(object):
         self.torch, self.dist, self.group = torch, dist, group
         self.P = int(P)
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        check_rank_placement(group)                          # nccl: two ranks on one device raise here, on every rank
         self.ranges = [shard_range(self.P, r, self.world) for r in range(self.world)]
         self.lo, self.hi = self.ranges[self.rank]
         self.device = "cuda:%d" % torch.cuda.current_device() if dist.get_backend(group) == "nccl" else "cpu"

@@ -113,6 +113,8 @@ class DistComm(object):
         self.torch, self.dist, self.group = torch, dist, group
         self.world = dist.get_world_size(group)
         if device is None:
+            from . import distributed as _D
+            _D.check_rank_placement(group)                   # nccl: two ranks on one device raise here, on every rank
             device = "cuda:%d" % torch.cuda.current_device() if dist.get_backend(group) == "nccl" else "cpu"
         self.device = device
 

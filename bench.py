@@ -172,6 +172,9 @@ def _preflight(dist, rank, world, local_rank, quiet=False):
             step["name"] = "no process group (one process): nothing to exchange"
         else:
             g = dist.group.WORLD
+            step["name"] = "rank placement (one process per GPU)"
+            D.check_rank_placement(g)                        # two ranks on one device: every rank raises, before any collective
+            ok.append("placement")
             step["name"] = "all_reduce of a known vector"
             t = torch.arange(4, dtype=torch.float64, device="cuda") + rank
             dist.all_reduce(t)

@@ -337,3 +337,57 @@ def test_smallres_dp_step_control_flow_over_gloo(world):
         assert np.array_equal(w, got[0][1]), r
         assert np.abs(w - want_w).max() < 5e-6, (r, np.abs(w - want_w).max())
         assert np.abs(m - np.asarray(want_m, np.float64)).max() < 2e-5, (r, m, want_m)      # f32 partial sums of a loss ~1.4 in a different order
+
+
+# ---- rank placement: two ranks on one device must fail fast, on every rank -------------------------------
+def _placement_worker(rank, world, port, q, identities):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import a_link_amd  # noqa: F401
+        from a_link_amd import distributed as D
+        out = []
+        for ident in identities:
+            try:
+                D.check_rank_placement(None, identity=ident[rank])
+                out.append("ok")
+            except RuntimeError as e:
+                out.append(str(e))
+            D._PLACEMENT_CHECKED.clear()
+            dist.barrier()
+        # under gloo (no identity given) the check is a no-op: RowShards builds
+        D.RowShards(5)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_device_raise_on_every_rank():
+    """distributed.check_rank_placement: every rank publishes (host, device); two ranks on the same device make ALL ranks raise
+    the same message naming them (a forgotten torch.cuda.set_device(LOCAL_RANK) otherwise shows up as an RCCL hang much
+    later); distinct devices, or the same device index on different hosts, pass.  Here over gloo with faked identities."""
+    import socket
+    import torch.multiprocessing as mp
+    world = 3
+    cases = [[("hostA", 0), ("hostA", 1), ("hostA", 2)],          # fine
+             [("hostA", 0), ("hostA", 1), ("hostA", 0)],          # ranks 0 and 2 share cuda:0
+             [("hostA", 0), ("hostB", 0), ("hostC", 0)]]          # device 0 of three hosts: fine
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_placement_worker, args=(r, world, port, q, cases)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r][0] == "ok" and got[r][2] == "ok", got[r]
+        assert "ranks [0, 2] are all on device 0 of host hostA" in got[r][1] and "set_device" in got[r][1], got[r][1]
+    assert got[0][1] == got[1][1] == got[2][1]

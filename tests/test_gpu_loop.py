@@ -80,9 +80,12 @@ def _literal_loop(flags, conv, bag, nz, student, X_plain_raw, X_dig_post, dataGe
 
 @pytest.mark.parametrize("col", [0, 1])
 def test_loop_equals_reference_shaped_loop(gpu, col, tmp_path):
+    """the library loop with DEFAULT flags (every embedding exact: the reference's semantics, Flags.screen_settle = False since
+    round 6) against a literal restatement of code/ALINK_arc.py:142-254"""
     from a_link_amd import alink_loop as AL, pairs
     flags = AL.Flags(alink_bs=3, batch_send=6, disparity_ratio=0.6, eps=0.0005, ft_epochs=2, mixture_ratio=2,
                      out_model=str(tmp_path / "post"))
+    assert flags.screen_settle is False
     X_plain, X_dig = _people(6, 1), _people(6, 2)
     results = []
     for which in ("library", "literal"):
@@ -92,8 +95,8 @@ def test_loop_equals_reference_shaped_loop(gpu, col, tmp_path):
                                  pairs.getImposterGenerator(feats_plain, feats_plain, 8), 8)
         np.random.seed(5)                                      # balanced sampling + fit() shuffles
         if which == "library":
-            # the library loop on a default-built ArcFace goes through screen-then-settle (its feature model carries a screening
-            # form): the literal loop below embeds everything exactly — equal results are the point
+            # (a default-built ArcFace carries a screening form, but the loop only uses it under flags.screen_settle: the spy on
+            # select_queries_settled must stay silent here)
             from a_link_amd import settle
             sets = []
             orig, orig_s = AL.selection.select_queries, settle.select_queries_settled
@@ -112,7 +115,7 @@ def test_loop_equals_reference_shaped_loop(gpu, col, tmp_path):
                 st = AL.run_alink_dfw(flags, conv, bag, nz, student, X_plain, X_dig, gen, SIZE, col=col, verbose=0)
             finally:
                 AL.selection.select_queries, settle.select_queries_settled = orig, orig_s
-            assert st.settle_info, "the default feature model should have taken the screen-then-settle path"
+            assert not st.settle_info, "default flags must take the all-exact path"
             results.append((st.active_count, st.un_size, sets, st.finetunes, student.siamese_net.get_weights()))
             assert (tmp_path / "post.h5").exists()
         else:
