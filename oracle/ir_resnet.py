@@ -97,8 +97,11 @@ def forward_raw(params, pixels_nchw, dtype=torch.float32, taps=None):
 def l2_normalize(e):
     """sklearn.preprocessing.normalize(X) (l2, axis=1): rows divided by their norm, zero norms -> 1
     (reference code/face_model.py:92)."""
+    # sklearn's own arithmetic (sklearn/preprocessing/_data.py normalize -> utils.extmath.row_norms): squared norms by einsum IN
+    # THE INPUT'S DTYPE, square root, zeros replaced by 1 — so that a float32 row whose squares underflow is left alone exactly
+    # where sklearn leaves it alone (checked against sklearn itself: tests/test_oracle_sklearn_pins.py)
     e = np.asarray(e)
-    n = np.sqrt((e.astype(np.float64) ** 2).sum(axis=1)).astype(e.dtype)
+    n = np.sqrt(np.einsum("ij,ij->i", e, e))
     n[n == 0] = 1
     return e / n[:, None]
 

@@ -622,3 +622,24 @@ def test_compile_time_epilogues_are_bit_identical_to_the_generic_one(gpu, dtype)
         finally:
             lib.alink_debug_set_generic_epilogue(0)
         assert torch.isfinite(fixed).all() and torch.equal(fixed, generic), (dtype, n, (fixed - generic).abs().max().item())
+
+
+def test_l2_epilogue_equals_sklearn_normalize(gpu):
+    """The reference's literal call after the forward is sklearn.preprocessing.normalize(embedding) (code/face_model.py:92;
+    sklearn IS installed here).  The product normalises in the FC-finish kernel: its embeddings must equal sklearn's
+    normalisation of the oracle's RAW fc1 output (f32 mode: 2e-6 — the exact mode's bar) and be fixed points of it."""
+    preprocessing = pytest.importorskip("sklearn.preprocessing")
+    from a_link_amd import weights as W
+    from a_link_amd.backbone import IRBackbone
+    from oracle import ir_resnet
+    size = (32, 32)
+    params = W.synthetic_ir_params((1, 2, 1, 1), size=size, seed=3)
+    x = _pixels(6, size, seed=2)
+    with torch.no_grad():
+        raw = ir_resnet.forward_raw(params, np.transpose(x, (0, 3, 1, 2))).numpy()
+    want = preprocessing.normalize(raw)                                   # the dependency itself, on the raw features
+    for dt, tol in (("f32", 2e-6), ("f16x2", 1e-5)):
+        got = IRBackbone(params, image_size=size, max_batch=8, dtype=dt).embed(x)
+        assert np.abs(got - want).max() < tol, (dt, np.abs(got - want).max())
+        np.testing.assert_allclose(preprocessing.normalize(got), got, rtol=0, atol=2e-7)     # already unit rows
+        np.testing.assert_allclose(np.linalg.norm(got.astype(np.float64), axis=1), 1.0, atol=3e-7)
