@@ -121,6 +121,12 @@ def _set_rows(a, idx, v):
         a[np.asarray(idx, np.int64)] = _np(v)
 
 
+class Recalibrated(RuntimeError):
+    """raised by alink_iteration(group=...) on EVERY rank when some rank's feature model re-calibrated its split-precision
+    scales during the iteration: the iteration's counters are rolled back; run_alink_dfw merges the scales
+    (distributed.merge_calibration) and runs the iteration once more under them"""
+
+
 def sync_host_randomness(ensembleNoise, shards):
     """Make rank 0's host-side random state every rank's: NumPy's global stream (the balanced generator's sampling,
     fit()'s shuffles and SmallRes' dropout masks draw from it, as the reference's do: SURVEY.md §5) and the stream
@@ -202,12 +208,38 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
     m1_labels = np.argmax(ensemblePredictions, axis=1)
     if labels_one_hot:                      # ALINK_MTP.py:174 passes keras.utils.to_categorical(..., 2)
         m1_labels = helpers.one_hot(m1_labels, 2)
+    # With ranks, whatever THIS rank does between two exchanges may fail on this rank alone — a Poisson lam < 0 in its rows, a
+    # 16-bit screening forward that leaves its range, an out-of-memory — while its peers are on their way into the next
+    # all-gather.  Every such phase runs under `guard`: a failure is recorded with the shards (RowShards.fail), the phase
+    # yields None, the rank feeds zeros of the right shape into the exchange, and EVERY rank raises there together
+    # (until then only the settle requests were covered and the peers of a failed rank blocked in the collective).
+    broken = []
+
+    def guard(fn):
+        if shards is None:
+            return fn()
+        if broken:
+            return None
+        try:
+            return fn()
+        except Exception as exc:
+            shards.fail("%s: %s" % (type(exc).__name__, exc))
+            broken.append(exc)
+            return None
+
     if shards is not None:
-        noisy_data = bag.attackModel(local_x, image_res, m1_labels[lo:hi], rows=(lo, P))
+        noisy_data = guard(lambda: bag.attackModel(local_x, image_res, m1_labels[lo:hi], rows=(lo, P)))
     else:
         noisy_data = bag.attackModel(local_x, image_res, m1_labels)
     n_noise = len(ensembleNoise)
     pred_shape = ensemblePredictions.shape[1:]
+
+    def convert(fn, p):
+        """what the student consumes for this rank's noisy rows; an empty shard converts nothing (the feature model is not
+        called on a (0, H, W, 3) batch) and yields an empty array shaped like the clean inputs' rows"""
+        if len(p) == 0:
+            return np.zeros((0,) + tuple(_np(clean_for_student[0][:1]).shape[1:]), _np(clean_for_student[0][:1]).dtype)
+        return fn(p)
 
     def predict_rows(sides):
         """the student's predictions for rows this rank holds (an empty shard predicts nothing)"""
@@ -225,9 +257,12 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
     if noisy_for_student_screen is not None and getattr(flags, "screen_settle", False):
         from . import settle
         pixels = noisy_data
-        noisy_data = [[noisy_for_student_screen(p) for p in part] for part in pixels]
-        noisy_data = [[f.clone() if hasattr(f, "detach") else np.array(f, copy=True) for f in part] for part in noisy_data]
-        screened = all_noises([predict_rows([noisy_data[0][jj], noisy_data[1][jj]]) for jj in range(n_noise)])
+        noisy_data = guard(lambda: [[convert(noisy_for_student_screen, p) for p in part] for part in pixels])
+        noisy_data = guard(lambda: [[f.clone() if hasattr(f, "detach") else np.array(f, copy=True) for f in part] for part in noisy_data])
+        local_preds = guard(lambda: [predict_rows([noisy_data[0][jj], noisy_data[1][jj]]) for jj in range(n_noise)])
+        if local_preds is None:                # this rank failed above: zeros into the exchange, where every rank raises
+            local_preds = [np.zeros((hi - lo,) + tuple(pred_shape), np.float32) for _ in range(n_noise)]
+        screened = all_noises(local_preds)
 
         def settle_many(requests):
             """a round's requests [(noise, pairs)]: both sides of every request converted in ONE exact call — by the
@@ -275,14 +310,28 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
                                                                      aud.get("m", 0), aud.get("max_err", "n/a"), aud.get("exceedances", "n/a"),
                                                                      " (bound widened, pass repeated)" if info.get("widened") else ""))
     else:
-        noisy_data = [[noisy_for_student(p) for p in part] for part in noisy_data]
-        disguisedPredictions = all_noises([predict_rows([noisy_data[0][jj], noisy_data[1][jj]]) for jj in range(n_noise)])
+        if shards is None:
+            noisy_data = [[convert(noisy_for_student, p) for p in part] for part in noisy_data]
+            local_preds = [predict_rows([noisy_data[0][jj], noisy_data[1][jj]]) for jj in range(n_noise)]
+        else:
+            pixels = noisy_data
+            noisy_data = guard(lambda: [[convert(noisy_for_student, p) for p in part] for part in pixels])
+            local_preds = guard(lambda: [predict_rows([noisy_data[0][jj], noisy_data[1][jj]]) for jj in range(n_noise)])
+            if local_preds is None:
+                local_preds = [np.zeros((hi - lo,) + tuple(pred_shape), np.float32) for _ in range(n_noise)]
+        disguisedPredictions = all_noises(local_preds)
         queryIndices, active, labels = selection.select_queries(
             ensemblePredictions, disguisedPredictions, batch_y, col=col, disparity_ratio=flags.disparity_ratio,
             eps=flags.eps, blind_strategy=flags.blind_strategy)
     if shards is not None and calibration_of is not None:
         if not shards.all_true(calibration_of() == cal0):
-            raise RuntimeError("alink_iteration: a rank's feature model re-calibrated itself during the iteration (a batch left the "
+            # nothing of this iteration has been committed yet beyond these three: rolled back, so that the caller can merge the
+            # ranks' scales and run it again (run_alink_dfw does, once)
+            state.iterations -= 1
+            state.un_size -= P
+            if noisy_for_student_screen is not None and getattr(flags, "screen_settle", False):
+                state.settle_info.pop()
+            raise Recalibrated("alink_iteration: a rank's feature model re-calibrated itself during the iteration (a batch left the "
                                "split-precision range): ranks no longer embed to the same bits.  Calibrate on noisy images like "
                                "these first, then distributed.broadcast_calibration()")
     elif calibration_of is not None and calibration_of() != cal0:
@@ -303,9 +352,11 @@ def alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensem
     else:
         # chunk i of the query list takes noise i's rows (code/ALINK_arc.py:213-222): gathered from the ranks that own them
         row_shape = tuple(_np(clean_for_student[0][:1]).shape[1:])
-        got = shards.subsets(chunks + chunks,
-                             [_np(_rows(noisy_data[s][i], shards.owned(chunks[i]))) for s in (0, 1) for i in range(n_noise)],
-                             row_shape, _np(clean_for_student[0][:1]).dtype)
+        mine_rows = guard(lambda: [_np(_rows(noisy_data[s][i], shards.owned(chunks[i]))) for s in (0, 1) for i in range(n_noise)])
+        if mine_rows is None:
+            mine_rows = [np.zeros((len(shards.owned(chunks[i])),) + tuple(row_shape), _np(clean_for_student[0][:1]).dtype)
+                         for s in (0, 1) for i in range(n_noise)]
+        got = shards.subsets(chunks + chunks, mine_rows, row_shape, _np(clean_for_student[0][:1]).dtype)
         noisy_left, noisy_right = got[:n_noise], got[n_noise:]
     state.left = _concat(state.left, noisy_left)
     state.right = _concat(state.right, noisy_right)
@@ -392,11 +443,34 @@ def run_alink_dfw(flags, conversionModel, bag, ensembleNoise, disguisedFacesMode
         else:
             batch_x = [unique[li], unique[ri]]
         batch_x_features = [feats[li], feats[ri]]
-        added = alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensembleNoise,
-                                disguisedFacesModel, dataGen, noisy_for_student=conversionModel.process,
-                                clean_for_student=batch_x_features, image_res=image_res, col=col, verbose=verbose,
-                                noisy_for_student_screen=getattr(conversionModel, "process_screen", None),
-                                group=group, batch_x_rows=rows, calibration_of=_calibration_probe(conversionModel))
+        probe = _calibration_probe(conversionModel)
+        streams = [z.stream_state() if hasattr(z, "stream_state") else None for z in ensembleNoise]
+        host_rng = np.random.get_state()
+        for attempt in (0, 1):
+            try:
+                added = alink_iteration(state, flags, batch_x, batch_y, batch_x_features, bag, ensembleNoise,
+                                        disguisedFacesModel, dataGen, noisy_for_student=conversionModel.process,
+                                        clean_for_student=batch_x_features, image_res=image_res, col=col, verbose=verbose,
+                                        noisy_for_student_screen=getattr(conversionModel, "process_screen", None),
+                                        group=group, batch_x_rows=rows, calibration_of=probe)
+                break
+            except Recalibrated:
+                #  noisy images left the calibrated range on some rank, which lowered ITS scales: every rank takes
+                # the elementwise minimum (distributed.merge_calibration, what committee_pool_topk_settled does), the
+                # iteration's random streams are wound back, the clean pass is embedded again under the merged scales and
+                # the iteration runs once more; a second change raises
+                if attempt or group is None:
+                    raise
+                _D.merge_calibration([conversionModel.model.model], group=group)
+                state.recalibrations += 1
+                log("note: a rank re-calibrated its split-precision scales; scales merged over the ranks, iteration repeated")
+                np.random.set_state(host_rng)
+                for z, st in zip(ensembleNoise, streams):
+                    if st is not None and hasattr(z, "set_stream_state"):
+                        z.set_stream_state(st)
+                unique, li, ri, batch_y, feats = _embed_pairs_unique(conversionModel, plain_part, disguise_part, on_device)
+                batch_x = [unique[li[rows[0]:rows[1]]], unique[ri[rows[0]:rows[1]]]]
+                batch_x_features = [feats[li], feats[ri]]
         if added < 0:
             continue
         if int(flags.active_ratio * state.un_size) <= state.active_count:

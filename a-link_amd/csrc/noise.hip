@@ -295,7 +295,11 @@ __global__ __launch_bounds__(1024) void unique_count_kernel(const UniqueP p) {
                 const unsigned int key = float_key(src[i]);
                 const unsigned int h = key * 2654435761u;
                 if ((int)(h >> (32 - p.parts_log2 - 1) >> 1) != part && p.parts_log2) continue;      // top parts_log2 bits
-                unsigned int slot = (h >> 2) & (kHashSlots - 1);
+                // the slot comes from the 15 bits just BELOW the part bits: the high bits of a multiplicative hash depend on every
+                // key bit.  (Until round 6: (h >> 2) & 32767 — bits 2..16 of the product, which only key bits 0..16 reach: float
+                // patterns with short mantissas — quarter steps, bf16 / f16-rounded pixels — all landed in a handful of home
+                // slots and linear probing degenerated into thousands of contended atomicCAS per element)
+                unsigned int slot = (h >> (32 - p.parts_log2 - 15)) & (kHashSlots - 1);
                 for (unsigned int probes = 0;; ++probes) {
                     const unsigned int old = atomicCAS(&tab[slot], kEmpty, key);
                     if (old == kEmpty) { ++mine; break; }

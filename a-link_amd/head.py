@@ -383,6 +383,9 @@ class DenseHead(KerasFitMixin):
         bs = int(batch_size)
         if self.dp_group is not None and not (self.dp_mode == "replicated" or (self.dp_mode == "auto" and bs < _D.DP_SHARD_MIN_ROWS)):
             return super(DenseHead, self).fit(x, y, batch_size, epochs, verbose, callbacks, validation_split, shuffle)
+        if type(self).train_on_batch is not DenseHead.train_on_batch or type(self).test_on_batch is not DenseHead.test_on_batch:
+            # a subclass (or an instrumented copy) that overrides a step must see every step: the generic form calls them
+            return super(DenseHead, self).fit(x, y, batch_size, epochs, verbose, callbacks, validation_split, shuffle)
         torch = self.torch
         L, R, Y = self._dev(x[0]), self._dev(x[1]), self._dev(np.asarray(y, dtype=np.float32) if not isinstance(y, torch.Tensor) else y)
         n_all = L.shape[0]
@@ -412,22 +415,21 @@ class DenseHead(KerasFitMixin):
                     index_array = np.array(box[0])
             idx = torch.from_numpy(index_array).to(self.device)
             M = torch.zeros((len(starts) + len(vstarts), 4), dtype=torch.float32, device=self.device)
-            keep = []                                             # the step's operands must outlive its launch
+            # (a step's gathered operands need no pinning: torch's allocator is stream-ordered, and everything here runs on ONE
+            # stream — a block freed by Python is reused only by work queued behind the launch that reads it; ADVICE r5: the
+            # list kept here until round 6 held a second copy of the training set per epoch)
             for k, s0 in enumerate(starts):
                 ids = idx[s0:s0 + bs]
                 Lb, Rb, Yb = L.index_select(0, ids), R.index_select(0, ids), Y.index_select(0, ids)
-                keep.append((Lb, Rb, Yb))
                 rc = self.lib.alink_head_train_step(self.h, Lb.data_ptr(), Rb.data_ptr(), Yb.data_ptr(), None, Lb.shape[0], 0.0, 1,
                                                     M[k].data_ptr(), st.cuda_stream)
                 if rc:
                     _abi.check(rc, "alink_head_train_step")
             for k, s0 in enumerate(vstarts):
                 a, b, c = vL[s0:s0 + bs].contiguous(), vR[s0:s0 + bs].contiguous(), vY[s0:s0 + bs].contiguous()
-                keep.append((a, b, c))
                 _abi.check(self.lib.alink_head_eval(self.h, _abi.ptr(a), _abi.ptr(b), _abi.ptr(c), a.shape[0],
                                                     C.c_void_p(M[len(starts) + k].data_ptr()), C.c_void_p(st.cuda_stream)), "alink_head_eval")
             m = M.cpu().numpy().astype(np.float64)                # one read-back (and synchronisation) per epoch
-            del keep
             tr = m[:len(starts), :2]
             # the same accumulation as the step-by-step form: sum of per-step value x size, in step order
             tot = np.zeros(2)

@@ -208,8 +208,15 @@ def resize_images(images, new_size, device=None):
     """cv2.resize(image, new_size) per image (code/committee.py:22-26; readMTP.resizeImages,
     code/readMTP.py:116-119): new_size = (width, height), bilinear."""
     import torch
-    if len(images) == 0:                  # an empty shard (more ranks than pairs): nothing to resize, the container stays what it was
-        return images if hasattr(images, "detach") else np.array(images)
+    if len(images) == 0:
+        # an empty shard (more ranks than pairs): nothing to resize — but the result has the shape its peers' shards have,
+        # (0, height, width, C), whatever noise produced the empty input (ADVICE r5: some returned [] -> shape (0,))
+        Wo, Ho = int(new_size[0]), int(new_size[1])
+        if hasattr(images, "detach"):
+            ch = images.shape[-1] if images.dim() == 4 else 3
+            return images.new_zeros((0, Ho, Wo, ch), dtype=torch.float32)
+        a = np.asarray(images)
+        return np.zeros((0, Ho, Wo, a.shape[-1] if a.ndim == 4 else 3), np.float32)
     device = _abi.resolve_device(device)
     x, as_torch = _as_device(images if not isinstance(images, (list, tuple)) else np.stack(images), device)
     n, H, W, Cc = x.shape
@@ -265,8 +272,8 @@ class AdversarialNoise(Noise):
         first = 0 if rows is None else int(rows[0])
         base = self._next_seed()
         n = len(image_pairs[0])
-        if n == 0:
-            return [[], []]
+        if n == 0:                                  # an empty shard: empty sides of the input's own shape (and container kind)
+            return [image_pairs[0], image_pairs[1]]
         image_pairs = [p.detach().cpu().numpy() if hasattr(p, "detach") else p for p in image_pairs]
         concat_data = [np.concatenate((image_pairs[0][i], image_pairs[1][i]), axis=0) for i in range(n)]
         img_shape = image_pairs[0][0].shape

@@ -385,6 +385,12 @@ def main():
         "value": emb_per_s, "unit": "embeddings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
+        # what a reader of `value` alone must know: the two at-reference-precision rates are value_exact and
+        # value_identical_selection below, filled in by their legs
+        "dtype_note": ("bf16 < reference f32; within 1e-3 cosine, not selection-identical" if args.dtype == "bf16" else
+                       "f16 < reference f32; within 1e-3 cosine, not selection-identical" if args.dtype == "f16" else
+                       "the reference's float32 accuracy (selection-identical)"),
+        "value_exact": None, "value_identical_selection": None,
         "config": {"workload": "LResNet%sE-IR embed, %d x 3x112x112 images per step per GPU (as %d-image launches "
                                "round-robin on %d streams), %s pixels resident in HBM"
                                % (args.model[1:], B, args.chunk, args.streams, args.input),
@@ -574,6 +580,8 @@ def main():
             "max_abs_diff_vs_headline_dtype": float((sel_out - out).abs().max()),
             "note": "selection sets identical to the f32 oracle's: tests/test_gpu_pool.py (config 3: 0 of 1,024 differ; config 4: "
                     "both columns equal at IR-50 and IR-100 depth)"}
+        line["value_exact"] = {"embeddings_per_s": sel_rate, "dtype": args.select_dtype, "same_workload_as_value": True,
+                               "note": "every image in the mode whose embeddings equal the f32 oracle's to float32 accuracy (exact_selection)"}
         if rank == 0 and not args.no_extras and args.select_dtype == "f16x2":
             # the exact mode's own dominant kernel: algorithmic fraction, issued fraction (3 MFMA FLOPs per algorithmic FLOP), traffic
             line["exact_selection"]["roofline"] = roofline_of(bs, "f16x2")
@@ -867,7 +875,14 @@ def main():
                                   "identical_to_exact_all": bool(same4),
                                   "identical_means": "oracle-query count, number of fine-tunes and the student's weights afterwards equal the all-exact iteration's bit for bit (compared in this run)"},
                 "oracle_queries": st_e.active_count, "finetunes": st_e.finetunes,
+                # which form the fine-tune's steps took: distributed.dp_train_on_batch in mode "auto"
+                "finetune_steps": {"rows_per_step": 16, "mode": ("replicated on every rank, no collective (16 rows < DP_SHARD_MIN_ROWS = %d: a 0.04 ms "
+                                                                 "step against a 1.18 MB exchange)" % __import__("a_link_amd.distributed", fromlist=["x"]).DP_SHARD_MIN_ROWS)
+                                   if world > 1 else "one process", "gradient_all_reduce_exercised_by": "finetune_step_dp_ms (this line, N > 1) and tests/test_gpu_distributed.py"},
                 "note": "whole iteration on the wall clock (max over ranks): noise kernels, embeddings, heads, host-side selection, collectives, fine-tune"}
+            line["value_identical_selection"] = {"embeddings_per_s": n_emb / t_q, "workload": "config4.screen_settle: one A-LINK iteration, results bit-equal "
+                                                 "to the all-exact iteration's in this run" if same4 else "config4.screen_settle (NOT identical in this run)",
+                                                 "all_exact_embeddings_per_s": n_emb / t_e}
 
     if not args.no_config5 and not args.no_extras:
         # ---- BASELINE configs[4] ("A2-LINK: adversarial-noise batch"): the reference's adversarial noise is the black-box few-pixel
@@ -985,6 +1000,22 @@ def main():
             hq.train_on_batch([L, R], yd)
             ts.append(time.perf_counter() - t1)
         line["finetune_step_bf16_ms"] = 1e3 * float(np.median(ts))
+        # the drivers' PRE-TRAINING loop (SiameseNetwork.customTrainModel, code/siamese.py:81-112; 20,000 steps an epoch x 100 epochs at
+        # the reference's settings): train_on_batch + test_on_batch per step over the balanced generator, 200 persons, batch 16 —
+        # the generator's feature table on the device, steps shipped as row indices in blocks (round 6)
+        from a_link_amd import pairs as PRc, siamese as SIc
+        rsc = np.random.RandomState(0)
+        fc_ = [rsc.randn(rsc.randint(3, 6), 512).astype(np.float32) for _ in range(200)]
+        genc = PRc.getGenerator(PRc.getNormalGenerator(fc_, 16), PRc.getNormalGenerator(fc_, 16), PRc.getImposterGenerator(fc_, fc_, 16), 16)
+        netc = SIc.SiameseNetwork((512,), "/tmp/alink_ctm", 0.1, seed=1)
+        np.random.seed(0)
+        netc.customTrainModel(genc, 1, 16, 0.2, n_steps=16 * 300, verbose=0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        netc.customTrainModel(genc, 1, 16, 0.2, n_steps=16 * 3000, verbose=0)
+        torch.cuda.synchronize()
+        line["custom_train_step_ms"] = 1e3 * (time.perf_counter() - t1) / 3000
+        del netc, genc, fc_
         # pair scoring throughput (K6): 1M pairs gathered from a 100k x 512 embedding matrix
         E = torch.randn(100000, 512, device="cuda")
         E = E / E.norm(dim=1, keepdim=True)
@@ -1137,6 +1168,17 @@ def main():
         parity["oracle_rows"] = int(nrow)
         parity["weights"] = args.weights
         assert parity["one_minus_cos_vs_cpu_oracle_max"] < 1e-3, parity
+        if args.weights == "survey" and args.dtype in ("bf16", "f16") and not args.cpu_baseline_small:
+            # the same check on the OTHER weight draw (BatchNorm statistics matching the activations, like a trained checkpoint's:
+            # the draw the config-3 / 4 / 5 legs use) — 8 images, one ~1.3 s CPU forward: the headline dtype's error is smaller there
+            pn = W.synthetic_ir_params(units, seed=1, normalized=True)
+            bn_ = IRBackbone(pn, image_size=(112, 112), dtype=args.dtype, device=local_rank, max_batch=8)
+            gn = bn_.embed_device(x[:8]).cpu().numpy().astype(np.float64)
+            on = ir_resnet.embed(pn, x[:8].float().cpu().numpy(), batch=8)
+            omn = 1.0 - (gn * on).sum(1)
+            parity["normalized_weights"] = {"one_minus_cos_vs_cpu_oracle_max": float(omn.max()), "one_minus_cos_vs_cpu_oracle_mean": float(omn.mean()),
+                                            "oracle_rows": 8}
+            del bn_, pn
         if sel_out is not None:
             sn = sel_out[:nrow].cpu().numpy().astype(np.float64)
             line["exact_selection"]["max_abs_diff_vs_cpu_oracle"] = float(np.abs(sn - oracle_rows).max())

@@ -318,3 +318,137 @@ def _shards_worker(rank, world, port, q):
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
+
+
+# ---- a rank that fails in the BULK phase, and a rank that re-calibrates itself ---------------------------------------
+class _FailingNoise(FakeNoise):
+    """raises for the rank whose rows include a chosen global row (a data-dependent failure: Poisson's lam < 0, say)"""
+
+    def __init__(self, seed, sigma, bad_row):
+        FakeNoise.__init__(self, seed, sigma)
+        self.bad_row = bad_row
+
+    def addPairNoise(self, image_pairs, target_labels, rows=None):
+        first = 0 if rows is None else int(rows[0])
+        if first <= self.bad_row < first + len(image_pairs[0]):
+            raise ValueError("lam < 0 in row %d" % self.bad_row)
+        return FakeNoise.addPairNoise(self, image_pairs, target_labels, rows=rows)
+
+
+class _RecalibratingFeature(FakeFeature):
+    """a feature model with a calibration state (one scale exponent) that rank `who` lowers by itself the first time it converts
+    noisy rows — what an f16x2 backbone does when a batch leaves its range; `model.model` is what merge_calibration talks to"""
+
+    def __init__(self, who, rank):
+        FakeFeature.__init__(self)
+        self.exp, self.who, self.rank, self.tripped, self.merged = [7], who, rank, False, 0
+        outer = self
+
+        class _BB(object):
+            dtype = "f16x2"
+
+            def state(self):
+                return {"dtype": "f16x2", "scale_exponents": list(outer.exp)}
+
+            def load_state(self, st):
+                outer.exp = list(st["scale_exponents"])
+                outer.merged += 1
+        self.model = type("M", (), {"model": _BB()})()
+        self.process_screen = None
+
+    def process(self, X):
+        if len(X) > 40 and self.rank == self.who and not self.tripped:       # the noisy rows (the clean pass is a few dozen images)
+            self.tripped = True
+            self.exp = [5]
+        return FakeFeature.process(self, X)
+
+
+def _advice_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = {}
+        X_plain, X_dig = _people(6, 1), _people(6, 2)
+        # (a) the noise of ONE rank raises: every rank must raise in the exchange that follows, none may wait
+        for screen in (False, True):
+            flags = AL.Flags(alink_bs=3, batch_send=6, disparity_ratio=0.6, eps=0.0005, ft_epochs=2, mixture_ratio=2, out_model="",
+                             screen_settle=screen)
+            conv = FakeFeature()
+            if not screen:
+                conv.process_screen = None
+            student = CpuStudent(7, scale=60.0)
+            ens = [CpuStudent(100 + i, scale=60.0) for i in range(2)]
+            nz = [FakeNoise(1000, 6.0), _FailingNoise(1001, 14.0, bad_row=1)]              # row 1 belongs to rank 0
+            feats_plain = [conv.process(p) for p in X_plain]
+            gen = pairs.getGenerator(pairs.getNormalGenerator(feats_plain, 8), pairs.getNormalGenerator(feats_plain, 8),
+                                     pairs.getImposterGenerator(feats_plain, feats_plain, 8), 8)
+            try:
+                AL.run_alink_dfw(flags, conv, CpuBagging(ens, nz), nz, student, X_plain, X_dig, gen, SIZE, col=0, verbose=0, on_device=False,
+                                 group=dist.group.WORLD)
+                out["fail_%s" % screen] = "no error"
+            except RuntimeError as e:
+                out["fail_%s" % screen] = str(e)
+            dist.barrier()
+        # (b) one rank re-calibrates during the first iteration: scales merged, the iteration repeated, the loop completes — and
+        # every rank ends with the student the single-process loop (calibrated to the merged scales from the start) ends with
+        flags = AL.Flags(alink_bs=3, batch_send=6, disparity_ratio=0.6, eps=0.0005, ft_epochs=2, mixture_ratio=2, out_model="")
+        conv = _RecalibratingFeature(who=1, rank=rank)
+        student = CpuStudent(7, scale=60.0)
+        ens = [CpuStudent(100 + i, scale=60.0) for i in range(2)]
+        nz = [FakeNoise(1000 + i, s) for i, s in enumerate((6.0, 14.0))]
+        feats_plain = [FakeFeature.process(conv, p) for p in X_plain]
+        gen = pairs.getGenerator(pairs.getNormalGenerator(feats_plain, 8), pairs.getNormalGenerator(feats_plain, 8),
+                                 pairs.getImposterGenerator(feats_plain, feats_plain, 8), 8)
+        np.random.seed(5)
+        st = AL.run_alink_dfw(flags, conv, CpuBagging(ens, nz), nz, student, X_plain, X_dig, gen, SIZE, col=0, verbose=0, on_device=False,
+                              group=dist.group.WORLD)
+        out["recal"] = {"recalibrations": st.recalibrations, "exp": list(conv.exp), "iterations": st.iterations, "un": st.un_size,
+                        "active": st.active_count, "finetunes": st.finetunes, "weights": student.siamese_net.get_weights()}
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_and_a_recalibrating_rank_do_not_strand_their_peers():
+    """ADVICE r5.  (a) A data-dependent failure in the bulk phase of alink_iteration(group=) — here the noise of the rank that owns
+    pair row 1 raises — is carried into the next exchange: BOTH ranks raise a RuntimeError naming rank 0 (only rank 0's message holds
+    the cause), with and without screen-then-settle; nobody blocks in a collective.  (b) A rank whose feature model lowers its
+    split-precision scales by itself during an iteration makes every rank roll the iteration back, take the elementwise minimum
+    of the scales, wind the random streams back and run it again — once; the loop then finishes with the counters and the student
+    of an undisturbed single-process loop."""
+    # the single-process loop (b) must reproduce: no re-calibration happens (rank 0 is never `who`)
+    X_plain, X_dig = _people(6, 1), _people(6, 2)
+    flags = AL.Flags(alink_bs=3, batch_send=6, disparity_ratio=0.6, eps=0.0005, ft_epochs=2, mixture_ratio=2, out_model="")
+    conv = _RecalibratingFeature(who=1, rank=0)
+    student = CpuStudent(7, scale=60.0)
+    ens = [CpuStudent(100 + i, scale=60.0) for i in range(2)]
+    nz = [FakeNoise(1000 + i, s) for i, s in enumerate((6.0, 14.0))]
+    feats_plain = [FakeFeature.process(conv, p) for p in X_plain]
+    gen = pairs.getGenerator(pairs.getNormalGenerator(feats_plain, 8), pairs.getNormalGenerator(feats_plain, 8),
+                             pairs.getImposterGenerator(feats_plain, feats_plain, 8), 8)
+    np.random.seed(5)
+    want = AL.run_alink_dfw(flags, conv, CpuBagging(ens, nz), nz, student, X_plain, X_dig, gen, SIZE, col=0, verbose=0, on_device=False)
+    want_w = student.siamese_net.get_weights()
+    assert want.finetunes >= 1 and want.recalibrations == 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_advice_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for screen in (False, True):
+        for r in range(2):
+            msg = res[r]["fail_%s" % screen]
+            assert "rank(s) [0] failed before this exchange" in msg, (screen, r, msg)
+            assert ("lam < 0 in row 1" in msg) == (r == 0), (screen, r, msg)
+    for r in range(2):
+        got = res[r]["recal"]
+        assert got["recalibrations"] == 1 and got["exp"] == [5], got
+        assert (got["iterations"], got["un"], got["active"], got["finetunes"]) == (want.iterations, want.un_size, want.active_count, want.finetunes)
+        for a, b in zip(got["weights"], want_w):
+            assert np.array_equal(a, b)

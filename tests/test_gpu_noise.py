@@ -406,6 +406,31 @@ def test_poisson_unique_count_survives_an_overfull_hash_part(gpu):
     assert p.last_vals.cpu().numpy()[0] == 32768.0
 
 
+def test_poisson_unique_count_of_short_mantissa_images_is_exact_and_fast(gpu):
+    """pixels with short mantissas — quarter steps, values rounded through bfloat16 — share the low bits of the
+    multiplicative hash; a table slot taken from those bits put thousands of distinct values into a handful of home slots
+    (linear probing then costs ~distinct / 2 contended atomicCAS per element: seconds per image).  The slot now comes from the
+    high bits: the count stays exact and 32 such images take well under a second."""
+    import time
+    from a_link_amd import noise as N
+    rng = np.random.RandomState(3)
+    shape = (32, 112, 112, 3)
+    quarter = (rng.randint(0, 4 * 255, shape) / 4.0).astype(np.float32)                       # ~1020 distinct quarter steps
+    bf = torch.from_numpy(rng.uniform(0, 255, shape).astype(np.float32)).to(torch.bfloat16).float().numpy()      # bf16-rounded
+    for x in (quarter, bf):
+        want = np.array([2.0 ** np.ceil(np.log2(len(np.unique(im)))) for im in x])
+        p = N.Poisson(seed=2)
+        xd = torch.from_numpy(x).cuda()
+        p.addNoise(xd[:2], None)                                                            # warm-up
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        p.addNoise(xd, None)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        assert np.array_equal(p.last_vals.cpu().numpy(), want)
+        assert dt < 1.0, "32 short-mantissa images took %.2f s" % dt
+
+
 def test_pool_scale_batches_take_several_launches(gpu):
     """The sampling kernels carry the image index in grid.y (at most 65,535): a batch of 70,000 (tiny) images — a pool-scale
     call — must go through, and equal the same images perturbed as two row ranges."""
