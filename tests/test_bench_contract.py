@@ -1,5 +1,5 @@
 """CPU: the bench line's CONTRACT, checked on the newest line committed under profiles/ (bench.py itself needs a GPU).  The
-keys the driver reads, the two objects this tier adds (`roofline`, `cpu_baseline`) with their fields, and the round-5 additions
+keys the driver reads, the two objects this tier adds (`roofline`, `cpu_baseline`) with their fields, and the round-5 / round-6 additions
 the documents cite (both roofline fractions with their sources, the N = 256 CPU forward, the 32-row parity, the audits, the
 config-4 leg's rank fields)."""
 import glob
@@ -48,3 +48,15 @@ def test_committed_bench_line_keeps_the_contract():
     # BASELINE.md §4 leg 3: the head's fine-tune step AND the SmallRes 32 x 32 end-to-end step, on the GPU and on the host
     assert 0 < l["finetune_step_ms"] < 1 and 0 < l["smallres32_train_step_ms"] < 20
     assert l["cpu_baseline"]["finetune_step_ms_cpu"] > l["finetune_step_ms"] and l["cpu_baseline"]["smallres32_train_step_ms_cpu"] > l["smallres32_train_step_ms"]
+    # round 6: the at-reference-precision rates at the top level, the few-pixel attack leg, the training loops
+    assert "bf16 < reference f32" in l["dtype_note"] and l["value_exact"]["dtype"] == "f16x2" and 0 < l["value_exact"]["embeddings_per_s"] < l["value"]
+    vi = l["value_identical_selection"]
+    assert vi["all_exact_embeddings_per_s"] < vi["embeddings_per_s"] < l["value"] and "bit-equal" in vi["workload"]
+    c5 = l["config5"]
+    assert c5["lockstep_images_identical_to_one_after_another"] is True and c5["n_gpus"] == l["n_gpus"]
+    for mode in ("screen", "bf16", "exact"):
+        assert c5[mode]["backbone_forwards_per_pair"] == 20400 and 0.9 < c5[mode]["frac_of_in_batch_rate"] <= 1.02, (mode, c5[mode])
+    assert c5["screen"]["backbone_forwards_per_s"] >= 40000 and c5["exact"]["search_dtype"] == "f16x2"
+    assert 0 < l["custom_train_step_ms"] < 0.08 and l["smallres32_train_step_ms"] < 0.6
+    assert l["parity"]["normalized_weights"]["one_minus_cos_vs_cpu_oracle_max"] < l["parity"]["one_minus_cos_vs_cpu_oracle_max"]
+    assert l["config4"]["finetune_steps"]["rows_per_step"] == 16
