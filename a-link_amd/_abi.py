@@ -115,6 +115,7 @@ PROTOTYPES = {
     "alink_smallres_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "alink_smallres_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _f, _i, _vp, _vp]),
     "alink_smallres_apply_update": (_i, [_vp, _vp]),
+    "alink_smallres_set_graph": (_i, [_vp, _i]),
     "alink_smallres_eval": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "alink_smallres_mask_sizes": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "alink_noise_gaussian": (_i, [_vp, _vp, _i64, _f, _f, _u64, _u64, _vp]),

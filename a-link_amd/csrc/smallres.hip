@@ -23,6 +23,7 @@ using namespace alink;
 extern "C" {
 int alink_head_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, int n, float* dev_dL,
                            float* dev_dR, void* stream);
+float* alink_head_params_dev(alink_head_t* h);
 }
 
 namespace {
@@ -120,12 +121,25 @@ struct alink_smallres {
     hipStream_t side = nullptr;        // weight gradients (independent of the dz chain once their dz exists)
     hipEvent_t ev_dz[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, ev_side = nullptr, ev_prev = nullptr;   // ev_prev: the dense layer's input gradient has read W
     float* ws2 = nullptr;              // split-K slabs of the side stream's GEMMs
+    // the whole train step as a captured graph, per distinct (operand pointers, n, flags, lr) — OPTIONAL and off: a step is ~40
+    // short launches on two streams, the host needs ~170 us to enqueue them and the device runs dry in the backward; but a replayed
+    // node costs more than a launch on this ROCm (0.457 ms replayed against 0.375: tools/experiments/smallres_graph_ab.py).
+    // `seen` = 1: the key ran once as plain launches (function attributes set, LDS sized), the next call captures.
+    struct StepGraph {
+        const void *L, *R, *y, *sw, *masks, *metrics;
+        int n, prescale, apply, overlap, seen;
+        float grad_scale, lr;
+        hipGraphExec_t exec;
+    };
+    std::vector<StepGraph> graphs;
+    bool use_graph = false;
     uint8_t *arg1 = nullptr, *arg2 = nullptr;
     float* d_all_grads = nullptr;      // [tower grads | head grads] contiguous copy for all-reduce
     float* ws = nullptr;               // split-K slabs of sgemm
     size_t ws_floats = 0;
     std::vector<void*> allocs;
     ~alink_smallres() {
+        for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
         for (hipEvent_t e : ev_dz) if (e) (void)hipEventDestroy(e);
         if (ev_side) (void)hipEventDestroy(ev_side);
@@ -339,12 +353,9 @@ int alink_smallres_eval(alink_smallres_t* m, const float* dev_L, const float* de
 static bool g_smallres_overlap = true;
 void alink_debug_set_smallres_overlap(int on) { g_smallres_overlap = on != 0; }      // include/alink_hip_debug.h
 
-int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
-                              const float* dev_sw, int n, int prescale, const uint8_t* dev_masks, float grad_scale,
-                              int apply, float* dev_metrics, void* stream) {
-    ALINK_REQUIRE(m && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
-    ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
-    DeviceGuard dg(m->device);
+static int train_step_launches(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
+                               const float* dev_sw, int n, int prescale, const uint8_t* dev_masks, float grad_scale,
+                               int apply, float* dev_metrics, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const size_t e1 = (size_t)m->P1h * m->P1w * 32;
     const uint8_t* m1 = dev_masks;
@@ -430,6 +441,61 @@ int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const flo
     // gradients only (a data-parallel caller all-reduces the contiguous buffer, then alink_smallres_apply_update)
     ALINK_HIP(hipMemcpyAsync(m->d_all_grads + m->ntower, alink_head_grads_dev(m->head),
                              alink_head_num_params(m->head) * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return ALINK_OK;
+}
+
+int alink_smallres_set_graph(alink_smallres_t* m, int on) {
+    ALINK_REQUIRE(m, ALINK_EINVAL, "NULL model");
+    m->use_graph = on != 0;
+    return ALINK_OK;
+}
+
+int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
+                              const float* dev_sw, int n, int prescale, const uint8_t* dev_masks, float grad_scale,
+                              int apply, float* dev_metrics, void* stream) {
+    ALINK_REQUIRE(m && dev_L && dev_R && dev_y && dev_metrics, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
+    DeviceGuard dg(m->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    // the legacy default stream cannot be captured; a stream the caller is already capturing simply receives the launches
+    const bool can_graph = m->use_graph && st != nullptr && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+    if (!can_graph) return train_step_launches(m, dev_L, dev_R, dev_y, dev_sw, n, prescale, dev_masks, grad_scale, apply, dev_metrics, stream);
+    const int overlap = g_smallres_overlap ? 1 : 0;
+    alink_smallres::StepGraph* hit = nullptr;
+    for (auto& g : m->graphs)
+        if (g.L == dev_L && g.R == dev_R && g.y == dev_y && g.sw == dev_sw && g.masks == dev_masks && g.metrics == dev_metrics && g.n == n &&
+            g.prescale == prescale && g.apply == apply && g.overlap == overlap && g.grad_scale == grad_scale && g.lr == m->lr) { hit = &g; break; }
+    if (hit && hit->exec) {
+        ALINK_HIP(hipGraphLaunch(hit->exec, st));
+        if (apply) (void)alink_head_params_dev(m->head);      // the head's derived weight copies are stale (what the plain path notes on the host)
+        return ALINK_OK;
+    }
+    if (!hit) {                                               // first sight of these operands: plain launches (and every one-off set-up they trigger)
+        if (m->graphs.size() >= 8) {
+            if (m->graphs.front().exec) (void)hipGraphExecDestroy(m->graphs.front().exec);
+            m->graphs.erase(m->graphs.begin());
+        }
+        m->graphs.push_back({dev_L, dev_R, dev_y, dev_sw, dev_masks, dev_metrics, n, prescale, apply, overlap, 1, grad_scale, m->lr, nullptr});
+        return train_step_launches(m, dev_L, dev_R, dev_y, dev_sw, n, prescale, dev_masks, grad_scale, apply, dev_metrics, stream);
+    }
+    hipGraph_t graph = nullptr;
+    ALINK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = train_step_launches(m, dev_L, dev_R, dev_y, dev_sw, n, prescale, dev_masks, grad_scale, apply, dev_metrics, stream);
+    const hipError_t ee = hipStreamEndCapture(st, &graph);
+    hipGraphExec_t exec = nullptr;
+    hipError_t ei = hipErrorUnknown;
+    if (!rc && ee == hipSuccess && graph) ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (rc || ee != hipSuccess || ei != hipSuccess) {
+        (void)hipGetLastError();
+        if (rc) return rc;
+        m->use_graph = false;                                 // capture is not available here: plain launches from now on
+        return train_step_launches(m, dev_L, dev_R, dev_y, dev_sw, n, prescale, dev_masks, grad_scale, apply, dev_metrics, stream);
+    }
+    hit->exec = exec;
+    ALINK_HIP(hipGraphLaunch(exec, st));
+    if (apply) (void)alink_head_params_dev(m->head);
     return ALINK_OK;
 }
 

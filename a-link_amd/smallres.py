@@ -53,6 +53,13 @@ class SmallResNet(KerasFitMixin):
         self._metrics_host = torch.zeros(2, dtype=torch.float32).pin_memory()
         self._tdev = torch.device(self.device)
         self._mask_buf = {}
+        # Optional, OFF: train_on_batch can replay its ~40 launches as ONE captured graph (use_graph = True + alink_smallres_set_graph):
+        # a stream of this model's own (torch's default stream is the NULL stream, which cannot be captured) and staging buffers that
+        # keep the operands at stable addresses.  Measured on MI355X / ROCm 7.2: 0.457 ms per 16-pair step replayed against 0.375
+        # as plain launches (tools/experiments/smallres_graph_ab.py) — a replayed node costs more than a launch here.
+        self._stream = torch.cuda.Stream(device=self._tdev)
+        self._stage = {}
+        self.use_graph = False
         self.prescale = 1 if prescale else 0
 
     def __del__(self):
@@ -147,30 +154,57 @@ class SmallResNet(KerasFitMixin):
         e1, e2 = self.mask_sizes
         return (np.random.rand(2 * n * e1 + 2 * n * e2) >= 0.25).astype(np.uint8)
 
+    def _staged(self, key, a, dtype=None):
+        """a device tensor holding `a` at an address that is the same from step to step (host array, or device tensor on any stream
+        the caller has made this model's stream wait for)"""
+        torch = self.torch
+        dtype = dtype or torch.float32
+        if isinstance(a, torch.Tensor):
+            src = a
+        else:
+            src = torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint8 if dtype is torch.uint8 else np.float32))
+        buf = self._stage.get((key, tuple(src.shape)))
+        if buf is None:
+            buf = self._stage[(key, tuple(src.shape))] = torch.empty(tuple(src.shape), dtype=dtype, device=self.device)
+        buf.copy_(src, non_blocking=True)
+        return buf
+
     def train_on_batch(self, x, y, class_weight=None, sample_weight=None, masks=None):
-        L, R, yd = self._dev(x[0]), self._dev(x[1]), self._dev(y)
-        n = L.shape[0]
+        torch = self.torch
+        n = len(y)
         assert n <= MAXN, "train batches larger than %d pairs are not supported" % MAXN
         sw = sample_weight
         if sw is None and class_weight is not None:
             sw = np.asarray([class_weight[c] for c in np.asarray(y).argmax(axis=1)], np.float32)
-        swd = self._dev(sw) if sw is not None else None
-        if masks is None and self.training_dropout:
-            # the keep-masks are drawn ON THE DEVICE (Philox, keyed by one 31-bit seed taken from np.random per step): drawing
-            # 2n(e1 + e2) = 304,128 uniforms with np.random on the host was 0.74 of the step's 1.68 ms.  One np.random draw per step
-            # keeps the ranks of a multi-rank loop in step (alink_loop.sync_host_randomness) like the host-drawn masks did.
-            e1, e2 = self.mask_sizes
-            md = self._mask_buf.get(n)                   # (a step's masks are consumed by that step, in stream order)
-            if md is None:
-                md = self._mask_buf[n] = self.torch.empty(2 * n * (e1 + e2), dtype=self.torch.uint8, device=self.device)
-            _abi.check(self.lib.alink_keep_masks(_abi.ptr(md), md.numel(), 0.75, int(np.random.randint(0, 2 ** 31 - 1)),
-                                                 _abi.current_stream(self.device)), "alink_keep_masks")
-        else:
-            md = self.torch.from_numpy(np.ascontiguousarray(masks, np.uint8)).to(self.device) if masks is not None else None
-        st = self.torch.cuda.current_stream(self._tdev)
-        _abi.check(self.lib.alink_smallres_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
-                                                      self.prescale, _abi.ptr(md), 0.0, 1, C.c_void_p(self._metrics_host.data_ptr()),
-                                                      C.c_void_p(st.cuda_stream)), "alink_smallres_train_step")
+        cur = torch.cuda.current_stream(self._tdev)
+        st = self._stream if self.use_graph else cur
+        if st is not cur:
+            st.wait_stream(cur)                       # inputs produced on the caller's stream
+        with torch.cuda.stream(st):
+            if self.use_graph:
+                L, R, yd = self._staged("L", x[0]), self._staged("R", x[1]), self._staged("y", y)
+                swd = self._staged("sw", sw) if sw is not None else None
+            else:
+                L, R, yd = self._dev(x[0]), self._dev(x[1]), self._dev(y)
+                swd = self._dev(sw) if sw is not None else None
+            if masks is None and self.training_dropout:
+                # the keep-masks are drawn ON THE DEVICE (Philox, keyed by one 31-bit seed taken from np.random per step): drawing
+                # 2n(e1 + e2) = 304,128 uniforms with np.random on the host was 0.74 of the step's 1.68 ms.  One np.random draw per step
+                # keeps the ranks of a multi-rank loop in step (alink_loop.sync_host_randomness) like the host-drawn masks did.
+                e1, e2 = self.mask_sizes
+                md = self._mask_buf.get(n)               # (a step's masks are consumed by that step, in stream order)
+                if md is None:
+                    md = self._mask_buf[n] = torch.empty(2 * n * (e1 + e2), dtype=torch.uint8, device=self.device)
+                _abi.check(self.lib.alink_keep_masks(_abi.ptr(md), md.numel(), 0.75, int(np.random.randint(0, 2 ** 31 - 1)),
+                                                     C.c_void_p(st.cuda_stream)), "alink_keep_masks")
+            elif masks is not None:
+                md = self._staged("masks", masks, torch.uint8) if self.use_graph else \
+                    torch.from_numpy(np.ascontiguousarray(masks, np.uint8)).to(self.device)
+            else:
+                md = None
+            _abi.check(self.lib.alink_smallres_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
+                                                          self.prescale, _abi.ptr(md), 0.0, 1, C.c_void_p(self._metrics_host.data_ptr()),
+                                                          C.c_void_p(st.cuda_stream)), "alink_smallres_train_step")
         st.synchronize()
         return self._metrics_host.tolist()
 

@@ -369,6 +369,10 @@ int alink_smallres_forward(alink_smallres_t* m, const float* dev_L, const float*
 int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
                               const float* dev_sw, int n, int prescale, const uint8_t* dev_masks,
                               float grad_scale, int apply, float* dev_metrics, void* stream);
+/* Optional (SmallResNet turns it on): on a non-default stream, the whole train step — ~40 short launches on two streams — is
+ * captured per distinct (operand pointers, n, flags, lr) the second time it is seen and replayed from then on.  The caller keeps its
+ * operands at stable addresses (staging buffers) for that to hit.  Same kernels, same order: the same results. */
+int alink_smallres_set_graph(alink_smallres_t* m, int on);
 int alink_smallres_apply_update(alink_smallres_t* m, void* stream);
 int alink_smallres_eval(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y, int n,
                         int prescale, float* dev_metrics, void* stream);

@@ -97,3 +97,27 @@ def test_device_drawn_dropout_masks(gpu):
     np.random.randint(0, 2 ** 31 - 1)
     assert after == np.random.rand()
     assert any(not np.array_equal(u, v) for u, v in zip(w0, net.get_weights()))
+
+
+def test_train_step_replayed_as_a_graph_equals_plain_launches(gpu):
+    """SmallResNet(use_graph=True) + alink_smallres_set_graph: the ~40 launches of a step on the model's own stream, captured the
+    second time an operand set is seen and replayed from then on (optional, off by default: a replayed node costs more than a
+    launch on this ROCm).  Same kernels in the same order: metrics and every weight after five steps — plain, plain, captured,
+    replayed, replayed — equal the plain-launch model's bit for bit, and predict sees the updated weights."""
+    from a_link_amd.smallres import SmallResNet
+    rs = np.random.RandomState(2)
+    L = ((rs.randint(0, 256, (8, 32, 32, 3)) - 128.0) / 128.0).astype(np.float32)
+    R = ((rs.randint(0, 256, (8, 32, 32, 3)) - 128.0) / 128.0).astype(np.float32)
+    y = np.eye(2, dtype=np.float32)[rs.randint(0, 2, 8)]
+    out = []
+    for graph in (False, True):
+        net = SmallResNet((32, 32, 3), 256, lr=0.1, seed=4)
+        net.use_graph = graph
+        gpu.check(net.lib.alink_smallres_set_graph(net.h, 1 if graph else 0))
+        np.random.seed(9)
+        ms = [net.train_on_batch([L, R], y) for _ in range(5)]
+        out.append((ms, net.get_weights(), net.predict([L, R])))
+    assert out[0][0] == out[1][0]
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out[0][2], out[1][2])
