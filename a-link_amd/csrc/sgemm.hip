@@ -296,7 +296,15 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
             bv[i] = Bs[(2 * i + hh) * LDB + wn * 32 + l31];
         }
         auto mfma_step = [&](int kk) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk >> 1], bv[kk >> 1], acc, 0, 0, 0); };
-        if (k0 + BK < kend) {
+        if (BK == BK_SMALL && k0 + BK < kend) {
+            // many workgroups per CU: other waves fill this one's shadows, and the scheduler does better left alone
+#pragma unroll
+            for (int j = 0; j < AQ; ++j) ma[j] = load_a(k0 + BK, j, ra[j]);
+#pragma unroll
+            for (int j = 0; j < BQ; ++j) mb[j] = load_b(k0 + BK, j, rb[j]);
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) mfma_step(kk);
+        } else if (k0 + BK < kend) {
             constexpr int NP = AQ + BQ, STEPS = BK / 2, PER = STEPS / NP > 0 ? STEPS / NP : 1;
             int kk = 0;
 #pragma unroll
@@ -338,43 +346,50 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
     const bool fin = p.splitk == 1;
     const float bias = (fin && p.bias) ? p.bias[col] : 0.f;
     const float alpha = (fin && p.alpha) ? p.alpha[col] : 1.f;
-    float va[16], vr[16], vc[16];
-    int idxs[16];
+    // (four rows at a time: the fetched values are live registers, and the 16-deep form runs many waves per SIMD — 64 of them
+    // for all 16 rows cost it its occupancy)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        idxs[r] = (row < p.M ? row : 0) * p.ldc + col;
-        va[r] = 1.f; vr[r] = 0.f; vc[r] = 0.f;
-    }
-    if (fin && p.act) {                     // (one uniform branch around sixteen loads, not sixteen branches around one each)
+    for (int r0 = 0; r0 < 16; r0 += 4) {
+        float va[4], vr[4], vc[4];
+        int idxs[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) va[r] = p.act[idxs[r]];
-    }
-    if (fin && p.resid) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) vr[r] = p.resid[idxs[r]];
-    }
-    if (fin && p.accumulate) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) vc[r] = C[idxs[r]];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float v = acc[r];
-        if (fin) {
-            v += bias;
-            if (p.alpha) v = v > 0.f ? v : v * alpha;
-            if (p.relu) v = fmaxf(v, 0.f);
-            if (p.act) v = va[r] > 0.f ? v : 0.f;
-            if (p.resid) v += vr[r];
-            if (p.accumulate) v += vc[r];
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + q;
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            idxs[q] = (row < p.M ? row : 0) * p.ldc + col;
+            va[q] = 1.f; vr[q] = 0.f; vc[q] = 0.f;
         }
-        va[r] = v;
-    }
+        if (fin && p.act) {                     // (one uniform branch around four loads, not four branches around one each)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < p.M) C[(size_t)row * p.ldc + col] = va[r];
+            for (int q = 0; q < 4; ++q) va[q] = p.act[idxs[q]];
+        }
+        if (fin && p.resid) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vr[q] = p.resid[idxs[q]];
+        }
+        if (fin && p.accumulate) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vc[q] = C[idxs[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = acc[r0 + q];
+            if (fin) {
+                v += bias;
+                if (p.alpha) v = v > 0.f ? v : v * alpha;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.act) v = va[q] > 0.f ? v : 0.f;
+                if (p.resid) v += vr[q];
+                if (p.accumulate) v += vc[q];
+            }
+            va[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + q;
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (row < p.M) C[(size_t)row * p.ldc + col] = va[q];
+        }
     }
     // [probe:8]
 }
