@@ -162,13 +162,16 @@ class _LockstepEngine(object):
         self.device = _abi.resolve_device(device)
         self.dev = "cuda:%d" % self.device
         self.lib = _abi.init(self.device)
-        first = np.asarray(images[0])
+        first = images[0]
         self.Hc, self.W = int(first.shape[0]), int(first.shape[1])
-        if first.ndim != 3 or first.shape[2] != 3 or self.Hc % 2 or (self.Hc // 2, self.W) != tuple(self.bb.image_size):
-            raise TypeError("stacked pair image %s does not match the backbone input" % (first.shape,))
+        if len(first.shape) != 3 or first.shape[2] != 3 or self.Hc % 2 or (self.Hc // 2, self.W) != tuple(self.bb.image_size):
+            raise TypeError("stacked pair image %s does not match the backbone input" % (tuple(first.shape),))
         # the stacked pair images of the whole call stay resident (301 KB each at 112 x 112: 3,840 pairs = 1.2 GB of 288)
-        host = np.ascontiguousarray(np.stack([np.asarray(im, dtype=np.float32) for im in images]))
-        self.imgs = torch.from_numpy(host).to(self.dev)
+        if isinstance(images, torch.Tensor):                     # (n, 2H, W, 3) already on a device: no trip through the host
+            self.imgs = images.to(self.dev, torch.float32).contiguous()
+        else:
+            host = np.ascontiguousarray(np.stack([np.asarray(im, dtype=np.float32) for im in images]))
+            self.imgs = torch.from_numpy(host).to(self.dev)
         self.ub = getattr(self.bb, "bb", self.bb)            # the IRBackbone under a one-product screening view
 
     # -- one launch ----------------------------------------------------------------------------------------------------
@@ -297,8 +300,8 @@ class _LockstepEngine(object):
             ub.lazy_range_check = saved_lazy
         return results
 
-    def attacked_images(self, results):
-        """perturb_image(result.x, image)[0] for every pair: one launch, one copy back"""
+    def attacked_images(self, results, as_device=False):
+        """perturb_image(result.x, image)[0] for every pair: one launch, one copy back (or none: as_device)"""
         torch = self.torch
         n = len(results)
         xs = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(r.x, dtype=np.float64) for r in results]))).to(self.dev)
@@ -306,7 +309,7 @@ class _LockstepEngine(object):
         out = torch.empty((n, self.Hc, self.W, 3), dtype=torch.float32, device=self.dev)
         _abi.check(self.lib.alink_perturb_images_multi(_abi.ptr(self.imgs), _abi.ptr(of), 1, _abi.ptr(xs), n, self.k, self.Hc, self.W, 0,
                                                        _abi.ptr(out), _abi.current_stream(self.device)), "alink_perturb_images_multi")
-        return out.cpu().numpy()
+        return out if as_device else out.cpu().numpy()
 
 
 def _success(confidence, target_class, targeted_attack, verbose=False):
@@ -402,6 +405,8 @@ class PixelAttacker:
             except TypeError:
                 eng = None                                 # no device fast path for this model: the generic route below
         if eng is None:
+            if hasattr(input_data, "detach"):                    # the generic route works on host arrays
+                input_data = input_data.detach().cpu().numpy()
             X = []
             for i, img in enumerate(input_data):
                 target_class = np.argmax(targets[i])
@@ -418,4 +423,6 @@ class PixelAttacker:
                           [(tc, True, False) for tc in tcs], maxiter, lockstep, verbose=verbose, early_stop=early_stop)
         self.last_results = results
         self.last_result = results[-1]
+        if hasattr(input_data, "detach"):                        # device tensor in -> device tensor out
+            return eng.attacked_images(results, as_device=True)
         return list(eng.attacked_images(results))

@@ -274,9 +274,15 @@ class AdversarialNoise(Noise):
         n = len(image_pairs[0])
         if n == 0:                                  # an empty shard: empty sides of the input's own shape (and container kind)
             return [image_pairs[0], image_pairs[1]]
-        image_pairs = [p.detach().cpu().numpy() if hasattr(p, "detach") else p for p in image_pairs]
-        concat_data = [np.concatenate((image_pairs[0][i], image_pairs[1][i]), axis=0) for i in range(n)]
-        img_shape = image_pairs[0][0].shape
+        on_device = all(hasattr(p, "detach") for p in image_pairs) and self.attacker.lockstep > 0
+        if on_device:
+            import torch
+            concat_data = torch.cat((image_pairs[0].float(), image_pairs[1].float()), dim=1)      # (n, 2H, W, 3): the stacked pairs, on the device
+            img_shape = tuple(image_pairs[0].shape[1:])
+        else:
+            image_pairs = [p.detach().cpu().numpy() if hasattr(p, "detach") else p for p in image_pairs]
+            concat_data = [np.concatenate((image_pairs[0][i], image_pairs[1][i]), axis=0) for i in range(n)]
+            img_shape = image_pairs[0][0].shape
         # splitmix64 of (stream, global row) -> a 32-bit RandomState seed per pair
         seeds = []
         for i in range(n):
@@ -286,6 +292,9 @@ class AdversarialNoise(Noise):
             seeds.append(int((z ^ (z >> 31)) & 0xFFFFFFFF))
         perturbed = self.attacker.attack_all(concat_data, target_labels, dimensions=(2 * img_shape[0], img_shape[1]),
                                              seeds=seeds, **self.search)
+        if hasattr(perturbed, "detach"):                     # device tensor out: the two halves as views
+            h = perturbed.shape[1] // 2
+            return [perturbed[:, :h].contiguous(), perturbed[:, h:].contiguous()]
         left_half = [p[:p.shape[0] // 2] for p in perturbed]
         right_half = [p[p.shape[0] // 2:] for p in perturbed]
         return [left_half, right_half]

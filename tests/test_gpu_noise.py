@@ -493,6 +493,9 @@ def test_lockstep_attack_equals_the_sequential_attack(gpu, search):
     att = A.PixelAttacker(wrapped, search=mode, lockstep=4)
     att.attack_all(imgs, targets, early_stop=False, **kw)
     assert [int(r.nit) for r in att.last_results] == [6] * n
+    # stacked pairs handed over as ONE device tensor come back as one (no trip through the host), the same images
+    dev_out = A.PixelAttacker(wrapped, search=mode, lockstep=4).attack_all(torch.from_numpy(np.stack(imgs)).cuda(), targets, **kw)
+    assert dev_out.is_cuda and np.array_equal(dev_out.cpu().numpy(), np.stack(want))
     # through the noise class, with its per-row seeds: rows of a shard equal rows of the whole, whatever the lock-step width
     L = np.stack([im[:32] for im in imgs])
     R = np.stack([im[32:] for im in imgs])
@@ -507,3 +510,6 @@ def test_lockstep_attack_equals_the_sequential_attack(gpu, search):
                 parts[s_] += list(got[s_])
         for s_ in (0, 1):
             assert np.array_equal(np.stack(parts[s_]), np.stack(whole[s_])), (search, K)
+    got_dev = N.AdversarialNoise(student, None, conv, seed=9, lockstep=32, **nk).addPairNoise([torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()], labels)
+    for s_ in (0, 1):                                      # device tensors in -> device tensors out, the same rows
+        assert got_dev[s_].is_cuda and np.array_equal(got_dev[s_].cpu().numpy(), np.stack(whole[s_])), search

@@ -96,25 +96,30 @@ def config4(out, noises, student_dtype="f32"):
 
 
 def config5(out, conv, student, n_pairs, search="exact"):
+    """the few-pixel attack at the reference's defaults, every search run to maxiter: K pairs in lock-step (round 6), and two pairs one
+    after another (the reference's shape) beside it"""
     import numpy as np
     from a_link_amd import attack as A, noise
     wrapped = noise.PredictionWrappedModel(student, conv)
     rng = np.random.RandomState(0)
     imgs = [rng.randint(0, 256, (224, 112, 3)).astype(np.float32) for _ in range(n_pairs)]
-    att = A.PixelAttacker(wrapped, seed=np.random.RandomState(1), search=search)
-    # force every generation to run: a callback that never stops, as when the attack does not succeed
-    att.attack_success = lambda *a, **k: None
+    targets = [[0, 1]] * n_pairs
+    seeds = list(range(n_pairs))
+    att = A.PixelAttacker(wrapped, search=search)
+    att.attack_all(imgs[:2], targets[:2], (224, 112), seeds=seeds[:2], maxiter=2, early_stop=False)      # warm-up
     t = time.perf_counter()
-    gens = evals = 0
-    for im in imgs:
-        att.attack(im, 1, 0, pixel_count=40, dimensions=(224, 112), maxiter=50, popsize=250)
-        gens += int(att.last_result.nit)
-        evals += int(att.last_result.nfev)
+    att.attack_all(imgs, targets, (224, 112), seeds=seeds, early_stop=False)
     dt = time.perf_counter() - t
-    out["config5_pixel_attack_r100" + ("" if search == "exact" else "_search_in_screening_mode")] = {
-        "pairs": n_pairs, "s_per_pair": dt / n_pairs, "generations_per_pair": gens / n_pairs,
-        "candidate_evaluations_per_pair": evals / n_pairs, "backbone_forwards_per_pair": 2 * evals / n_pairs,
-        "backbone_forwards_per_s": 2 * evals / dt}
+    evals = sum(int(r.nfev) for r in att.last_results)
+    key = "config5_pixel_attack_r100" + ("" if search == "exact" else "_search_" + search)
+    out[key] = {"pairs": n_pairs, "lockstep": att.lockstep, "s_per_pair": dt / n_pairs,
+                "generations_per_pair": float(np.mean([r.nit for r in att.last_results])),
+                "backbone_forwards_per_pair": 2 * evals / n_pairs, "backbone_forwards_per_s": 2 * evals / dt}
+    seq = A.PixelAttacker(wrapped, search=search, lockstep=0)
+    seq.attack_success = lambda *a, **k: None            # every generation runs, as when the attack does not succeed
+    t = time.perf_counter()
+    seq.attack_all(imgs[:2], targets[:2], (224, 112), seeds=seeds[:2])
+    out[key]["one_pair_after_another_s_per_pair"] = (time.perf_counter() - t) / 2
 
 
 def config5_gradient(out, n_pairs):
