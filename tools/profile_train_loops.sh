@@ -19,3 +19,6 @@ rm -rf $O/prof/kt_ctm
 cat $O/${P}_smallres_step.json $O/${P}_custom_train_time.json
 head -40 $O/${P}_smallres_step_kernel_stats.csv
 head -20 $O/${P}_custom_train_kernel_stats.csv
+# the few-pixel attack in lock-step (8 pairs, 16-bit search): which kernels its time is in
+cd $R && bash tools/trace.sh ${P}_pixel_attack_lockstep tools/pixel_attack_time.py 8 screen 8 > $O/prof/kt_pa.log 2>&1
+head -12 $O/${P}_pixel_attack_lockstep_kernel_stats.csv
