@@ -538,6 +538,13 @@ hipError_t launch_gemm32(const GemmP& p, float* workspace, hipStream_t st) {
     return e;
 }
 
+hipError_t launch_slab_sum(const float* part, float* out, long long MN, int S, hipStream_t st) {
+    if (!part || !out || MN <= 0 || S <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN + 31) / 32)), dim3(256), 0, st, part, out, MN, (int)MN, (int)MN, S,
+                       (const float*)nullptr, 0, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr);
+    return hipGetLastError();
+}
+
 hipError_t launch_colsum(const float* dz, float* gb, int n, int C, hipStream_t st) {
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dz, gb, n, C);
     return hipGetLastError();

@@ -96,6 +96,99 @@ __global__ void adadelta2_kernel(float* __restrict__ prm, const float* __restric
     a[i] = na;
 }
 
+// ---- the first layer (3 -> 32 channels, 3x3 'same') on the vector units ---------------------------------------------------
+// K = 27 is not a GEMM's shape: as one the layer was a single half-empty MFMA stage fed by 32 four-byte gathers per thread
+// (12.6 us at 2 x 16 images), its weight gradient a 28-row tile reduced over 32,768 pixels by scalar gathers (26 + 6 us, the
+// LAST link of the backward chain).  Here a thread owns a pixel: 27 inputs, 32 accumulators, the weights broadcast from LDS,
+// k ascending like the GEMM's reduction (the matrix instruction is an ordered fmaf chain too: sgemm.hip).
+struct Conv1P {
+    const float *L, *R;       // images 0 .. split-1 from L, the rest from R (R == nullptr: all from L); [n][H][W][3]
+    const float *w, *b;       // (3,3,3,32) = [27][32], [32]
+    float* out;               // [nb][H][W][32]
+    int nb, split, H, W, prescale;
+};
+// this pixel's 27 inputs (3 x 3 taps x 3 channels, zero outside the image): every load is issued from a clamped, always valid
+// address and its value kept or dropped by an AND with a mask the compiler cannot see through — `ok ? load : 0` becomes a branch
+// around the load, and 27 of those are 27 trips to memory one after the other (the lesson of sgemm.hip's loaders)
+__device__ __forceinline__ void conv1_patch(const Conv1P& p, int pix, float (&in)[27]) {
+    const int x = pix % p.W, r = pix / p.W, y = r % p.H, n = r / p.H;
+    const float* img = (p.R && n >= p.split) ? p.R + (size_t)(n - p.split) * p.H * p.W * 3 : p.L + (size_t)n * p.H * p.W * 3;
+    const float sub = p.prescale ? 128.f : 0.f, mul = p.prescale ? 0.0078125f : 1.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const int off = ok ? (iy * p.W + ix) * 3 : 0;
+        int mk = ok ? -1 : 0;
+        asm volatile("" : "+v"(mk));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) in[t * 3 + c] = __int_as_float(__float_as_int((img[off + c] - sub) * mul) & mk);
+    }
+}
+
+// thread = (pixel, 8 output channels): 131,072 threads at 2 x 16 images of 32 x 32 (a thread per pixel left half the chip idle)
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const Conv1P p) {
+    __shared__ __attribute__((aligned(16))) float ws[27 * 32 + 32];
+    for (int i = threadIdx.x; i < 27 * 32 + 32; i += 256) ws[i] = i < 27 * 32 ? p.w[i] : p.b[i - 27 * 32];
+    __syncthreads();
+    const int g = blockIdx.x * 256 + threadIdx.x, pix = g >> 2, c0 = (g & 3) * 8;
+    if (pix >= p.nb * p.H * p.W) return;
+    float in[27];
+    conv1_patch(p, pix, in);
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        const f32x4 wa = *(const f32x4*)(ws + k * 32 + c0), wb = *(const f32x4*)(ws + k * 32 + c0 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] = fmaf(in[k], wa[j], acc[j]); acc[4 + j] = fmaf(in[k], wb[j], acc[4 + j]); }
+    }
+    float* o = p.out + (size_t)pix * 32 + c0;
+    f32x4 v0, v1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(acc[j] + ws[27 * 32 + c0 + j], 0.f); v1[j] = fmaxf(acc[4 + j] + ws[27 * 32 + c0 + 4 + j], 0.f); }
+    *(f32x4*)o = v0;
+    *(f32x4*)(o + 4) = v1;
+}
+
+// partial weight + bias gradients of the first layer over 128 pixels per workgroup: part[block][28][32] (row 27 = bias);
+// summed over the blocks, in a fixed order, by sgemm's slab reduction
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1P p, const float* __restrict__ dz, float* __restrict__ part) {
+    __shared__ float xs[128 * 29];                     // [pixel][27 inputs + the ones column], pitch 29 (odd: conflict-free rows)
+    __shared__ __attribute__((aligned(16))) float ds[128 * 32];
+    const int tid = threadIdx.x, p0 = blockIdx.x * 128, P = p.nb * p.H * p.W;
+    if (tid < 128) {                                   // half the threads fetch a pixel's patch each, the other half the dz rows
+        const int pix = p0 + tid;
+        float in[27];
+        conv1_patch(p, pix < P ? pix : 0, in);
+#pragma unroll
+        for (int k = 0; k < 27; ++k) xs[tid * 29 + k] = pix < P ? in[k] : 0.f;
+        xs[tid * 29 + 27] = pix < P ? 1.f : 0.f;       // the ones column: the bias gradient
+    } else {
+        for (int i = tid - 128; i < 128 * 8; i += 128) {
+            const int lp = i >> 3, c4 = (i & 7) * 4;
+            const bool ok = p0 + lp < P;
+            f32x4 v = *(const f32x4*)(dz + (size_t)(ok ? p0 + lp : 0) * 32 + c4);
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)(ds + lp * 32 + c4) = v;
+        }
+    }
+    __syncthreads();
+    const int co = tid & 31, kb = tid >> 5;                                 // outputs (kb + 8 j, co), j < 4 (k < 28)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int lp = 0; lp < 128; ++lp) {
+        const float d = ds[lp * 32 + co];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(xs[lp * 29 + ((kb + 8 * j) < 28 ? kb + 8 * j : 27)], (kb + 8 * j) < 28 ? d : 0.f, acc[j]);
+    }
+    float* o = part + (size_t)blockIdx.x * (28 * 32);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (kb + 8 * j < 28) o[(kb + 8 * j) * 32 + co] = acc[j];
+}
+
 }  // namespace
 
 struct alink_smallres {
@@ -191,7 +284,10 @@ int tower_fwd(alink_smallres* m, const float* L, const float* R, int n, int pres
     const float keep_scale = 1.f / (1.f - 0.25f);
     const int nb = R ? 2 * n : n;
     int rc;
-    if ((rc = conv_fwd(m, L, m->a1, 0, nb, m->H, m->W, prescale, st, R, n))) return rc;
+    {   // the first layer on the vector units (K = 27 is no GEMM: see conv1_fwd_kernel)
+        Conv1P c{L, R, P + m->oW[0], P + m->oB[0], m->a1, nb, n, m->H, m->W, prescale};
+        hipLaunchKernelGGL(conv1_fwd_kernel, g1((long long)nb * m->H * m->W * 4), dim3(256), 0, st, c);
+    }
     if ((rc = conv_fwd(m, m->a1, m->a2, 1, nb, m->H, m->W, 0, st))) return rc;
     hipLaunchKernelGGL(pool_fwd_kernel, g1((long long)nb * m->P1h * m->P1w * 32), dim3(256), 0, st, m->a2, m->p1,
                        m->arg1, mask1, keep_scale, nb, m->H1, m->W1, 32);
@@ -423,8 +519,16 @@ static int train_step_launches(alink_smallres_t* m, const float* dev_L, const fl
     if ((rc = fork(3))) return rc;
     if ((rc = wgrad(m, m->a1, m->ga2, 1, nb, m->H, m->W, 0, 0, sw, wsw))) return rc;
     if ((rc = dgrad(m, m->ga2, m->ga1, m->a1, 1, nb, m->H, m->W, st))) return rc;
-    // conv1's weight gradient gathers from the two image buffers (the last link of the dz chain: on the caller's stream)
-    if ((rc = wgrad(m, dev_L, m->ga1, 0, nb, m->H, m->W, prescale, 0, st, nullptr, dev_R, n))) return rc;
+    // conv1's weight + bias gradient (the last link of the dz chain: on the caller's stream): partial sums over 128 pixels per
+    // workgroup on the vector units, then the slab sum
+    {
+        const long long Px = (long long)nb * m->H * m->W;
+        const int blocks = (int)((Px + 127) / 128);
+        ALINK_REQUIRE((size_t)blocks * 28 * 32 <= m->ws_floats, ALINK_ENOMEM, "workspace too small for conv1's gradient");
+        Conv1P c{dev_L, dev_R, nullptr, nullptr, nullptr, nb, n, m->H, m->W, prescale};
+        hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(blocks), dim3(256), 0, st, c, m->ga1, m->ws);
+        ALINK_HIP(launch_slab_sum(m->ws, G + m->oW[0], 28 * 32, blocks, st));
+    }
     ALINK_HIP(hipGetLastError());
     if (two) {                             // join: everything after this sees every gradient
         ALINK_HIP(hipEventRecord(m->ev_side, m->side));
