@@ -262,6 +262,14 @@ int run_gemm(alink_smallres* m, GemmP& g, int max_split, hipStream_t st, float* 
     return ALINK_OK;
 }
 
+// A layer of at most 128 tiles with a long reduction (a small batch's deeper layers: conv4 at 2 x 16 images is 85 tiles x 9 stages on
+// 256 CUs, its input gradient 57 tiles x 9) is split over K: the chip fills, and the slab sum — which applies the epilogue — is one
+// short launch.  Larger grids are not (the slab sum of a 28,800 x 32 output costs more than the split saves: measured).
+inline bool small_grid(const GemmP& g) {
+    const int bm = g.N <= 32 ? 128 : 64, bn = g.N <= 32 ? 32 : 64;
+    return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) <= 128 && g.K >= 512;
+}
+
 // out = relu(conv3x3(in, w[layer]) + b[layer]); in is [nb][H][W][Ci]
 int conv_fwd(alink_smallres* m, const float* in, float* out, int layer, int nb, int H, int W, int prescale,
              hipStream_t st, const float* in2 = nullptr, int split = 0) {
@@ -272,7 +280,7 @@ int conv_fwd(alink_smallres* m, const float* in, float* out, int layer, int nb, 
     g.M = nb * g.Ho * g.Wo; g.N = Co; g.K = 9 * Ci; g.ldb = Co; g.ldc = Co;
     g.amode = A_CONV; g.bmode = B_ROW; g.H = H; g.W = W; g.Ci = Ci; g.pad = pad; g.prescale = prescale;
     g.bias = m->d_p + m->oB[layer]; g.relu = 1;
-    return run_gemm(m, g, 1, st);
+    return run_gemm(m, g, small_grid(g) ? 4 : 1, st);
 }
 
 // tower forward on the nb = 2n images of a siamese batch — images 0 .. n-1 from `L`, n .. 2n-1 from `R` (R == nullptr: nb
@@ -329,7 +337,7 @@ int dgrad(alink_smallres* m, const float* dz, float* din, const float* act, int 
     g.Ci = Co; g.Ho = H; g.Wo = W; g.pad = 2 - pad;
     g.M = nb * H * W; g.N = Ci; g.K = 9 * Co; g.ldc = Ci;
     g.amode = A_CONV; g.bmode = B_FLIP; g.act = act;
-    return run_gemm(m, g, 1, st);
+    return run_gemm(m, g, small_grid(g) ? 4 : 1, st);
 }
 
 }  // namespace
