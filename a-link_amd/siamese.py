@@ -184,7 +184,6 @@ class SiameseNetwork:
         for st in sets:
             st["i_np"], st["f_np"] = st["i_host"].numpy(), st["f_host"].numpy()
         stream = torch.cuda.current_stream(net._tdev)
-        logs = []
 
         # The launches of a block (5 per step) cost the host about as much as planning the block does: they run on a worker
         # thread (ctypes drops the GIL for the call) while this thread plans the next block.  One worker, jobs in order: the
