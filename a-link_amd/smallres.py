@@ -59,6 +59,7 @@ class SmallResNet(KerasFitMixin):
         # as plain launches (tools/experiments/smallres_graph_ab.py) — a replayed node costs more than a launch here.
         self._stream = torch.cuda.Stream(device=self._tdev)
         self._stage = {}
+        self._pin = {}
         self.use_graph = False
         self.prescale = 1 if prescale else 0
 
@@ -169,6 +170,20 @@ class SmallResNet(KerasFitMixin):
         buf.copy_(src, non_blocking=True)
         return buf
 
+    def _up(self, key, a):
+        """host array -> device through a pinned staging buffer and an asynchronous copy (a pageable upload is a synchronous
+        ~15 us each, three per step); the step ends with a stream synchronisation, so the buffer is free again by the next one.
+        Device tensors pass through."""
+        torch = self.torch
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device, torch.float32).contiguous()
+        a = np.asarray(a, dtype=np.float32)
+        buf = self._pin.get((key, a.shape))
+        if buf is None:
+            buf = self._pin[(key, a.shape)] = torch.empty(a.shape, dtype=torch.float32).pin_memory()
+        buf.numpy()[...] = a
+        return buf.to(self.device, non_blocking=True)
+
     def train_on_batch(self, x, y, class_weight=None, sample_weight=None, masks=None):
         torch = self.torch
         n = len(y)
@@ -185,8 +200,8 @@ class SmallResNet(KerasFitMixin):
                 L, R, yd = self._staged("L", x[0]), self._staged("R", x[1]), self._staged("y", y)
                 swd = self._staged("sw", sw) if sw is not None else None
             else:
-                L, R, yd = self._dev(x[0]), self._dev(x[1]), self._dev(y)
-                swd = self._dev(sw) if sw is not None else None
+                L, R, yd = self._up("L", x[0]), self._up("R", x[1]), self._up("y", y)
+                swd = self._up("sw", sw) if sw is not None else None
             if masks is None and self.training_dropout:
                 # the keep-masks are drawn ON THE DEVICE (Philox, keyed by one 31-bit seed taken from np.random per step): drawing
                 # 2n(e1 + e2) = 304,128 uniforms with np.random on the host was 0.74 of the step's 1.68 ms.  One np.random draw per step
