@@ -513,3 +513,38 @@ def test_lockstep_attack_equals_the_sequential_attack(gpu, search):
     got_dev = N.AdversarialNoise(student, None, conv, seed=9, lockstep=32, **nk).addPairNoise([torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()], labels)
     for s_ in (0, 1):                                      # device tensors in -> device tensors out, the same rows
         assert got_dev[s_].is_cuda and np.array_equal(got_dev[s_].cpu().numpy(), np.stack(whole[s_])), search
+
+
+def test_lockstep_attack_survives_a_range_exit_of_the_exact_mode(gpu):
+    """The exact (split-precision) backbone re-calibrates itself when a batch leaves its calibrated range; under the lock-step
+    engine its per-call range synchronisation is deferred to one flag read per step, and a raised flag makes the engine
+    re-calibrate on the images in flight (scales only go down) and run the step again.  Given scales 2^7 too fine and
+    attacked with full-range pairs: the searches must complete with finite energies, the scales must have moved, and a second
+    run under the now-sufficient scales must equal the one-pair-at-a-time form bit for bit."""
+    from a_link_amd import attack as A, noise as N, siamese
+    size = (32, 32)
+    conv = siamese.ArcFace(size, "synthetic:r18:3", screen_dtype=None)            # f16x2, the API default
+    bb = conv.model.model
+    assert bb.dtype == "f16x2"
+    # scales 2^7 too fine for real images (as if calibrated on images with activations 128 x smaller: the headroom is 32 x)
+    st0 = bb.state()
+    bb.load_state(dict(st0, scale_exponents=[e + 7 for e in st0["scale_exponents"]]))
+    before = bb.state()["scale_exponents"]
+    student = siamese.SiameseNetwork((512,), "s", 0.1, seed=3)
+    wrapped = N.PredictionWrappedModel(student, conv)
+    rng = np.random.RandomState(8)
+    imgs = [rng.randint(0, 256, (64, 32, 3)).astype(np.float32) for _ in range(5)]
+    targets = [[0, 1]] * 5
+    kw = dict(dimensions=(64, 32), pixel_count=3, maxiter=3, popsize=30, seeds=[1, 2, 3, 4, 5], early_stop=False)
+    att = A.PixelAttacker(wrapped, lockstep=4)
+    out = att.attack_all(imgs, targets, **kw)
+    after = bb.state()["scale_exponents"]
+    assert after != before and all(a <= b for a, b in zip(after, before)), "the engine should have re-calibrated (scales only go down)"
+    assert all(np.isfinite(r.fun) for r in att.last_results) and np.isfinite(np.stack(out)).all()
+    assert not bb.lazy_range_check                                                   # the deferred check was handed back
+    again = A.PixelAttacker(wrapped, lockstep=4).attack_all(imgs, targets, **kw)
+    seq = A.PixelAttacker(wrapped, lockstep=0)
+    seq.attack_success = lambda *a_, **k_: None
+    one = seq.attack_all(imgs, targets, **{k_: v for k_, v in kw.items() if k_ != "early_stop"})
+    assert bb.state()["scale_exponents"] == after
+    assert np.array_equal(np.stack(again), np.stack(one))
