@@ -438,7 +438,11 @@ def getGenerator(norGen, normImpGen, impGen, batch_size, type=0, val_ratio=0.2):
 
 def getGeneratorMTP(datGen, batch_size, resize_res=None, featurize=None):
     """reference code/readMTP.py:80-113: balance, optionally resize (bilinear, device kernel) and
-    featurize each source batch, accumulate to batch_size."""
+    featurize each source batch, accumulate to batch_size.
+    Over one of this module's own sources (rows of a table gathered by index) the resize / featurize run ONCE, on the
+    table: both are per-image maps (an image resizes — and embeds — to the same values whatever batch it arrives in), so
+    gathering rows of the transformed table IS transforming the gathered rows; the reference resizes every copy of every
+    image again in every round (a pair batch holds each image many times).  The mix is then indexable like the DFW one."""
     def transform(sides):
         if resize_res:
             from . import noise as _noise
@@ -446,4 +450,9 @@ def getGeneratorMTP(datGen, batch_size, resize_res=None, featurize=None):
         if featurize:
             sides = [featurize.process(s) for s in sides]
         return sides
+    if (resize_res or featurize) and isinstance(datGen, _Gathering) and len(datGen.rows):
+        rows = datGen.rows
+        step = 4096                                   # the table goes through the device in chunks (pool-sized tables)
+        parts = [transform([rows[i:i + step]])[0] for i in range(0, len(rows), step)]
+        return mix_balanced([_Gathering(_cat([np.asarray(p) if not hasattr(p, "detach") else p for p in parts]), datGen.index)], batch_size)
     return mix_balanced([datGen], batch_size, transform if (resize_res or featurize) else None)

@@ -214,3 +214,30 @@ def test_loop_with_screen_then_settle_equals_all_exact_loop(gpu, capsys, screen,
     assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[3] == b[3] >= 1
     for x, y in zip(a[4], b[4]):
         assert np.array_equal(x, y)
+
+
+def test_mtp_generator_transforms_its_table_once(gpu):
+    """readMTP.getGenerator (code/readMTP.py:80-113) resizes (and featurizes) every source batch of every round; over this
+    package's own source the table is transformed ONCE and rows are gathered from it (both are per-image maps).  The batches
+    must equal, bit for bit, the round-by-round transform of the same source behind an opaque generator — resize alone, and
+    resize + a feature model."""
+    from a_link_amd import pairs, siamese
+    rng = np.random.RandomState(0)
+    people = [rng.randint(0, 256, (rng.randint(2, 5), 40, 40, 3)).astype(np.float32) for _ in range(9)]
+    fm = siamese.ArcFace((32, 32), "synthetic:r18:3", dtype="bf16", screen_dtype=None)
+
+    def foreign(g):
+        while True:
+            yield next(g)
+    for kw in (dict(resize_res=(32, 32)), dict(resize_res=(32, 32), featurize=fm)):
+        own = pairs.getGeneratorMTP(pairs.getNormalGenerator(people, 16), 8, **kw)
+        leg = pairs.getGeneratorMTP(foreign(pairs.getNormalGenerator(people, 16)), 8, **kw)
+        assert own.indexable and not leg.indexable
+        np.random.seed(4)
+        a = [next(own) for _ in range(6)]
+        np.random.seed(4)
+        b = [next(leg) for _ in range(6)]
+        for (xa, ya), (xb, yb) in zip(a, b):
+            assert np.array_equal(ya, yb)
+            for s in (0, 1):
+                assert np.asarray(xa[s]).shape == np.asarray(xb[s]).shape and np.array_equal(np.asarray(xa[s]), np.asarray(xb[s])), kw.keys()
