@@ -56,6 +56,7 @@ struct alink_head {
     float *d_dm = nullptr, *d_z1 = nullptr, *d_z2 = nullptr, *d_dz1 = nullptr, *d_dz2 = nullptr,
           *d_dz3 = nullptr, *d_p = nullptr;
     float* d_tiny = nullptr;     // per-row-group partials of the tiny-batch train step
+    float* d_mini = nullptr;     // Dense1 partial sums of SmallRes' three-launch step ([D / 32][n][128]); only for that head shape
     unsigned* d_counter = nullptr;   // row groups finished (tiny_eval), 0 between launches
     std::vector<void*> allocs;
     // hipGraph cache of the fine-tune step (a launch-bound chain of 8-9 small kernels): one executable
@@ -680,9 +681,12 @@ __global__ void dense_dgrad_kernel(const float* __restrict__ dz, const float* __
 // dL[r][k] = sign(L - R) * sum_c dZ1[r][c] W1[k][c], dR = -dL.  Workgroup = 64 inputs k x 16 rows, W1 and dZ1 staged through
 // LDS 128 columns at a time (a thread per (r, k) walking W1 row k straight from memory read it at a 4 * h1-byte stride from
 // lane to lane: 19.8 us for 8 MFLOP at n = 32, D = 2048 until round 6); c ascending per output, as before.
+// relu_in: L and R are the outputs of a ReLU (SmallRes' tower ends in one) and the gradients wanted are those w.r.t. its
+// pre-activations: the mask (x > 0) is applied here instead of by a launch of its own.
 __global__ __launch_bounds__(256) void head_input_grad_kernel(const float* __restrict__ L, const float* __restrict__ R,
                                                               const float* __restrict__ dz1, const float* __restrict__ w1,
-                                                              float* __restrict__ dL, float* __restrict__ dR, int n, int D, int h1) {
+                                                              float* __restrict__ dL, float* __restrict__ dR, int n, int D, int h1,
+                                                              int relu_in) {
     __shared__ float Ws[64 * 129];
     __shared__ __attribute__((aligned(16))) float Dz[16 * 128];
     const int tid = threadIdx.x, kl = tid & 63, rg = tid >> 6;
@@ -718,10 +722,11 @@ __global__ __launch_bounds__(256) void head_input_grad_kernel(const float* __res
         const int r = r0 + rg * 4 + q;
         if (r >= n) continue;
         const size_t i = (size_t)r * D + k;
-        const float d = L[i] - R[i];
+        const float l = L[i], r_ = R[i], d = l - r_;
         const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        dL[i] = acc[q] * sg;
-        dR[i] = -acc[q] * sg;
+        const float gl = acc[q] * sg, gr = -acc[q] * sg;
+        dL[i] = (relu_in && !(l > 0.f)) ? 0.f : gl;
+        dR[i] = (relu_in && !(r_ > 0.f)) ? 0.f : gr;
     }
 }
 
@@ -1526,6 +1531,322 @@ int tiny_eval(alink_head* h, const float* L, const float* R, const float* y, int
     return ALINK_OK;
 }
 
+// --------------- SmallRes' head: train step + input gradients in three launches (round 6) -------------------
+// SmallRes (code/siamese.py:156-168) ends in |l - r| -> Dense(128) -> Dense(32) -> Dense(2) on 2048 features at batch 16.  On
+// the generic chain above that is seven dependent launches (two forwards, loss, middle, two weight gradients' worth, input
+// gradients: 57 us of a 339 us step, every one of them a few workgroups waiting on memory).  The dependencies allow three:
+//   A  mini_dense1_kernel   one workgroup per 32 inputs k: partial Dense1 sums of every row over its W1 rows (one round trip)
+//   B  mini_mid_kernel      ONE workgroup: adds the partials, Dense2, Dense3, softmax, BCE, metrics, dZ3, dZ2, dZ1, dW3, dW2
+//                           (everything whose operands fit in LDS: 16 x 128 activations, the 16 KB of W2)
+//   C  mini_wgrad1_kernel   one workgroup per 32 inputs k again: its rows of dW1 and its columns of dL / dR (the same W1 rows)
+// Sums run in a fixed order (k ascending inside a slice, slices in eight interleaved groups; rows / columns ascending as in
+// the generic kernels), so a step is reproducible; against the generic chain the Dense1 / Dense2 sums differ by rounding.
+constexpr int MINI_N = 32;       // rows (pairs) the path takes
+constexpr int MINI_KS = 32;      // inputs per workgroup in A and C
+bool g_use_mini = true;
+
+template <int NJ>                // rows per thread: 8 (n <= 16) or 16
+__global__ __launch_bounds__(256) void mini_dense1_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                                                          const float* __restrict__ W1, float* __restrict__ part, int n, int D) {
+    __shared__ __attribute__((aligned(16))) float Ws[MINI_KS * 128];
+    __shared__ __attribute__((aligned(16))) float dms[2 * NJ * MINI_KS];
+    const int tid = threadIdx.x, k0 = blockIdx.x * MINI_KS;
+    f32x4 wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wv[j] = *(const f32x4*)(W1 + (size_t)k0 * 128 + (size_t)(tid + 256 * j) * 4);     // 32 rows of W1 are contiguous
+    const int row = tid >> 3, k4 = (tid & 7) * 4;
+    f32x4 lv = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
+    if (row < n) {
+        lv = *(const f32x4*)(L + (size_t)row * D + k0 + k4);
+        rv = *(const f32x4*)(R + (size_t)row * D + k0 + k4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(f32x4*)(Ws + (tid + 256 * j) * 4) = wv[j];
+    if (row < 2 * NJ) {
+        f32x4 d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = fabsf(lv[i] - rv[i]);
+        *(f32x4*)(dms + row * MINI_KS + k4) = d;
+    }
+    __syncthreads();
+    const int c = tid & 127, half = tid >> 7;         // thread: column c, rows half, half + 2, ...
+    float acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+#pragma unroll 2
+    for (int k = 0; k < MINI_KS; k += 4) {
+        const float w0 = Ws[k * 128 + c], w1 = Ws[(k + 1) * 128 + c], w2 = Ws[(k + 2) * 128 + c], w3 = Ws[(k + 3) * 128 + c];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const f32x4 d = *(const f32x4*)(dms + (half + 2 * j) * MINI_KS + k);
+            acc[j] = fmaf(d[0], w0, acc[j]);
+            acc[j] = fmaf(d[1], w1, acc[j]);
+            acc[j] = fmaf(d[2], w2, acc[j]);
+            acc[j] = fmaf(d[3], w3, acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int r = half + 2 * j;
+        if (r < n) part[((size_t)blockIdx.x * n + r) * 128 + c] = acc[j];
+    }
+}
+
+struct MiniMid {
+    const float *part, *b1, *W2, *b2, *W3, *b3, *y, *sw;
+    float *gW2, *gb2, *gW3, *gb3, *dz1, *probs, *metrics;
+    int n, S;                // rows; slices of A (a multiple of 8)
+    float grad_scale;        // <= 0: 1 / count(sw != 0)
+};
+
+__global__ __launch_bounds__(1024) void mini_mid_kernel(const MiniMid p) {
+    __shared__ float z1s[MINI_N * 128];
+    __shared__ float W2s[128 * 33];
+    __shared__ float z2s[MINI_N * 32], dz2s[MINI_N * 32];
+    __shared__ float dz3s[MINI_N * 2], rowm[MINI_N * 2], w3s[66], b2s[32], sws[MINI_N], ys[MINI_N * 2];
+    const int tid = threadIdx.x, n = p.n, S = p.S;
+    const int nz1 = n * 128;
+    // ---- every global load of the forward first: W2 and the small vectors ride under the partial sums
+    const f32x4 w2v = *(const f32x4*)(p.W2 + tid * 4);
+    float small = 0.f;
+    if (tid < 64) small = p.W3[tid];
+    else if (tid < 66) small = p.b3[tid - 64];
+    else if (tid >= 128 && tid < 160) small = p.b2[tid - 128];
+    else if (tid >= 192 && tid < 192 + n) small = p.sw ? p.sw[tid - 192] : 1.f;
+    else if (tid >= 256 && tid < 256 + 2 * n) small = p.y[tid - 256];
+    // z1[r][c] = b1[c] + sum over slices: eight interleaved groups (slices g, g + 8, ... ascending), then the groups pairwise
+    for (int o = tid; o < nz1; o += 1024) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* pp = p.part + o;
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t[g] = pp[(size_t)(s0 + g) * nz1];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) a[g] += t[g];
+        }
+        z1s[o] = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + p.b1[o & 127];
+    }
+    {
+        const int k = tid >> 3, c = (tid & 7) * 4;
+        float* d = W2s + k * 33 + c;
+        d[0] = w2v[0]; d[1] = w2v[1]; d[2] = w2v[2]; d[3] = w2v[3];
+    }
+    if (tid < 66) w3s[tid] = small;
+    else if (tid >= 128 && tid < 160) b2s[tid - 128] = small;
+    else if (tid >= 192 && tid < 192 + n) sws[tid - 192] = small;
+    else if (tid >= 256 && tid < 256 + 2 * n) ys[tid - 256] = small;
+    __syncthreads();
+    // ---- Dense2 on relu(z1): one thread per (row, column), k ascending
+    if (tid < n * 32) {
+        const int r = tid >> 5, c2 = tid & 31;
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 128; ++k) s = fmaf(fmaxf(z1s[r * 128 + k], 0.f), W2s[k * 33 + c2], s);
+        z2s[tid] = s + b2s[c2];
+    }
+    __syncthreads();
+    // ---- per row: Dense3, softmax, Keras binary_crossentropy on the clipped probabilities, accuracy, dZ3 (head_loss_kernel's arithmetic)
+    float cnt = 0.f;
+    for (int i = 0; i < n; ++i) cnt += sws[i] != 0.f ? 1.f : 0.f;
+    const float scale = p.grad_scale > 0.f ? p.grad_scale : 1.f / cnt;
+    if (tid < n) {
+        const float* a = z2s + tid * 32;
+        const float w = sws[tid];
+        float z0 = 0.f, z1 = 0.f;
+        for (int c = 0; c < 32; ++c) {
+            const float v = fmaxf(a[c], 0.f);
+            z0 = fmaf(v, w3s[c * 2 + 0], z0);
+            z1 = fmaf(v, w3s[c * 2 + 1], z1);
+        }
+        z0 += w3s[64];
+        z1 += w3s[65];
+        const float m = fmaxf(z0, z1);
+        const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+        const float pr[2] = {e0 / (e0 + e1), e1 / (e0 + e1)};
+        p.probs[tid * 2 + 0] = pr[0];
+        p.probs[tid * 2 + 1] = pr[1];
+        float li = 0.f, acc = 0.f, dp[2];
+        for (int c = 0; c < 2; ++c) {
+            const float y = ys[tid * 2 + c];
+            const float pc = fminf(fmaxf(pr[c], 1e-7f), 1.f - 1e-7f);
+            const float x = logf(pc / (1.f - pc));
+            li += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+            acc += (rintf(pr[c]) == y) ? 1.f : 0.f;
+            const bool inside = pr[c] >= 1e-7f && pr[c] <= 1.f - 1e-7f;
+            dp[c] = inside ? 0.5f * w * scale * (pc - y) / (pc * (1.f - pc)) : 0.f;
+        }
+        rowm[tid * 2 + 0] = 0.5f * li * w;
+        rowm[tid * 2 + 1] = 0.5f * acc;
+        const float dot = dp[0] * pr[0] + dp[1] * pr[1];
+        dz3s[tid * 2 + 0] = pr[0] * (dp[0] - dot);
+        dz3s[tid * 2 + 1] = pr[1] * (dp[1] - dot);
+    }
+    __syncthreads();
+    // ---- metrics (rows ascending), dW3 / db3, dZ2
+    if (tid == 1023) {
+        float ls = 0.f, as = 0.f;
+        for (int i = 0; i < n; ++i) { ls += rowm[i * 2]; as += rowm[i * 2 + 1]; }
+        p.metrics[0] = ls * scale;
+        p.metrics[1] = as / (float)n;
+    }
+    if (tid >= 896 && tid < 896 + 66) {
+        const int t = tid - 896;
+        float s = 0.f;
+        if (t < 64) {
+            const int c = t >> 1, j = t & 1;
+            for (int i = 0; i < n; ++i) s = fmaf(fmaxf(z2s[i * 32 + c], 0.f), dz3s[i * 2 + j], s);
+            p.gW3[t] = s;
+        } else {
+            const int j = t - 64;
+            for (int i = 0; i < n; ++i) s += dz3s[i * 2 + j];
+            p.gb3[j] = s;
+        }
+    }
+    if (tid < n * 32) {
+        const int i = tid >> 5, c = tid & 31;
+        float g = 0.f;
+        g = fmaf(dz3s[i * 2 + 0], w3s[c * 2 + 0], g);
+        g = fmaf(dz3s[i * 2 + 1], w3s[c * 2 + 1], g);
+        dz2s[tid] = z2s[tid] > 0.f ? g : 0.f;
+    }
+    __syncthreads();
+    // ---- dW2[k][c] = sum_i relu(z1[i][k]) dZ2[i][c], db2; dZ1[r][k] = (z1 > 0) sum_c dZ2[r][c] W2[k][c]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int o = tid + 1024 * j, k = o >> 5, c2 = o & 31;
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s = fmaf(fmaxf(z1s[i * 128 + k], 0.f), dz2s[i * 32 + c2], s);
+        p.gW2[o] = s;
+    }
+    if (tid < 32) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += dz2s[i * 32 + tid];
+        p.gb2[tid] = s;
+    }
+    for (int o = tid; o < nz1; o += 1024) {
+        const int r = o >> 7, k = o & 127;
+        float g = 0.f;
+#pragma unroll 8
+        for (int c2 = 0; c2 < 32; ++c2) g = fmaf(dz2s[r * 32 + c2], W2s[k * 33 + c2], g);
+        p.dz1[o] = z1s[o] > 0.f ? g : 0.f;
+    }
+}
+
+// C: rows k0 .. k0 + 31 of dW1 (= |l - r|^T dZ1, rows ascending) and columns k0 .. k0 + 31 of dL / dR (= +-sign(l - r) dZ1 W1^T,
+// c ascending; relu_in: times (input > 0), see head_input_grad_kernel); workgroup 0 also db1
+template <int NI>                // row passes of the input gradients: 2 (n <= 16) or 4
+__global__ __launch_bounds__(256) void mini_wgrad1_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                                                          const float* __restrict__ W1, const float* __restrict__ dz1,
+                                                          float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ dL,
+                                                          float* __restrict__ dR, int n, int D, int relu_in) {
+    __shared__ float Ws[MINI_KS * 129];
+    __shared__ __attribute__((aligned(16))) float dz1s[8 * NI * 128];
+    __shared__ __attribute__((aligned(16))) float ls[8 * NI * MINI_KS], rs[8 * NI * MINI_KS], dms[8 * NI * MINI_KS];
+    const int tid = threadIdx.x, k0 = blockIdx.x * MINI_KS;
+    f32x4 wv[4], dv[NI];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wv[j] = *(const f32x4*)(W1 + (size_t)k0 * 128 + (size_t)(tid + 256 * j) * 4);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int i4 = (tid + 256 * j) * 4;                   // dz1 is [n][128]: rows >= n read as zeros
+        dv[j] = i4 < n * 128 ? *(const f32x4*)(dz1 + i4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int row = tid >> 3, k4 = (tid & 7) * 4;
+    f32x4 lv = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
+    if (row < n) {
+        lv = *(const f32x4*)(L + (size_t)row * D + k0 + k4);
+        rv = *(const f32x4*)(R + (size_t)row * D + k0 + k4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = (tid + 256 * j) * 4, k = i >> 7, c = i & 127;
+        float* d = Ws + k * 129 + c;
+        d[0] = wv[j][0]; d[1] = wv[j][1]; d[2] = wv[j][2]; d[3] = wv[j][3];
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) *(f32x4*)(dz1s + (tid + 256 * j) * 4) = dv[j];
+    if (row < 8 * NI) {
+        f32x4 d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = fabsf(lv[i] - rv[i]);
+        *(f32x4*)(dms + row * MINI_KS + k4) = d;
+        *(f32x4*)(ls + row * MINI_KS + k4) = lv;
+        *(f32x4*)(rs + row * MINI_KS + k4) = rv;
+    }
+    __syncthreads();
+    {   // dW1: thread = column c, rows kh * 16 .. + 15 of the slice
+        const int c = tid & 127, kh = tid >> 7;
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int r = 0; r < n; ++r) {
+            const float d = dz1s[r * 128 + c];
+#pragma unroll
+            for (int j4 = 0; j4 < 16; j4 += 4) {
+                const f32x4 a = *(const f32x4*)(dms + r * MINI_KS + kh * 16 + j4);
+                acc[j4 + 0] = fmaf(a[0], d, acc[j4 + 0]);
+                acc[j4 + 1] = fmaf(a[1], d, acc[j4 + 1]);
+                acc[j4 + 2] = fmaf(a[2], d, acc[j4 + 2]);
+                acc[j4 + 3] = fmaf(a[3], d, acc[j4 + 3]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gW1[(size_t)(k0 + kh * 16 + j) * 128 + c] = acc[j];
+        if (blockIdx.x == 0 && tid < 128) {
+            float s = 0.f;
+            for (int r = 0; r < n; ++r) s += dz1s[r * 128 + tid];
+            gb1[tid] = s;
+        }
+    }
+    {   // input gradients: thread = input k, rows rg, rg + 8, ...
+        const int k = tid & 31, rg = tid >> 5;
+        float acc[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+        for (int c = 0; c < 128; ++c) {
+            const float w = Ws[k * 129 + c];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[i] = fmaf(dz1s[(rg + 8 * i) * 128 + c], w, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = rg + 8 * i;
+            if (r >= n) continue;
+            const float l = ls[r * MINI_KS + k], r_ = rs[r * MINI_KS + k], d = l - r_;
+            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            const float gl = acc[i] * sg, gr = -acc[i] * sg;
+            const size_t o = (size_t)r * D + k0 + k;
+            dL[o] = (relu_in && !(l > 0.f)) ? 0.f : gl;
+            dR[o] = (relu_in && !(r_ > 0.f)) ? 0.f : gr;
+        }
+    }
+}
+
+bool mini_ok(const alink_head* h, int n) {
+    return g_use_mini && h->d_mini && !h->qmode && n <= MINI_N && h->h1 == 128 && h->h2 == 32 && h->od == 2 && h->oW1 == 0 &&
+           h->D % (8 * MINI_KS) == 0;
+}
+
+int mini_step(alink_head* h, const float* L, const float* R, const float* y, const float* sw, int n, float grad_scale,
+              int relu_in, float* dL, float* dR, float* metrics, hipStream_t st) {
+    const int D = h->D, S = D / MINI_KS;
+    float* P = h->d_params;
+    float* G = h->d_grads;
+    if (n <= 16) hipLaunchKernelGGL(mini_dense1_kernel<8>, dim3(S), dim3(256), 0, st, L, R, P + h->oW1, h->d_mini, n, D);
+    else hipLaunchKernelGGL(mini_dense1_kernel<16>, dim3(S), dim3(256), 0, st, L, R, P + h->oW1, h->d_mini, n, D);
+    MiniMid mp{};
+    mp.part = h->d_mini; mp.b1 = P + h->ob1; mp.W2 = P + h->oW2; mp.b2 = P + h->ob2; mp.W3 = P + h->oW3; mp.b3 = P + h->ob3;
+    mp.y = y; mp.sw = sw; mp.gW2 = G + h->oW2; mp.gb2 = G + h->ob2; mp.gW3 = G + h->oW3; mp.gb3 = G + h->ob3; mp.dz1 = h->d_dz1;
+    mp.probs = h->d_p; mp.metrics = metrics; mp.n = n; mp.S = S; mp.grad_scale = grad_scale;
+    hipLaunchKernelGGL(mini_mid_kernel, dim3(1), dim3(1024), 0, st, mp);
+    if (n <= 16) hipLaunchKernelGGL(mini_wgrad1_kernel<2>, dim3(S), dim3(256), 0, st, L, R, P + h->oW1, h->d_dz1, G + h->oW1, G + h->ob1, dL, dR, n, D, relu_in);
+    else hipLaunchKernelGGL(mini_wgrad1_kernel<4>, dim3(S), dim3(256), 0, st, L, R, P + h->oW1, h->d_dz1, G + h->oW1, G + h->ob1, dL, dR, n, D, relu_in);
+    ALINK_HIP(hipGetLastError());
+    return ALINK_OK;
+}
+
+
 // forward (+ optional backward) on a small batch with the VALU kernels
 // The step is a chain of dependent small kernels (each ~7 us of pure latency at batch 16), so the chain
 // is kept short: |l - r| inside the first Dense, the two independent middle gradients in one launch,
@@ -1618,6 +1939,8 @@ alink_head_t* alink_head_create_ex(int d_in, int h1, int h2, int out_dim, float 
     rc |= head_alloc(h, &h->d_p, (size_t)h->cap * 2);
     rc |= head_alloc(h, &h->d_tiny, (size_t)(TINY_N / TINY_RG) * TINY_PART);
     rc |= head_alloc(h, (float**)&h->d_counter, 4);
+    if (h1 == 128 && h2 == 32 && out_dim == 2 && d_in % (8 * MINI_KS) == 0)
+        rc |= head_alloc(h, &h->d_mini, (size_t)(d_in / MINI_KS) * MINI_N * 128);
     if (rc) { delete h; return nullptr; }
     return h;
 }
@@ -1744,6 +2067,7 @@ static int train_step_launches(alink_head_t* h, const float* dev_L, const float*
 }
 
 void alink_debug_set_tiny_step(int on) { g_use_tiny = on != 0; }
+void alink_debug_set_mini_step(int on) { g_use_mini = on != 0; }
 void alink_debug_set_head_bf16_mfma(int on) { g_use_bf16_mfma = on != 0; }
 
 int alink_head_set_graph(alink_head_t* h, int on) {
@@ -1835,16 +2159,39 @@ int alink_head_set_compute_dtype(alink_head_t* h, int dtype) {
 }
 int alink_head_get_compute_dtype(const alink_head_t* h) { return h && h->qmode ? ALINK_DT_BF16 : ALINK_DT_F32; }
 
-int alink_head_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, int n, float* dev_dL,
-                           float* dev_dR, void* stream) {
+static int input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, int n, float* dev_dL, float* dev_dR, int relu_in,
+                       void* stream) {
     ALINK_REQUIRE(h && dev_L && dev_R && dev_dL && dev_dR, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(n > 0 && n <= h->cap, ALINK_EINVAL, "batch of %d rows outside 1..%d", n, h->cap);
     ALINK_REQUIRE(!h->qmode, ALINK_ESTATE, "input gradients (the SmallRes tower) are float32 only");
     DeviceGuard dg(h->device);
     hipLaunchKernelGGL(head_input_grad_kernel, dim3((h->D + 63) / 64, (n + 15) / 16), dim3(256), 0, (hipStream_t)stream, dev_L,
-                       dev_R, h->d_dz1, h->d_params + h->oW1, dev_dL, dev_dR, n, h->D, h->h1);
+                       dev_R, h->d_dz1, h->d_params + h->oW1, dev_dL, dev_dR, n, h->D, h->h1, relu_in);
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
+}
+int alink_head_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, int n, float* dev_dL,
+                           float* dev_dR, void* stream) {
+    return input_grads(h, dev_L, dev_R, n, dev_dL, dev_dR, 0, stream);
+}
+int alink_head_input_grads_relu(alink_head_t* h, const float* dev_L, const float* dev_R, int n, float* dev_dL,
+                                float* dev_dR, void* stream) {
+    return input_grads(h, dev_L, dev_R, n, dev_dL, dev_dR, 1, stream);
+}
+
+int alink_head_train_step_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
+                                      const float* dev_sw, int n, float grad_scale, int relu_inputs, float* dev_dL,
+                                      float* dev_dR, float* dev_metrics, void* stream) {
+    ALINK_REQUIRE(h && dev_L && dev_R && dev_y && dev_metrics && dev_dL && dev_dR, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(n > 0 && n <= h->cap, ALINK_EINVAL, "batch of %d rows outside 1..%d", n, h->cap);
+    ALINK_REQUIRE(!h->qmode, ALINK_ESTATE, "input gradients (the SmallRes tower) are float32 only");
+    if (mini_ok(h, n)) {
+        DeviceGuard dg(h->device);
+        return mini_step(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, relu_inputs != 0, dev_dL, dev_dR, dev_metrics, (hipStream_t)stream);
+    }
+    const int rc = alink_head_train_step(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, 0, dev_metrics, stream);
+    if (rc) return rc;
+    return input_grads(h, dev_L, dev_R, n, dev_dL, dev_dR, relu_inputs != 0, stream);
 }
 
 int alink_head_eval(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y, int n,

@@ -397,6 +397,11 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
 // out[m][n] = epilogue( sum_z part[z][m][n] ): 32 outputs x 8 slab groups per workgroup — group g adds slabs g, g + 8, ...
 // in ascending order, the eight group sums are added in group order (a fixed order whatever the grid: deterministic); the
 // loads of a group are independent, so a reduction over 128 slabs is 16 dependent adds per thread, not 128 round trips.
+// (Tried in round 6 and dropped: the tile's last slab to arrive — an arrival counter per tile — summing the slabs inside the
+// GEMM launch.  Same bits, one launch less, but slower: with a __threadfence() per workgroup every L2 is written back and
+// invalidated under the kernels running beside it (a conv input gradient 18 -> 94 us, the side stream's Adadelta 20 -> 88 us);
+// with device-scope slab stores and loads instead, the one finishing workgroup's round trips outweigh this launch (Dense
+// forward 18.6 + 5.0 -> 43.6 us, conv4 12.6 + 5.9 -> 21.2 us).  The sum is parallel work; a launch is how it stays parallel.)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long long MN, int ldc,
                                                             int N, int S, const float* __restrict__ bias, int relu,
                                                             const float* __restrict__ act, int accumulate, const float* __restrict__ alpha,

@@ -21,8 +21,9 @@
 using namespace alink;
 
 extern "C" {
-int alink_head_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, int n, float* dev_dL,
-                           float* dev_dR, void* stream);
+int alink_head_train_step_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
+                                      const float* dev_sw, int n, float grad_scale, int relu_inputs, float* dev_dL,
+                                      float* dev_dR, float* dev_metrics, void* stream);
 float* alink_head_params_dev(alink_head_t* h);
 }
 
@@ -78,12 +79,6 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dpool, const uint8_t* 
     dact[i] = act[i] > 0.f ? g : 0.f;          // relu of the conv that produced `act`
 }
 
-// dz = dout * relu'(z);  gw[k][c] = sum_r a[r][k] dz[r][c];  gb[c] = sum_r dz[r][c]
-__global__ void relu_mask_kernel(const float* __restrict__ z, const float* __restrict__ d, float* __restrict__ dz,
-                                 long long n) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dz[i] = z[i] > 0.f ? d[i] : 0.f;
-}
 __global__ void adadelta2_kernel(float* __restrict__ prm, const float* __restrict__ g, float* __restrict__ a,
                                  float* __restrict__ d, size_t n, float lr, float rho, float eps) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -207,7 +202,6 @@ struct alink_smallres {
     float *d_p = nullptr, *d_g = nullptr, *d_a = nullptr, *d_d = nullptr;   // tower params / grads / Adadelta
     // activations for up to 2*MAXN tower passes
     float *a1 = nullptr, *a2 = nullptr, *p1 = nullptr, *a3 = nullptr, *a4 = nullptr, *p2 = nullptr, *f = nullptr;
-    float *dfeat = nullptr;
     // activation gradients, one buffer per tensor (round 6: a ping-pong pair until then — the weight gradients now run on
     // a side stream beside the input-gradient chain, so a dz must stay put until its weight gradient has read it)
     float *gf = nullptr, *gp2 = nullptr, *ga4 = nullptr, *ga3 = nullptr, *gp1 = nullptr, *ga2 = nullptr, *ga1 = nullptr;
@@ -371,7 +365,6 @@ alink_smallres_t* alink_smallres_create(int img_h, int img_w, int feat, float lr
     rc |= sr_alloc(m, &m->a4, nb * m->H3 * m->W3 * 64);
     rc |= sr_alloc(m, &m->p2, nb * m->flat);
     rc |= sr_alloc(m, &m->f, nb * feat);
-    rc |= sr_alloc(m, &m->dfeat, nb * feat);
     rc |= sr_alloc(m, &m->gf, nb * feat);
     rc |= sr_alloc(m, &m->gp2, nb * m->flat);
     rc |= sr_alloc(m, &m->ga4, nb * m->H3 * m->W3 * 64);
@@ -468,8 +461,9 @@ static int train_step_launches(alink_smallres_t* m, const float* dev_L, const fl
     if (rc) return rc;
     float* fL = m->f;
     float* fR = m->f + (size_t)n * m->feat;
-    if ((rc = alink_head_train_step(m->head, fL, fR, dev_y, dev_sw, n, grad_scale, 0, dev_metrics, stream))) return rc;
-    if ((rc = alink_head_input_grads(m->head, fL, fR, n, m->dfeat, m->dfeat + (size_t)n * m->feat, stream))) return rc;
+    // the head's gradients, and dz of the tower's Dense(feat, relu) straight from the head: d loss / d feature times relu'(feature)
+    if ((rc = alink_head_train_step_input_grads(m->head, fL, fR, dev_y, dev_sw, n, grad_scale, 1, m->gf, m->gf + (size_t)n * m->feat,
+                                                dev_metrics, stream))) return rc;
     // The shared tower saw 2n images ([L ; R] contiguous in every activation buffer): ONE backward pass over 2n images
     // gives both branches' weight gradients.  Two chains from here: the input gradients (dz of a layer from the dz of
     // the next) on the caller's stream, and the weight gradients — each needs only its layer's input and dz — on a side
@@ -487,8 +481,6 @@ static int train_step_launches(alink_smallres_t* m, const float* dev_L, const fl
     float* G = m->d_g;
     const int nb = 2 * n;
     const float keep_scale = 1.f / (1.f - 0.25f);
-    hipLaunchKernelGGL(relu_mask_kernel, g1((long long)nb * m->feat), dim3(256), 0, st, m->f, m->dfeat, m->gf,
-                       (long long)nb * m->feat);
     if ((rc = fork(0))) return rc;
     {   // gW[flat][feat] = p2^T . dz ; gb = column sums
         GemmP g{};

@@ -487,11 +487,12 @@ class DenseHead(KerasFitMixin):
     def dp_apply(self):
         _abi.check(self.lib.alink_head_apply_update(self.h, _abi.current_stream(self.device)), "alink_head_apply_update")
 
-    def input_gradients(self, L, R, y):
+    def input_gradients(self, L, R, y, sample_weight=None):
         """EXTENSION (FGSM / PGD): d(loss)/dL, d(loss)/dR of the Keras loss of this batch (mean over the
         batch), parameters untouched.  L, R: (n, d_in) CUDA float32; y: (n, out_dim) targets."""
         torch = self.torch
         L, R, yd = self._dev(L), self._dev(R), self._dev(y)
+        swd = None if sample_weight is None else self._dev(np.asarray(sample_weight, dtype=np.float32))
         n = L.shape[0]
         dL, dR = torch.empty_like(L), torch.empty_like(R)
         # the input-gradient kernels are float32 only; a head in the bf16 compute mode (BASELINE configs[4]: gradient-attack
@@ -501,10 +502,9 @@ class DenseHead(KerasFitMixin):
         if quantised:
             self.set_compute_dtype("f32")
         try:
-            _abi.check(self.lib.alink_head_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), None, n, 0.0, 0,
-                                                      _abi.ptr(self._metrics), _abi.current_stream(self.device)), "alink_head_train_step")
-            _abi.check(self.lib.alink_head_input_grads(self.h, _abi.ptr(L), _abi.ptr(R), n, _abi.ptr(dL), _abi.ptr(dR),
-                                                       _abi.current_stream(self.device)), "alink_head_input_grads")
+            _abi.check(self.lib.alink_head_train_step_input_grads(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n, 0.0, 0,
+                                                                  _abi.ptr(dL), _abi.ptr(dR), _abi.ptr(self._metrics),
+                                                                  _abi.current_stream(self.device)), "alink_head_train_step_input_grads")
         finally:
             if quantised:
                 self.set_compute_dtype("bf16")

@@ -326,6 +326,18 @@ int alink_head_set_graph(alink_head_t* h, int on);
  * SmallRes, code/siamese.py:158-168): dL, dR are (n, d_in) f32. */
 int alink_head_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, int n,
                            float* dev_dL, float* dev_dR, void* stream);
+/* The same for inputs that are the outputs of a ReLU (SmallRes' Dense(2048, relu), code/siamese.py:156):
+ * gradients w.r.t. that layer's pre-activations, i.e. the above times (input > 0), in the same launch. */
+int alink_head_input_grads_relu(alink_head_t* h, const float* dev_L, const float* dev_R, int n,
+                                float* dev_dL, float* dev_dR, void* stream);
+/* alink_head_train_step(apply = 0) and alink_head_input_grads (relu_inputs: ..._relu) as ONE call: what an end-to-end
+ * model's step needs from its head (SmallRes.trainModel, code/siamese.py:158-180).  For SmallRes' own head shape
+ * (128 / 32 / 2 outputs on a multiple of 256 features, at most 32 pairs, float32) the pair is three launches instead
+ * of seven; other shapes run the two calls above.  Gradients are left in alink_head_grads_dev, the parameters
+ * untouched (alink_head_apply_update applies them). */
+int alink_head_train_step_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
+                                      const float* dev_sw, int n, float grad_scale, int relu_inputs,
+                                      float* dev_dL, float* dev_dR, float* dev_metrics, void* stream);
 /* Keras test_on_batch: {loss, binary_accuracy} without touching parameters. */
 int alink_head_eval(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
                     int n, float* dev_metrics, void* stream);

@@ -54,6 +54,8 @@ void alink_debug_set_shard_stagger(int on);
 /* ---- the pair head (csrc/head.hip) ------------------------------------------------------------------------------------ */
 /* 0: batches <= 32 on the generic train chain instead of the three-launch tiny step */
 void alink_debug_set_tiny_step(int on);
+/* 0: alink_head_train_step_input_grads on the generic chain (train step, then input gradients) for SmallRes' head shape too */
+void alink_debug_set_mini_step(int on);
 /* 0: the bf16 compute mode's predict on the f32-input kernel with in-flight rounding instead of head_fwd_bf16_kernel */
 void alink_debug_set_head_bf16_mfma(int on);
 

@@ -378,3 +378,60 @@ def test_custom_train_model_over_index_batches_equals_the_step_by_step_form(gpu)
         ends.append(net.siamese_net.get_weights())
     for a, b in zip(*ends):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("d", [2048, 256])
+def test_three_launch_step_of_smallres_head_matches_generic_chain_and_oracle(gpu, d):
+    """alink_head_train_step_input_grads: gradients-only train step + input gradients in one call.  For SmallRes' head shape
+    (128 / 32 / 2 on a multiple of 256 features, at most 32 pairs) it is three launches — Dense1 partial sums per 32 inputs, ONE
+    workgroup for everything whose operands fit in LDS, dW1 + input gradients per 32 inputs — instead of the generic chain's
+    seven (alink_debug_set_mini_step(0) brings those back).  Same sums in a different order for Dense1 / Dense2: parameters'
+    gradients, input gradients (with and without the ReLU mask of SmallRes' feature layer) and metrics agree to rounding
+    with the generic chain, and with the NumPy oracle's gradients; 33 pairs are beyond the path and take the generic one."""
+    from oracle import siamese_head as O
+    g, o = _pair(d, 128, 32, seed=5)
+    lib = g.lib
+    rng = np.random.RandomState(8)
+    for n in (1, 5, 16, 17, 32, 33):
+        L = np.abs(rng.randn(n, d)).astype(np.float32) * (rng.rand(n, d) > 0.4)      # post-ReLU features: zeros included
+        R = np.abs(rng.randn(n, d)).astype(np.float32) * (rng.rand(n, d) > 0.4)
+        L, R = L.astype(np.float32), R.astype(np.float32)
+        R[:, :7] = L[:, :7]                                                          # l == r: the abs gradient is 0 there
+        y = np.eye(2, dtype=np.float32)[rng.randint(0, 2, n)]
+        sw = None
+        if n in (5, 17, 32):
+            sw = rng.rand(n).astype(np.float32)
+            sw[::4] = 0.0
+        out = {}
+        for mini in (1, 0):
+            lib.alink_debug_set_mini_step(mini)
+            try:
+                dL, dR = g.input_gradients(L, R, y, sample_weight=sw)
+                met = g._metrics.cpu().numpy()[:2].copy()
+                Ld, Rd, yd = g._dev(L), g._dev(R), g._dev(y)
+                swd = None if sw is None else g._dev(sw)
+                mL, mR = torch.empty_like(Ld), torch.empty_like(Rd)
+                gpu.check(lib.alink_head_train_step_input_grads(g.h, gpu.ptr(Ld), gpu.ptr(Rd), gpu.ptr(yd), gpu.ptr(swd), n, 0.0, 1,
+                                                                gpu.ptr(mL), gpu.ptr(mR), gpu.ptr(g._metrics),
+                                                                gpu.current_stream(g.device)))
+                out[mini] = (dL.cpu().numpy(), dR.cpu().numpy(), g.grads_tensor().cpu().numpy().copy(), met,
+                             mL.cpu().numpy(), mR.cpu().numpy())
+            finally:
+                lib.alink_debug_set_mini_step(1)
+        a, b = out[1], out[0]
+        scale = max(np.abs(b[2]).max(), 1e-12)
+        for x, z in zip(a[:3], b[:3]):
+            np.testing.assert_allclose(x, z, rtol=2e-4, atol=2e-6 * max(np.abs(z).max(), 1e-12))
+        np.testing.assert_allclose(a[3], b[3], rtol=2e-6, atol=1e-7)
+        if n == 33:
+            for x, z in zip(a, b):
+                assert np.array_equal(x, z)
+        # the masked form: the plain input gradients where the input is positive, zero elsewhere
+        assert np.array_equal(a[4], np.where(L > 0, a[0], 0.0).astype(np.float32))
+        assert np.array_equal(a[5], np.where(R > 0, a[1], 0.0).astype(np.float32))
+        assert np.all(a[0][:, :7] == 0) and np.all(a[1][:, :7] == 0)
+        # the oracle's parameter gradients of the same batch
+        ref, loss, acc = O.gradients(o.get_weights(), L, R, y, sw, dtype=np.float64)
+        flat = np.concatenate([np.asarray(t).ravel() for t in ref])
+        np.testing.assert_allclose(a[2], flat, rtol=1e-3, atol=1e-5 * scale)
+        np.testing.assert_allclose(a[3], [loss, acc], rtol=1e-5, atol=1e-6)
