@@ -101,12 +101,13 @@ PROTOTYPES = {
     "alink_roc_counts": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "alink_head_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp]),
     "alink_head_apply_update": (_i, [_vp, _vp]),
+    "alink_head_apply_update_with": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "alink_head_set_graph": (_i, [_vp, _i]),
     "alink_head_eval": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "alink_head_custom_train_steps": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "alink_head_input_grads": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "alink_head_input_grads_relu": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
-    "alink_head_train_step_input_grads": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "alink_head_train_step_input_grads": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "alink_smallres_create": (_vp, [_i, _i, _i, _f, _f, _f]),
     "alink_smallres_destroy": (None, [_vp]),
     "alink_smallres_num_params": (_sz, [_vp]),

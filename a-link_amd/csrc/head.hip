@@ -809,6 +809,24 @@ __global__ void adadelta_kernel(float* __restrict__ prm, const float* __restrict
     a[i] = na;
 }
 
+// One launch for the update of TWO parameter blocks (an end-to-end model's tower, then the head): workgroups [0, nb2) take block 2
+__global__ void adadelta_two_kernel(float* __restrict__ p2, const float* __restrict__ g2, float* __restrict__ a2, float* __restrict__ d2,
+                                    size_t n2, float* __restrict__ p1, const float* __restrict__ g1v, float* __restrict__ a1,
+                                    float* __restrict__ d1, size_t n1, int nb2, float lr, float rho, float eps) {
+    const bool second = (int)blockIdx.x < nb2;
+    const size_t i = (size_t)(second ? blockIdx.x : blockIdx.x - nb2) * 256 + threadIdx.x;
+    if (i >= (second ? n2 : n1)) return;
+    float* prm = second ? p2 : p1;
+    float* a = second ? a2 : a1;
+    float* d = second ? d2 : d1;
+    const float gi = second ? g2[i] : g1v[i];
+    const float na = rho * a[i] + (1.f - rho) * gi * gi;
+    const float u = gi * sqrtf(d[i] + eps) / sqrtf(na + eps);
+    prm[i] = prm[i] - lr * u;
+    d[i] = rho * d[i] + (1.f - rho) * u * u;
+    a[i] = na;
+}
+
 inline dim3 g1(long long n) { return dim3((unsigned)((n + 255) / 256), 1, 1); }
 
 int head_alloc(alink_head* h, float** p, size_t count) {
@@ -1614,18 +1632,31 @@ __global__ __launch_bounds__(1024) void mini_mid_kernel(const MiniMid p) {
     else if (tid >= 128 && tid < 160) small = p.b2[tid - 128];
     else if (tid >= 192 && tid < 192 + n) small = p.sw ? p.sw[tid - 192] : 1.f;
     else if (tid >= 256 && tid < 256 + 2 * n) small = p.y[tid - 256];
-    // z1[r][c] = b1[c] + sum over slices: eight interleaved groups (slices g, g + 8, ... ascending), then the groups pairwise
-    for (int o = tid; o < nz1; o += 1024) {
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float* pp = p.part + o;
-        for (int s0 = 0; s0 < S; s0 += 8) {
-            float t[8];
+    // z1[r][c] = b1[c] + sum over slices: eight interleaved groups (slices g, g + 8, ... ascending), then the groups pairwise.
+    // Two outputs at a time, 16 slices of each per batch of loads: 32 loads in flight per thread (one output and 8 slices at a
+    // time was 16 dependent round trips, most of this kernel's 14 us).
+    for (int o = tid; o < nz1; o += 2048) {
+        const bool two = o + 1024 < nz1;
+        const float* pa = p.part + o;
+        const float* pb = p.part + (two ? o + 1024 : o);
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s0 = 0;
+        for (; s0 + 16 <= S; s0 += 16) {
+            float ta[16], tb[16];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) t[g] = pp[(size_t)(s0 + g) * nz1];
+            for (int g = 0; g < 16; ++g) { ta[g] = pa[(size_t)(s0 + g) * nz1]; tb[g] = pb[(size_t)(s0 + g) * nz1]; }
 #pragma unroll
-            for (int g = 0; g < 8; ++g) a[g] += t[g];
+            for (int g = 0; g < 16; ++g) { a[g & 7] += ta[g]; b[g & 7] += tb[g]; }
+        }
+        if (s0 < S) {                              // (S is a multiple of 8)
+            float ta[8], tb[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { ta[g] = pa[(size_t)(s0 + g) * nz1]; tb[g] = pb[(size_t)(s0 + g) * nz1]; }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { a[g] += ta[g]; b[g] += tb[g]; }
         }
         z1s[o] = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + p.b1[o & 127];
+        if (two) z1s[o + 1024] = (((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]))) + p.b1[o & 127];
     }
     {
         const int k = tid >> 3, c = (tid & 7) * 4;
@@ -1739,7 +1770,7 @@ template <int NI>                // row passes of the input gradients: 2 (n <= 1
 __global__ __launch_bounds__(256) void mini_wgrad1_kernel(const float* __restrict__ L, const float* __restrict__ R,
                                                           const float* __restrict__ W1, const float* __restrict__ dz1,
                                                           float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ dL,
-                                                          float* __restrict__ dR, int n, int D, int relu_in) {
+                                                          float* __restrict__ dR, float* __restrict__ colsum, int n, int D, int relu_in) {
     __shared__ float Ws[MINI_KS * 129];
     __shared__ __attribute__((aligned(16))) float dz1s[8 * NI * 128];
     __shared__ __attribute__((aligned(16))) float ls[8 * NI * MINI_KS], rs[8 * NI * MINI_KS], dms[8 * NI * MINI_KS];
@@ -1817,10 +1848,31 @@ __global__ __launch_bounds__(256) void mini_wgrad1_kernel(const float* __restric
             const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
             const float gl = acc[i] * sg, gr = -acc[i] * sg;
             const size_t o = (size_t)r * D + k0 + k;
-            dL[o] = (relu_in && !(l > 0.f)) ? 0.f : gl;
-            dR[o] = (relu_in && !(r_ > 0.f)) ? 0.f : gr;
+            const float vl = (relu_in && !(l > 0.f)) ? 0.f : gl, vr = (relu_in && !(r_ > 0.f)) ? 0.f : gr;
+            dL[o] = vl;
+            dR[o] = vr;
+            ls[r * MINI_KS + k] = vl;              // (this thread's own slot: nobody else reads l, r of (r, k))
+            rs[r * MINI_KS + k] = vr;
         }
     }
+    if (!colsum) return;                           // (uniform)
+    __syncthreads();
+    if (tid < MINI_KS) {                           // column sums over the 2n rows [dL ; dR], rows ascending (colsum_two_kernel's order)
+        float t = 0.f;
+        for (int r = 0; r < n; ++r) t += ls[r * MINI_KS + tid];
+        for (int r = 0; r < n; ++r) t += rs[r * MINI_KS + tid];
+        colsum[k0 + tid] = t;
+    }
+}
+
+// out[k] = sum_r dL[r][k] + sum_r dR[r][k], rows ascending, dL's first: the column sums of the 2n x D matrix [dL ; dR]
+__global__ void colsum_two_kernel(const float* __restrict__ dL, const float* __restrict__ dR, float* __restrict__ out, int n, int D) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= D) return;
+    float t = 0.f;
+    for (int r = 0; r < n; ++r) t += dL[(size_t)r * D + k];
+    for (int r = 0; r < n; ++r) t += dR[(size_t)r * D + k];
+    out[k] = t;
 }
 
 bool mini_ok(const alink_head* h, int n) {
@@ -1829,7 +1881,7 @@ bool mini_ok(const alink_head* h, int n) {
 }
 
 int mini_step(alink_head* h, const float* L, const float* R, const float* y, const float* sw, int n, float grad_scale,
-              int relu_in, float* dL, float* dR, float* metrics, hipStream_t st) {
+              int relu_in, float* dL, float* dR, float* colsum, float* metrics, hipStream_t st) {
     const int D = h->D, S = D / MINI_KS;
     float* P = h->d_params;
     float* G = h->d_grads;
@@ -1840,8 +1892,8 @@ int mini_step(alink_head* h, const float* L, const float* R, const float* y, con
     mp.y = y; mp.sw = sw; mp.gW2 = G + h->oW2; mp.gb2 = G + h->ob2; mp.gW3 = G + h->oW3; mp.gb3 = G + h->ob3; mp.dz1 = h->d_dz1;
     mp.probs = h->d_p; mp.metrics = metrics; mp.n = n; mp.S = S; mp.grad_scale = grad_scale;
     hipLaunchKernelGGL(mini_mid_kernel, dim3(1), dim3(1024), 0, st, mp);
-    if (n <= 16) hipLaunchKernelGGL(mini_wgrad1_kernel<2>, dim3(S), dim3(256), 0, st, L, R, P + h->oW1, h->d_dz1, G + h->oW1, G + h->ob1, dL, dR, n, D, relu_in);
-    else hipLaunchKernelGGL(mini_wgrad1_kernel<4>, dim3(S), dim3(256), 0, st, L, R, P + h->oW1, h->d_dz1, G + h->oW1, G + h->ob1, dL, dR, n, D, relu_in);
+    if (n <= 16) hipLaunchKernelGGL(mini_wgrad1_kernel<2>, dim3(S), dim3(256), 0, st, L, R, P + h->oW1, h->d_dz1, G + h->oW1, G + h->ob1, dL, dR, colsum, n, D, relu_in);
+    else hipLaunchKernelGGL(mini_wgrad1_kernel<4>, dim3(S), dim3(256), 0, st, L, R, P + h->oW1, h->d_dz1, G + h->oW1, G + h->ob1, dL, dR, colsum, n, D, relu_in);
     ALINK_HIP(hipGetLastError());
     return ALINK_OK;
 }
@@ -2135,6 +2187,18 @@ int alink_head_apply_update(alink_head_t* h, void* stream) {
     return ALINK_OK;
 }
 
+int alink_head_apply_update_with(alink_head_t* h, float* dev_params2, const float* dev_grads2, float* dev_acc2, float* dev_dacc2,
+                                 size_t n2, void* stream) {
+    ALINK_REQUIRE(h && dev_params2 && dev_grads2 && dev_acc2 && dev_dacc2 && n2 > 0, ALINK_EINVAL, "NULL argument");
+    DeviceGuard dg(h->device);
+    const int nb2 = (int)((n2 + 255) / 256), nb1 = (int)((h->nparams + 255) / 256);
+    hipLaunchKernelGGL(adadelta_two_kernel, dim3(nb2 + nb1), dim3(256), 0, (hipStream_t)stream, dev_params2, dev_grads2, dev_acc2,
+                       dev_dacc2, n2, h->d_params, h->d_grads, h->d_acc, h->d_dacc, h->nparams, nb2, h->lr, h->rho, h->eps);
+    ALINK_HIP(hipGetLastError());
+    h->packed_dirty = h->pq_dirty = h->pqf_dirty = true;
+    return ALINK_OK;
+}
+
 int alink_head_set_compute_dtype(alink_head_t* h, int dtype) {
     ALINK_REQUIRE(h, ALINK_EINVAL, "NULL head");
     ALINK_REQUIRE(dtype == ALINK_DT_F32 || dtype == ALINK_DT_BF16, ALINK_EINVAL, "compute dtype must be ALINK_DT_F32 or ALINK_DT_BF16");
@@ -2181,17 +2245,23 @@ int alink_head_input_grads_relu(alink_head_t* h, const float* dev_L, const float
 
 int alink_head_train_step_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
                                       const float* dev_sw, int n, float grad_scale, int relu_inputs, float* dev_dL,
-                                      float* dev_dR, float* dev_metrics, void* stream) {
+                                      float* dev_dR, float* dev_colsum, float* dev_metrics, void* stream) {
     ALINK_REQUIRE(h && dev_L && dev_R && dev_y && dev_metrics && dev_dL && dev_dR, ALINK_EINVAL, "NULL argument");
     ALINK_REQUIRE(n > 0 && n <= h->cap, ALINK_EINVAL, "batch of %d rows outside 1..%d", n, h->cap);
     ALINK_REQUIRE(!h->qmode, ALINK_ESTATE, "input gradients (the SmallRes tower) are float32 only");
     if (mini_ok(h, n)) {
         DeviceGuard dg(h->device);
-        return mini_step(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, relu_inputs != 0, dev_dL, dev_dR, dev_metrics, (hipStream_t)stream);
+        return mini_step(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, relu_inputs != 0, dev_dL, dev_dR, dev_colsum, dev_metrics, (hipStream_t)stream);
     }
-    const int rc = alink_head_train_step(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, 0, dev_metrics, stream);
+    int rc = alink_head_train_step(h, dev_L, dev_R, dev_y, dev_sw, n, grad_scale, 0, dev_metrics, stream);
     if (rc) return rc;
-    return input_grads(h, dev_L, dev_R, n, dev_dL, dev_dR, relu_inputs != 0, stream);
+    if ((rc = input_grads(h, dev_L, dev_R, n, dev_dL, dev_dR, relu_inputs != 0, stream))) return rc;
+    if (dev_colsum) {
+        DeviceGuard dg(h->device);
+        hipLaunchKernelGGL(colsum_two_kernel, g1(h->D), dim3(256), 0, (hipStream_t)stream, dev_dL, dev_dR, dev_colsum, n, h->D);
+        ALINK_HIP(hipGetLastError());
+    }
+    return ALINK_OK;
 }
 
 int alink_head_eval(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y, int n,

@@ -36,7 +36,6 @@ struct GemmP {
 void       gemm32_plan_split(GemmP& p, int max_split);
 size_t     gemm32_workspace_floats(const GemmP& p);
 hipError_t launch_gemm32(const GemmP& p, float* workspace, hipStream_t st);
-hipError_t launch_colsum(const float* dz, float* gb, int n, int C, hipStream_t st);
 // out[i] = sum_z part[z][i], i < MN, z < S — the split-K slab sum on its own (fixed order: 8 interleaved groups, then the groups)
 hipError_t launch_slab_sum(const float* part, float* out, long long MN, int S, hipStream_t st);
 

@@ -428,15 +428,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     out[i] = s;
 }
 
-// gb[c] = sum_r dz[r][c] (fixed order)
-__global__ void colsum_kernel(const float* __restrict__ dz, float* __restrict__ gb, int n, int C) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int r = 0; r < n; ++r) s += dz[(size_t)r * C + c];
-    gb[c] = s;
-}
-
 inline bool narrow(const GemmP& p) { return p.N <= 32; }      // 128 x 32 tiles for layers with <= 32 outputs
 inline long long tiles_of(const GemmP& p) {
     const int bm = narrow(p) ? 128 : 64, bn = narrow(p) ? 32 : 64;
@@ -547,11 +538,6 @@ hipError_t launch_slab_sum(const float* part, float* out, long long MN, int S, h
     if (!part || !out || MN <= 0 || S <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN + 31) / 32)), dim3(256), 0, st, part, out, MN, (int)MN, (int)MN, S,
                        (const float*)nullptr, 0, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr);
-    return hipGetLastError();
-}
-
-hipError_t launch_colsum(const float* dz, float* gb, int n, int C, hipStream_t st) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dz, gb, n, C);
     return hipGetLastError();
 }
 

@@ -23,8 +23,10 @@ using namespace alink;
 extern "C" {
 int alink_head_train_step_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
                                       const float* dev_sw, int n, float grad_scale, int relu_inputs, float* dev_dL,
-                                      float* dev_dR, float* dev_metrics, void* stream);
+                                      float* dev_dR, float* dev_colsum, float* dev_metrics, void* stream);
 float* alink_head_params_dev(alink_head_t* h);
+int alink_head_apply_update_with(alink_head_t* h, float* dev_params2, const float* dev_grads2, float* dev_acc2, float* dev_dacc2,
+                                 size_t n2, void* stream);
 }
 
 namespace {
@@ -206,7 +208,7 @@ struct alink_smallres {
     // a side stream beside the input-gradient chain, so a dz must stay put until its weight gradient has read it)
     float *gf = nullptr, *gp2 = nullptr, *ga4 = nullptr, *ga3 = nullptr, *gp1 = nullptr, *ga2 = nullptr, *ga1 = nullptr;
     hipStream_t side = nullptr;        // weight gradients (independent of the dz chain once their dz exists)
-    hipEvent_t ev_dz[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, ev_side = nullptr, ev_prev = nullptr;   // ev_prev: the dense layer's input gradient has read W
+    hipEvent_t ev_dz[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, ev_side = nullptr;
     float* ws2 = nullptr;              // split-K slabs of the side stream's GEMMs
     // the whole train step as a captured graph, per distinct (operand pointers, n, flags, lr) — OPTIONAL and off: a step is ~40
     // short launches on two streams, the host needs ~170 us to enqueue them and the device runs dry in the backward; but a replayed
@@ -230,7 +232,6 @@ struct alink_smallres {
         if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
         for (hipEvent_t e : ev_dz) if (e) (void)hipEventDestroy(e);
         if (ev_side) (void)hipEventDestroy(ev_side);
-        if (ev_prev) (void)hipEventDestroy(ev_prev);
         for (void* p : allocs) (void)hipFree(p);
         if (head) alink_head_destroy(head);
     }
@@ -384,7 +385,6 @@ alink_smallres_t* alink_smallres_create(int img_h, int img_w, int feat, float lr
     bool ok = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess;
     for (hipEvent_t& e : m->ev_dz) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&m->ev_prev, hipEventDisableTiming) == hipSuccess;
     if (!ok) { set_error("SmallRes: side stream / events could not be created"); delete m; return nullptr; }
     return m;
 }
@@ -449,6 +449,8 @@ int alink_smallres_eval(alink_smallres_t* m, const float* dev_L, const float* de
 
 static bool g_smallres_overlap = true;
 void alink_debug_set_smallres_overlap(int on) { g_smallres_overlap = on != 0; }      // include/alink_hip_debug.h
+static bool g_smallres_one_update = true;
+void alink_debug_set_smallres_one_update(int on) { g_smallres_one_update = on != 0; }
 
 static int train_step_launches(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
                                const float* dev_sw, int n, int prescale, const uint8_t* dev_masks, float grad_scale,
@@ -461,9 +463,10 @@ static int train_step_launches(alink_smallres_t* m, const float* dev_L, const fl
     if (rc) return rc;
     float* fL = m->f;
     float* fR = m->f + (size_t)n * m->feat;
-    // the head's gradients, and dz of the tower's Dense(feat, relu) straight from the head: d loss / d feature times relu'(feature)
+    // the head's gradients, and dz of the tower's Dense(feat, relu) straight from the head: d loss / d feature times relu'(feature),
+    // with its column sums — that layer's bias gradient (a launch of its own on the side stream until round 6)
     if ((rc = alink_head_train_step_input_grads(m->head, fL, fR, dev_y, dev_sw, n, grad_scale, 1, m->gf, m->gf + (size_t)n * m->feat,
-                                                dev_metrics, stream))) return rc;
+                                                m->d_g + m->oDB, dev_metrics, stream))) return rc;
     // The shared tower saw 2n images ([L ; R] contiguous in every activation buffer): ONE backward pass over 2n images
     // gives both branches' weight gradients.  Two chains from here: the input gradients (dz of a layer from the dz of
     // the next) on the caller's stream, and the weight gradients — each needs only its layer's input and dz — on a side
@@ -482,12 +485,11 @@ static int train_step_launches(alink_smallres_t* m, const float* dev_L, const fl
     const int nb = 2 * n;
     const float keep_scale = 1.f / (1.f - 0.25f);
     if ((rc = fork(0))) return rc;
-    {   // gW[flat][feat] = p2^T . dz ; gb = column sums
+    {   // gW[flat][feat] = p2^T . dz
         GemmP g{};
         g.A = m->p2; g.B = m->gf; g.C = G + m->oDW; g.M = m->flat; g.N = m->feat; g.K = nb;
         g.lda = m->flat; g.ldb = m->feat; g.ldc = m->feat; g.amode = A_COL; g.bmode = B_ROW;
         if ((rc = run_gemm(m, g, 1, sw, wsw))) return rc;
-        ALINK_HIP(launch_colsum(m->gf, G + m->oDB, nb, m->feat, sw));
     }
     {   // d(p2)[nb][flat] = dz . W^T
         GemmP g{};
@@ -496,19 +498,18 @@ static int train_step_launches(alink_smallres_t* m, const float* dev_L, const fl
         if ((rc = run_gemm(m, g, 16, st))) return rc;
     }
     const bool early = two && apply;
+    hipLaunchKernelGGL(pool_bwd_kernel, g1((long long)nb * m->H3 * m->W3 * 64), dim3(256), 0, st, m->gp2, m->arg2, m2,
+                       keep_scale, m->a4, m->ga4, nb, m->H3, m->W3, 64);
+    if ((rc = fork(1))) return rc;
     if (early) {
         // The wide Dense layer is 99 % of the parameters (flat x feat = 4.7 M of 4.8 M at 32 x 32 / 2048) and its update 20 us
-        // of HBM traffic: it starts on the side stream as soon as its gradient exists and the input gradient above has read
-        // the old W — beside the dz chain instead of after it.
-        ALINK_HIP(hipEventRecord(m->ev_prev, st));
-        ALINK_HIP(hipStreamWaitEvent(m->side, m->ev_prev, 0));
+        // of HBM traffic: it runs on the side stream beside the dz chain instead of after it — behind this fork, which says both
+        // that its gradient exists (the side stream's own order) and that the input gradient above has read the old W (an
+        // event of its own for that cost the dz chain ~6 us: a record in a stream delays the stream's next kernel by that much).
         const size_t nd = m->ntower - m->oDW;
         hipLaunchKernelGGL(adadelta2_kernel, g1((long long)nd), dim3(256), 0, m->side, m->d_p + m->oDW, m->d_g + m->oDW,
                            m->d_a + m->oDW, m->d_d + m->oDW, nd, m->lr, m->rho, m->eps);
     }
-    hipLaunchKernelGGL(pool_bwd_kernel, g1((long long)nb * m->H3 * m->W3 * 64), dim3(256), 0, st, m->gp2, m->arg2, m2,
-                       keep_scale, m->a4, m->ga4, nb, m->H3, m->W3, 64);
-    if ((rc = fork(1))) return rc;
     if ((rc = wgrad(m, m->a3, m->ga4, 3, nb, m->P1h, m->P1w, 0, 0, sw, wsw))) return rc;
     if ((rc = dgrad(m, m->ga4, m->ga3, m->a3, 3, nb, m->P1h, m->P1w, st))) return rc;
     if ((rc = fork(2))) return rc;
@@ -520,7 +521,8 @@ static int train_step_launches(alink_smallres_t* m, const float* dev_L, const fl
     if ((rc = wgrad(m, m->a1, m->ga2, 1, nb, m->H, m->W, 0, 0, sw, wsw))) return rc;
     if ((rc = dgrad(m, m->ga2, m->ga1, m->a1, 1, nb, m->H, m->W, st))) return rc;
     // conv1's weight + bias gradient (the last link of the dz chain: on the caller's stream): partial sums over 128 pixels per
-    // workgroup on the vector units, then the slab sum
+    // workgroup on the vector units, then the slab sum (which runs while the join below waits for the side stream: folding it
+    // into the update that follows the join put its 256 loads per output on the critical path — measured slower by 2.5 us)
     {
         const long long Px = (long long)nb * m->H * m->W;
         const int blocks = (int)((Px + 127) / 128);
@@ -535,12 +537,14 @@ static int train_step_launches(alink_smallres_t* m, const float* dev_L, const fl
         ALINK_HIP(hipStreamWaitEvent(st, m->ev_side, 0));
     }
     if (apply) {
-        // the update takes the tower's gradients where they are and the head's from its own buffer: nothing is copied
         const size_t nu = early ? m->oDW : m->ntower;        // (the Dense layer's share is already under way)
-        hipLaunchKernelGGL(adadelta2_kernel, g1((long long)nu), dim3(256), 0, st, m->d_p, m->d_g, m->d_a, m->d_d,
-                           nu, m->lr, m->rho, m->eps);
-        ALINK_HIP(hipGetLastError());
-        return alink_head_apply_update(m->head, stream);
+        if (!g_smallres_one_update) {
+            hipLaunchKernelGGL(adadelta2_kernel, g1((long long)nu), dim3(256), 0, st, m->d_p, m->d_g, m->d_a, m->d_d, nu, m->lr, m->rho, m->eps);
+            ALINK_HIP(hipGetLastError());
+            return alink_head_apply_update(m->head, stream);
+        }
+        // ONE launch ends the step: the tower's update from the gradients where they are and the head's from its own buffer
+        return alink_head_apply_update_with(m->head, m->d_p, m->d_g, m->d_a, m->d_d, nu, stream);
     }
     // gradients only (a data-parallel caller all-reduces the contiguous buffer, then alink_smallres_apply_update)
     ALINK_HIP(hipMemcpyAsync(m->d_all_grads + m->ntower, alink_head_grads_dev(m->head),

@@ -503,7 +503,7 @@ class DenseHead(KerasFitMixin):
             self.set_compute_dtype("f32")
         try:
             _abi.check(self.lib.alink_head_train_step_input_grads(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n, 0.0, 0,
-                                                                  _abi.ptr(dL), _abi.ptr(dR), _abi.ptr(self._metrics),
+                                                                  _abi.ptr(dL), _abi.ptr(dR), None, _abi.ptr(self._metrics),
                                                                   _abi.current_stream(self.device)), "alink_head_train_step_input_grads")
         finally:
             if quantised:

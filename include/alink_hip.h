@@ -318,6 +318,10 @@ int alink_head_train_step(alink_head_t* h, const float* dev_L, const float* dev_
                           const float* dev_y, const float* dev_sw, int n, float grad_scale,
                           int apply, float* dev_metrics, void* stream);
 int alink_head_apply_update(alink_head_t* h, void* stream);
+/* The same and, in the same launch, the same Adadelta rule (the head's lr, rho, eps) on a second parameter block of n2
+ * floats: the tower of an end-to-end model (SmallRes' step ends with one update launch instead of two). */
+int alink_head_apply_update_with(alink_head_t* h, float* dev_params2, const float* dev_grads2, float* dev_acc2,
+                                 float* dev_dacc2, size_t n2, void* stream);
 /* Optional: on a non-default stream, capture the train step into a hipGraph per distinct (operand
  * pointers, n, grad_scale, apply, lr) and replay it.  Default OFF: measured 67.8 us vs 66.2 us of plain
  * launches — the chain is bound by dependency latency between its kernels, not by launch cost. */
@@ -334,10 +338,12 @@ int alink_head_input_grads_relu(alink_head_t* h, const float* dev_L, const float
  * model's step needs from its head (SmallRes.trainModel, code/siamese.py:158-180).  For SmallRes' own head shape
  * (128 / 32 / 2 outputs on a multiple of 256 features, at most 32 pairs, float32) the pair is three launches instead
  * of seven; other shapes run the two calls above.  Gradients are left in alink_head_grads_dev, the parameters
- * untouched (alink_head_apply_update applies them). */
+ * untouched (alink_head_apply_update applies them).  dev_colsum (optional, d_in floats): the column sums of the
+ * 2n x d_in matrix [dL ; dR], rows ascending — the bias gradient of the layer that produced the inputs. */
 int alink_head_train_step_input_grads(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
                                       const float* dev_sw, int n, float grad_scale, int relu_inputs,
-                                      float* dev_dL, float* dev_dR, float* dev_metrics, void* stream);
+                                      float* dev_dL, float* dev_dR, float* dev_colsum, float* dev_metrics,
+                                      void* stream);
 /* Keras test_on_batch: {loss, binary_accuracy} without touching parameters. */
 int alink_head_eval(alink_head_t* h, const float* dev_L, const float* dev_R, const float* dev_y,
                     int n, float* dev_metrics, void* stream);

@@ -62,6 +62,8 @@ void alink_debug_set_head_bf16_mfma(int on);
 /* ---- SmallRes (csrc/smallres.hip) -------------------------------------------------------------------------------------- */
 /* 0: the weight gradients of a train step on the caller's stream, after their dz, instead of a side stream beside the dz chain */
 void alink_debug_set_smallres_overlap(int on);
+/* 0: a train step ends with two update launches (the tower's, the head's) instead of one (the same bits) */
+void alink_debug_set_smallres_one_update(int on);
 
 /* ---- diagnostics ------------------------------------------------------------------------------------------------------ */
 /* alink_embed returns after this many convolution launches (0 = the whole chain): per-layer timing by difference.

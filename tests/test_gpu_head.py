@@ -411,16 +411,17 @@ def test_three_launch_step_of_smallres_head_matches_generic_chain_and_oracle(gpu
                 Ld, Rd, yd = g._dev(L), g._dev(R), g._dev(y)
                 swd = None if sw is None else g._dev(sw)
                 mL, mR = torch.empty_like(Ld), torch.empty_like(Rd)
+                cs = torch.empty(d, dtype=torch.float32, device=g.device)
                 gpu.check(lib.alink_head_train_step_input_grads(g.h, gpu.ptr(Ld), gpu.ptr(Rd), gpu.ptr(yd), gpu.ptr(swd), n, 0.0, 1,
-                                                                gpu.ptr(mL), gpu.ptr(mR), gpu.ptr(g._metrics),
+                                                                gpu.ptr(mL), gpu.ptr(mR), gpu.ptr(cs), gpu.ptr(g._metrics),
                                                                 gpu.current_stream(g.device)))
                 out[mini] = (dL.cpu().numpy(), dR.cpu().numpy(), g.grads_tensor().cpu().numpy().copy(), met,
-                             mL.cpu().numpy(), mR.cpu().numpy())
+                             mL.cpu().numpy(), mR.cpu().numpy(), cs.cpu().numpy())
             finally:
                 lib.alink_debug_set_mini_step(1)
         a, b = out[1], out[0]
         scale = max(np.abs(b[2]).max(), 1e-12)
-        for x, z in zip(a[:3], b[:3]):
+        for x, z in zip(a[:3] + a[4:], b[:3] + b[4:]):
             np.testing.assert_allclose(x, z, rtol=2e-4, atol=2e-6 * max(np.abs(z).max(), 1e-12))
         np.testing.assert_allclose(a[3], b[3], rtol=2e-6, atol=1e-7)
         if n == 33:
@@ -430,6 +431,12 @@ def test_three_launch_step_of_smallres_head_matches_generic_chain_and_oracle(gpu
         assert np.array_equal(a[4], np.where(L > 0, a[0], 0.0).astype(np.float32))
         assert np.array_equal(a[5], np.where(R > 0, a[1], 0.0).astype(np.float32))
         assert np.all(a[0][:, :7] == 0) and np.all(a[1][:, :7] == 0)
+        # the column sums of [dL ; dR] (the bias gradient of the layer before the head), rows ascending: the same bits as a loop
+        for got in (a, b):
+            t = np.zeros(d, np.float32)
+            for row in np.concatenate([got[4], got[5]]):
+                t = t + row
+            assert np.array_equal(got[6], t)
         # the oracle's parameter gradients of the same batch
         ref, loss, acc = O.gradients(o.get_weights(), L, R, y, sw, dtype=np.float64)
         flat = np.concatenate([np.asarray(t).ravel() for t in ref])
