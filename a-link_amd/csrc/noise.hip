@@ -10,42 +10,11 @@
 // Every kernel streams its input once and writes its output once (4 B + 4 B per element, 16-B lane
 // accesses); nothing is staged through LDS because nothing is reused.
 #include "alink_common.h"
+#include "philox.h"
 
 namespace alink {
 namespace {
 
-// ---- Philox4x32-10 (Salmon et al., SC'11) -------------------------------------------------------
-struct U4 { unsigned int x, y, z, w; };
-
-__device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned int k0, unsigned int k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x;
-        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c.z;
-        U4 n;
-        n.x = (unsigned int)(p1 >> 32) ^ c.y ^ k0;
-        n.y = (unsigned int)p1;
-        n.z = (unsigned int)(p0 >> 32) ^ c.w ^ k1;
-        n.w = (unsigned int)p0;
-        c = n;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return c;
-}
-
-// stream ids (counter word 3) keep the draws of different kernels disjoint under one seed
-enum { ST_NORMAL = 0, ST_POISSON = 1, ST_SALTPEPPER = 2, ST_PERLIN = 3, ST_DROPOUT = 4 };
-
-__device__ __forceinline__ U4 draw(unsigned long long seed, unsigned long long idx, unsigned int sub, unsigned int st) {
-    U4 c{(unsigned int)idx, (unsigned int)(idx >> 32), sub, st};
-    return philox4x32_10(c, (unsigned int)seed, (unsigned int)(seed >> 32));
-}
-
-// 24-bit uniform in the open interval (0, 1)
-__device__ __forceinline__ float u01(unsigned int x) {
-    return (float)(x >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
-}
 // 53-bit-ish uniform in (0, 1) from two words (double precision consumers: Poisson)
 __device__ __forceinline__ double u01d(unsigned int hi, unsigned int lo) {
     const unsigned long long v = ((unsigned long long)(hi >> 5) << 26) | (lo >> 6);   // 27 + 26 bits
@@ -104,19 +73,11 @@ __global__ __launch_bounds__(256) void affine_noise_kernel(const AffineNoise p) 
 }
 
 // ---- Bernoulli keep-masks (Dropout of the SmallRes tower, code/siamese.py:146,153) -----------------------------
-// mask[e] = 1 with probability `keep`: the element's 24-bit uniform (word e & 3 of Philox block e >> 2) < keep.
+// (philox.h: keep_mask_block)
 // `first`: the element out[0] stands for — a rank that trains rows lo : hi of a batch draws those rows' masks exactly
 __global__ __launch_bounds__(256) void keep_mask_kernel(unsigned char* __restrict__ out, long long count, float keep,
                                                         unsigned long long seed, unsigned long long first) {
-    const unsigned long long b = (first >> 2) + (unsigned long long)blockIdx.x * 256 + threadIdx.x;      // Philox block
-    const unsigned long long e0 = b * 4;
-    if (e0 >= first + (unsigned long long)count) return;
-    const U4 r = draw(seed, b, 0, ST_DROPOUT);
-    const unsigned int w[4] = {r.x, r.y, r.z, r.w};
-    for (int j = 0; j < 4; ++j) {
-        const unsigned long long e = e0 + j;
-        if (e >= first && e < first + (unsigned long long)count) out[e - first] = u01(w[j]) < keep ? 1 : 0;
-    }
+    keep_mask_block(out, count, keep, seed, first, (first >> 2) + (unsigned long long)blockIdx.x * 256 + threadIdx.x);
 }
 
 // ---- Salt & pepper (code/noise.py:54-65, tuple-index semantics of NumPy < 1.23) --------------------

@@ -15,6 +15,7 @@
 // tower forward/backward and ties the two Adadelta states together.
 #include "alink_common.h"
 #include "sgemm.h"
+#include "philox.h"
 
 #include <vector>
 
@@ -25,6 +26,7 @@ int alink_head_train_step_input_grads(alink_head_t* h, const float* dev_L, const
                                       const float* dev_sw, int n, float grad_scale, int relu_inputs, float* dev_dL,
                                       float* dev_dR, float* dev_colsum, float* dev_metrics, void* stream);
 float* alink_head_params_dev(alink_head_t* h);
+int alink_keep_masks(uint8_t* dev_out, int64_t count, float keep, uint64_t seed, void* stream);
 int alink_head_apply_update_with(alink_head_t* h, float* dev_params2, const float* dev_grads2, float* dev_acc2, float* dev_dacc2,
                                  size_t n2, void* stream);
 }
@@ -124,7 +126,14 @@ __device__ __forceinline__ void conv1_patch(const Conv1P& p, int pix, float (&in
 }
 
 // thread = (pixel, 8 output channels): 131,072 threads at 2 x 16 images of 32 x 32 (a thread per pixel left half the chip idle)
-__global__ __launch_bounds__(256) void conv1_fwd_kernel(const Conv1P p) {
+// Workgroups beyond the layer's own (`conv_blocks`) draw the step's Dropout keep-masks (mk: alink_keep_masks' bytes, philox.h) —
+// the masks are first read two launches later, and a launch of their own was 2.7 us + a launch gap at the head of every step.
+struct MaskDraw { unsigned char* out; long long count; float keep; unsigned long long seed; int conv_blocks; };
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const Conv1P p, const MaskDraw mk) {
+    if (mk.out && (int)blockIdx.x >= mk.conv_blocks) {
+        keep_mask_block(mk.out, mk.count, mk.keep, mk.seed, 0ull, (unsigned long long)(blockIdx.x - mk.conv_blocks) * 256 + threadIdx.x);
+        return;
+    }
     __shared__ __attribute__((aligned(16))) float ws[27 * 32 + 32];
     for (int i = threadIdx.x; i < 27 * 32 + 32; i += 256) ws[i] = i < 27 * 32 ? p.w[i] : p.b[i - 27 * 32];
     __syncthreads();
@@ -282,14 +291,18 @@ int conv_fwd(alink_smallres* m, const float* in, float* out, int layer, int nb, 
 // images from L) — in ONE pass (until round 6: one pass per side; the two sides share every weight, and a layer's launch on
 // 2n images costs what it costs on n: none of them fills the chip); masks == nullptr -> inference (no dropout)
 int tower_fwd(alink_smallres* m, const float* L, const float* R, int n, int prescale, const uint8_t* mask1, const uint8_t* mask2,
-              hipStream_t st) {
+              hipStream_t st, const MaskDraw* draw = nullptr) {
     const float* P = m->d_p;
     const float keep_scale = 1.f / (1.f - 0.25f);
     const int nb = R ? 2 * n : n;
     int rc;
     {   // the first layer on the vector units (K = 27 is no GEMM: see conv1_fwd_kernel)
         Conv1P c{L, R, P + m->oW[0], P + m->oB[0], m->a1, nb, n, m->H, m->W, prescale};
-        hipLaunchKernelGGL(conv1_fwd_kernel, g1((long long)nb * m->H * m->W * 4), dim3(256), 0, st, c);
+        MaskDraw mk{nullptr, 0, 0.f, 0ull, 0};
+        if (draw) mk = *draw;
+        mk.conv_blocks = (int)g1((long long)nb * m->H * m->W * 4).x;
+        const int mask_blocks = mk.out ? (int)((mk.count + 1023) / 1024) : 0;      // 4 bytes per thread
+        hipLaunchKernelGGL(conv1_fwd_kernel, dim3(mk.conv_blocks + mask_blocks), dim3(256), 0, st, c, mk);
     }
     if ((rc = conv_fwd(m, m->a1, m->a2, 1, nb, m->H, m->W, 0, st))) return rc;
     hipLaunchKernelGGL(pool_fwd_kernel, g1((long long)nb * m->P1h * m->P1w * 32), dim3(256), 0, st, m->a2, m->p1,
@@ -452,14 +465,16 @@ void alink_debug_set_smallres_overlap(int on) { g_smallres_overlap = on != 0; } 
 static bool g_smallres_one_update = true;
 void alink_debug_set_smallres_one_update(int on) { g_smallres_one_update = on != 0; }
 
+// draw_seed != nullptr: dev_masks is an OUTPUT first — the step's first launch fills it with alink_keep_masks(…, 0.75, *draw_seed)
 static int train_step_launches(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
                                const float* dev_sw, int n, int prescale, const uint8_t* dev_masks, float grad_scale,
-                               int apply, float* dev_metrics, void* stream) {
+                               int apply, float* dev_metrics, void* stream, const uint64_t* draw_seed = nullptr) {
     hipStream_t st = (hipStream_t)stream;
-    const size_t e1 = (size_t)m->P1h * m->P1w * 32;
+    const size_t e1 = (size_t)m->P1h * m->P1w * 32, e2 = (size_t)m->P2h * m->P2w * 64;
     const uint8_t* m1 = dev_masks;
     const uint8_t* m2 = dev_masks ? dev_masks + 2 * (size_t)n * e1 : nullptr;
-    int rc = tower_fwd(m, dev_L, dev_R, n, prescale, m1, m2, st);
+    MaskDraw mk{const_cast<uint8_t*>(dev_masks), (long long)(2 * (size_t)n * (e1 + e2)), 1.f - 0.25f, draw_seed ? *draw_seed : 0ull, 0};
+    int rc = tower_fwd(m, dev_L, dev_R, n, prescale, m1, m2, st, draw_seed && dev_masks ? &mk : nullptr);
     if (rc) return rc;
     float* fL = m->f;
     float* fR = m->f + (size_t)n * m->feat;
@@ -605,6 +620,22 @@ int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const flo
     ALINK_HIP(hipGraphLaunch(exec, st));
     if (apply) (void)alink_head_params_dev(m->head);
     return ALINK_OK;
+}
+
+int alink_smallres_train_step_drawn(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
+                                    const float* dev_sw, int n, int prescale, uint8_t* dev_masks, uint64_t mask_seed,
+                                    float grad_scale, int apply, float* dev_metrics, void* stream) {
+    ALINK_REQUIRE(m && dev_L && dev_R && dev_y && dev_metrics && dev_masks, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
+    if (m->use_graph) {                    // (a captured step's arguments are fixed, a step's seed is not: the masks in a launch of their own)
+        int a = 0, b = 0;
+        alink_smallres_mask_sizes(m, &a, &b);
+        const int rc = alink_keep_masks(dev_masks, (int64_t)2 * n * ((int64_t)a + b), 0.75f, mask_seed, stream);
+        if (rc) return rc;
+        return alink_smallres_train_step(m, dev_L, dev_R, dev_y, dev_sw, n, prescale, dev_masks, grad_scale, apply, dev_metrics, stream);
+    }
+    DeviceGuard dg(m->device);
+    return train_step_launches(m, dev_L, dev_R, dev_y, dev_sw, n, prescale, dev_masks, grad_scale, apply, dev_metrics, stream, &mask_seed);
 }
 
 int alink_smallres_apply_update(alink_smallres_t* m, void* stream) {

@@ -6,6 +6,7 @@ fit / get_weights / set_weights / save_weights / load_weights, all on libalink_h
 Dropout masks are drawn on the host with np.random (the reference's come from TensorFlow's op-level
 RNG, which cannot be reproduced; the distribution — keep probability 0.75, scale 1/0.75 — is the same).
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -14,6 +15,7 @@ from . import _abi
 from .head import KerasFitMixin, glorot_uniform
 
 MAXN = 256
+_NO_CONTEXT = contextlib.nullcontext()
 
 
 class SmallResNet(KerasFitMixin):
@@ -52,6 +54,7 @@ class SmallResNet(KerasFitMixin):
         # one stream wait instead of a device-to-host copy
         self._metrics_host = torch.zeros(2, dtype=torch.float32).pin_memory()
         self._tdev = torch.device(self.device)
+        self._tdev_index = self._tdev.index
         self._mask_buf = {}
         # Optional, OFF: train_on_batch can replay its ~40 launches as ONE captured graph (use_graph = True + alink_smallres_set_graph):
         # a stream of this model's own (torch's default stream is the NULL stream, which cannot be captured) and staging buffers that
@@ -171,6 +174,9 @@ class SmallResNet(KerasFitMixin):
         return buf
 
     def _up(self, key, a):
+        if isinstance(a, self.torch.Tensor) and a.dtype is self.torch.float32 and a.is_cuda and a.is_contiguous() and \
+                a.device.index == self._tdev_index:
+            return a                                  # already where and what the kernels read
         """host array -> device through a pinned staging buffer and an asynchronous copy (a pageable upload is a synchronous
         ~15 us each, three per step); the step ends with a stream synchronisation, so the buffer is free again by the next one.
         Device tensors pass through."""
@@ -195,7 +201,9 @@ class SmallResNet(KerasFitMixin):
         st = self._stream if self.use_graph else cur
         if st is not cur:
             st.wait_stream(cur)                       # inputs produced on the caller's stream
-        with torch.cuda.stream(st):
+        # (entering a stream context costs ~5 us of host time before the step's first launch, with the device idle: only when
+        # the step runs on another stream than the caller's)
+        with (torch.cuda.stream(st) if st is not cur else _NO_CONTEXT):
             if self.use_graph:
                 L, R, yd = self._staged("L", x[0]), self._staged("R", x[1]), self._staged("y", y)
                 swd = self._staged("sw", sw) if sw is not None else None
@@ -206,20 +214,24 @@ class SmallResNet(KerasFitMixin):
                 # the keep-masks are drawn ON THE DEVICE (Philox, keyed by one 31-bit seed taken from np.random per step): drawing
                 # 2n(e1 + e2) = 304,128 uniforms with np.random on the host was 0.74 of the step's 1.68 ms.  One np.random draw per step
                 # keeps the ranks of a multi-rank loop in step (alink_loop.sync_host_randomness) like the host-drawn masks did.
+                # They are drawn by the step's own first launch (alink_smallres_train_step_drawn: the bytes alink_keep_masks writes).
                 e1, e2 = self.mask_sizes
                 md = self._mask_buf.get(n)               # (a step's masks are consumed by that step, in stream order)
                 if md is None:
                     md = self._mask_buf[n] = torch.empty(2 * n * (e1 + e2), dtype=torch.uint8, device=self.device)
-                _abi.check(self.lib.alink_keep_masks(_abi.ptr(md), md.numel(), 0.75, int(np.random.randint(0, 2 ** 31 - 1)),
-                                                     C.c_void_p(st.cuda_stream)), "alink_keep_masks")
-            elif masks is not None:
-                md = self._staged("masks", masks, torch.uint8) if self.use_graph else \
-                    torch.from_numpy(np.ascontiguousarray(masks, np.uint8)).to(self.device)
+                _abi.check(self.lib.alink_smallres_train_step_drawn(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
+                                                                    self.prescale, _abi.ptr(md), int(np.random.randint(0, 2 ** 31 - 1)), 0.0, 1,
+                                                                    C.c_void_p(self._metrics_host.data_ptr()), C.c_void_p(st.cuda_stream)),
+                           "alink_smallres_train_step_drawn")
             else:
-                md = None
-            _abi.check(self.lib.alink_smallres_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
-                                                          self.prescale, _abi.ptr(md), 0.0, 1, C.c_void_p(self._metrics_host.data_ptr()),
-                                                          C.c_void_p(st.cuda_stream)), "alink_smallres_train_step")
+                if masks is not None:
+                    md = self._staged("masks", masks, torch.uint8) if self.use_graph else \
+                        torch.from_numpy(np.ascontiguousarray(masks, np.uint8)).to(self.device)
+                else:
+                    md = None
+                _abi.check(self.lib.alink_smallres_train_step(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), _abi.ptr(swd), n,
+                                                              self.prescale, _abi.ptr(md), 0.0, 1, C.c_void_p(self._metrics_host.data_ptr()),
+                                                              C.c_void_p(st.cuda_stream)), "alink_smallres_train_step")
         st.synchronize()
         return self._metrics_host.tolist()
 

@@ -387,6 +387,12 @@ int alink_smallres_forward(alink_smallres_t* m, const float* dev_L, const float*
 int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
                               const float* dev_sw, int n, int prescale, const uint8_t* dev_masks,
                               float grad_scale, int apply, float* dev_metrics, void* stream);
+/* The same with the step's Dropout keep-masks drawn BY the step: dev_masks (2n (a + b) bytes, a and b from
+ * alink_smallres_mask_sizes) is first filled with alink_keep_masks(dev_masks, 2n (a + b), 0.75, mask_seed) — by
+ * extra workgroups of the step's first launch instead of a launch of its own — then read as above. */
+int alink_smallres_train_step_drawn(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
+                                    const float* dev_sw, int n, int prescale, uint8_t* dev_masks, uint64_t mask_seed,
+                                    float grad_scale, int apply, float* dev_metrics, void* stream);
 /* Optional (SmallResNet turns it on): on a non-default stream, the whole train step — ~40 short launches on two streams — is
  * captured per distinct (operand pointers, n, flags, lr) the second time it is seen and replayed from then on.  The caller keeps its
  * operands at stable addresses (staging buffers) for that to hit.  Same kernels, same order: the same results. */

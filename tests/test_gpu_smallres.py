@@ -121,3 +121,39 @@ def test_train_step_replayed_as_a_graph_equals_plain_launches(gpu):
     for a, b in zip(out[0][1], out[1][1]):
         assert np.array_equal(a, b)
     assert np.array_equal(out[0][2], out[1][2])
+
+
+def test_masks_drawn_by_the_step_equal_a_mask_launch_then_the_step(gpu):
+    """alink_smallres_train_step_drawn: the Dropout keep-masks come from extra workgroups of the step's first launch.  They are
+    alink_keep_masks' bytes for the same seed, so three steps that draw their own (train_on_batch's default) leave the same
+    metrics and weights, bit for bit, as three steps fed masks a separate alink_keep_masks launch drew from the same seeds —
+    with and without the captured-graph form (which draws in a launch of its own: a captured launch's seed would be frozen)."""
+    import torch
+    from a_link_amd.smallres import SmallResNet
+    rs = np.random.RandomState(7)
+    L = rs.randint(0, 256, (12, 32, 32, 3)).astype(np.float32)
+    R = rs.randint(0, 256, (12, 32, 32, 3)).astype(np.float32)
+    y = np.eye(2, dtype=np.float32)[rs.randint(0, 2, 12)]
+    lib = gpu.load()
+    out = []
+    for mode in ("drawn", "launch", "drawn_graph"):
+        net = SmallResNet((32, 32, 3), 256, lr=0.1, seed=8)
+        if mode == "drawn_graph":
+            net.use_graph = True
+            gpu.check(lib.alink_smallres_set_graph(net.h, 1))
+        np.random.seed(21)
+        ms = []
+        for _ in range(3):
+            if mode == "launch":
+                e1, e2 = net.mask_sizes
+                md = torch.empty(2 * 12 * (e1 + e2), dtype=torch.uint8, device="cuda")
+                gpu.check(lib.alink_keep_masks(gpu.ptr(md), md.numel(), 0.75, int(np.random.randint(0, 2 ** 31 - 1)), None))
+                torch.cuda.synchronize()
+                ms.append(net.train_on_batch([L, R], y, masks=md.cpu().numpy()))
+            else:
+                ms.append(net.train_on_batch([L, R], y))
+        out.append((ms, net.get_weights()))
+    for other in out[1:]:
+        assert out[0][0] == other[0]
+        for a, b in zip(out[0][1], other[1]):
+            assert np.array_equal(a, b)
