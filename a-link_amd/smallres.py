@@ -174,21 +174,50 @@ class SmallResNet(KerasFitMixin):
         return buf
 
     def _up(self, key, a):
-        if isinstance(a, self.torch.Tensor) and a.dtype is self.torch.float32 and a.is_cuda and a.is_contiguous() and \
-                a.device.index == self._tdev_index:
-            return a                                  # already where and what the kernels read
-        """host array -> device through a pinned staging buffer and an asynchronous copy (a pageable upload is a synchronous
-        ~15 us each, three per step); the step ends with a stream synchronisation, so the buffer is free again by the next one.
-        Device tensors pass through."""
+        """operand `a` as a float32 device tensor: device tensors as they are, a host array through a pinned staging buffer and an
+        asynchronous copy (a pageable upload is a synchronous ~15 us each); the step ends with a stream synchronisation, so the
+        buffer is free again by the next one."""
         torch = self.torch
         if isinstance(a, torch.Tensor):
+            if a.dtype is torch.float32 and a.is_cuda and a.is_contiguous() and a.device.index == self._tdev_index:
+                return a
             return a.to(self.device, torch.float32).contiguous()
         a = np.asarray(a, dtype=np.float32)
         buf = self._pin.get((key, a.shape))
         if buf is None:
-            buf = self._pin[(key, a.shape)] = torch.empty(a.shape, dtype=torch.float32).pin_memory()
-        buf.numpy()[...] = a
-        return buf.to(self.device, non_blocking=True)
+            t = torch.empty(a.shape, dtype=torch.float32).pin_memory()
+            buf = self._pin[(key, a.shape)] = (t, t.numpy(), torch.empty(a.shape, dtype=torch.float32, device=self.device))
+        buf[1][...] = a
+        buf[2].copy_(buf[0], non_blocking=True)
+        return buf[2]
+
+    def _up_all(self, arrays):
+        """the host arrays of one step (images of both sides, targets, sample weights) through ONE pinned staging buffer and ONE
+        asynchronous copy into a device buffer kept from step to step (three copies and three allocations until round 6):
+        returns the device views, or None if any operand is not a host array (those go through _up one by one)."""
+        torch = self.torch
+        if any(isinstance(a, torch.Tensor) for a in arrays if a is not None):
+            return None
+        arrs = [None if a is None else np.asarray(a, dtype=np.float32) for a in arrays]
+        key = tuple(None if a is None else a.shape for a in arrs)
+        ent = self._pin.get(key)
+        if ent is None:
+            offs, o = [], 0
+            for a in arrs:
+                offs.append(o)
+                o += 0 if a is None else (a.size + 63) // 64 * 64          # 256-byte aligned pieces
+            host = torch.empty(max(o, 64), dtype=torch.float32).pin_memory()
+            dev = torch.empty(max(o, 64), dtype=torch.float32, device=self.device)
+            hv = host.numpy()
+            views = [None if a is None else hv[f:f + a.size].reshape(a.shape) for a, f in zip(arrs, offs)]
+            dviews = [None if a is None else dev[f:f + a.size].view(a.shape) for a, f in zip(arrs, offs)]
+            ent = self._pin[key] = (host, dev, views, dviews, o)
+        host, dev, views, dviews, o = ent
+        for v, a in zip(views, arrs):
+            if a is not None:
+                v[...] = a
+        dev.copy_(host, non_blocking=True)
+        return dviews
 
     def train_on_batch(self, x, y, class_weight=None, sample_weight=None, masks=None):
         torch = self.torch
@@ -208,8 +237,12 @@ class SmallResNet(KerasFitMixin):
                 L, R, yd = self._staged("L", x[0]), self._staged("R", x[1]), self._staged("y", y)
                 swd = self._staged("sw", sw) if sw is not None else None
             else:
-                L, R, yd = self._up("L", x[0]), self._up("R", x[1]), self._up("y", y)
-                swd = self._up("sw", sw) if sw is not None else None
+                staged = self._up_all((x[0], x[1], y, sw))
+                if staged is not None:
+                    L, R, yd, swd = staged
+                else:
+                    L, R, yd = self._up("L", x[0]), self._up("R", x[1]), self._up("y", y)
+                    swd = self._up("sw", sw) if sw is not None else None
             if masks is None and self.training_dropout:
                 # the keep-masks are drawn ON THE DEVICE (Philox, keyed by one 31-bit seed taken from np.random per step): drawing
                 # 2n(e1 + e2) = 304,128 uniforms with np.random on the host was 0.74 of the step's 1.68 ms.  One np.random draw per step

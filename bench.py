@@ -1053,7 +1053,20 @@ def main():
             t1 = time.perf_counter()
             srn.train_on_batch([sL, sR], sy)
             ts.append(time.perf_counter() - t1)
+        # host (NumPy) operands, as the reference's Keras call takes them: one staging copy + one upload per step inside the time
         line["smallres32_train_step_ms"] = 1e3 * float(np.median(ts))
+        # the same step with its operands already in HBM (the bench contract's convention for the timed region; the loop's own
+        # generator hands SmallRes device tensors): what the device and its launches cost
+        dL, dR, dy = (torch.from_numpy(a).to("cuda:%d" % local_rank) for a in (sL, sR, sy))
+        for _ in range(5):
+            srn.train_on_batch([dL, dR], dy)
+        ts = []
+        for _ in range(50):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            srn.train_on_batch([dL, dR], dy)
+            ts.append(time.perf_counter() - t1)
+        line["smallres32_train_step_resident_ms"] = 1e3 * float(np.median(ts))
         smallres_weights = srn.get_weights()
         del srn
 

@@ -58,5 +58,6 @@ def test_committed_bench_line_keeps_the_contract():
         assert c5[mode]["backbone_forwards_per_pair"] == 20400 and 0.9 < c5[mode]["frac_of_in_batch_rate"] <= 1.02, (mode, c5[mode])
     assert c5["screen"]["backbone_forwards_per_s"] >= 40000 and c5["exact"]["search_dtype"] == "f16x2"
     assert 0 < l["custom_train_step_ms"] < 0.08 and l["smallres32_train_step_ms"] < 0.6
+    assert 0 < l["smallres32_train_step_resident_ms"] <= l["smallres32_train_step_ms"]          # operands already in HBM: no staging, no upload
     assert l["parity"]["normalized_weights"]["one_minus_cos_vs_cpu_oracle_max"] < l["parity"]["one_minus_cos_vs_cpu_oracle_max"]
     assert l["config4"]["finetune_steps"]["rows_per_step"] == 16
