@@ -1618,10 +1618,12 @@ struct MiniMid {
 };
 
 __global__ __launch_bounds__(1024) void mini_mid_kernel(const MiniMid p) {
-    __shared__ float z1s[MINI_N * 128];
-    __shared__ float W2s[128 * 33];
-    __shared__ float z2s[MINI_N * 32], dz2s[MINI_N * 32];
-    __shared__ float dz3s[MINI_N * 2], rowm[MINI_N * 2], w3s[66], b2s[32], sws[MINI_N], ys[MINI_N * 2];
+    __shared__ __attribute__((aligned(16))) float z1s[MINI_N * 128];
+    __shared__ __attribute__((aligned(16))) float W2s[128 * 36];      // [k][c2], pitch 36: 16-byte rows for the dZ1 phase
+    __shared__ __attribute__((aligned(16))) float W2T[32 * 132];      // [c2][k], pitch 132: 16-byte reads along k for Dense2
+    __shared__ __attribute__((aligned(16))) float z2s[MINI_N * 32], dz2s[MINI_N * 32];
+    __shared__ __attribute__((aligned(16))) float w3s[68];
+    __shared__ float dz3s[MINI_N * 2], rowm[MINI_N * 2], b2s[32], sws[MINI_N], ys[MINI_N * 2];
     const int tid = threadIdx.x, n = p.n, S = p.S;
     const int nz1 = n * 128;
     // ---- every global load of the forward first: W2 and the small vectors ride under the partial sums
@@ -1660,8 +1662,8 @@ __global__ __launch_bounds__(1024) void mini_mid_kernel(const MiniMid p) {
     }
     {
         const int k = tid >> 3, c = (tid & 7) * 4;
-        float* d = W2s + k * 33 + c;
-        d[0] = w2v[0]; d[1] = w2v[1]; d[2] = w2v[2]; d[3] = w2v[3];
+        *(f32x4*)(W2s + k * 36 + c) = w2v;
+        W2T[(c + 0) * 132 + k] = w2v[0]; W2T[(c + 1) * 132 + k] = w2v[1]; W2T[(c + 2) * 132 + k] = w2v[2]; W2T[(c + 3) * 132 + k] = w2v[3];
     }
     if (tid < 66) w3s[tid] = small;
     else if (tid >= 128 && tid < 160) b2s[tid - 128] = small;
@@ -1672,8 +1674,15 @@ __global__ __launch_bounds__(1024) void mini_mid_kernel(const MiniMid p) {
     if (tid < n * 32) {
         const int r = tid >> 5, c2 = tid & 31;
         float s = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < 128; ++k) s = fmaf(fmaxf(z1s[r * 128 + k], 0.f), W2s[k * 33 + c2], s);
+        // (16-byte LDS reads: one per four steps from each operand — with 4-byte reads this phase was 4.2 of the kernel's 14 us)
+#pragma unroll 4
+        for (int k = 0; k < 128; k += 4) {
+            const f32x4 a = *(const f32x4*)(z1s + r * 128 + k), w = *(const f32x4*)(W2T + c2 * 132 + k);
+            s = fmaf(fmaxf(a[0], 0.f), w[0], s);
+            s = fmaf(fmaxf(a[1], 0.f), w[1], s);
+            s = fmaf(fmaxf(a[2], 0.f), w[2], s);
+            s = fmaf(fmaxf(a[3], 0.f), w[3], s);
+        }
         z2s[tid] = s + b2s[c2];
     }
     __syncthreads();
@@ -1685,10 +1694,13 @@ __global__ __launch_bounds__(1024) void mini_mid_kernel(const MiniMid p) {
         const float* a = z2s + tid * 32;
         const float w = sws[tid];
         float z0 = 0.f, z1 = 0.f;
-        for (int c = 0; c < 32; ++c) {
-            const float v = fmaxf(a[c], 0.f);
-            z0 = fmaf(v, w3s[c * 2 + 0], z0);
-            z1 = fmaf(v, w3s[c * 2 + 1], z1);
+#pragma unroll
+        for (int c = 0; c < 32; c += 4) {
+            const f32x4 av = *(const f32x4*)(a + c), wa = *(const f32x4*)(w3s + c * 2), wb = *(const f32x4*)(w3s + c * 2 + 4);
+            z0 = fmaf(fmaxf(av[0], 0.f), wa[0], z0); z1 = fmaf(fmaxf(av[0], 0.f), wa[1], z1);
+            z0 = fmaf(fmaxf(av[1], 0.f), wa[2], z0); z1 = fmaf(fmaxf(av[1], 0.f), wa[3], z1);
+            z0 = fmaf(fmaxf(av[2], 0.f), wb[0], z0); z1 = fmaf(fmaxf(av[2], 0.f), wb[1], z1);
+            z0 = fmaf(fmaxf(av[3], 0.f), wb[2], z0); z1 = fmaf(fmaxf(av[3], 0.f), wb[3], z1);
         }
         z0 += w3s[64];
         z1 += w3s[65];
@@ -1758,8 +1770,14 @@ __global__ __launch_bounds__(1024) void mini_mid_kernel(const MiniMid p) {
     for (int o = tid; o < nz1; o += 1024) {
         const int r = o >> 7, k = o & 127;
         float g = 0.f;
-#pragma unroll 8
-        for (int c2 = 0; c2 < 32; ++c2) g = fmaf(dz2s[r * 32 + c2], W2s[k * 33 + c2], g);
+#pragma unroll
+        for (int c2 = 0; c2 < 32; c2 += 4) {
+            const f32x4 dv = *(const f32x4*)(dz2s + r * 32 + c2), w = *(const f32x4*)(W2s + k * 36 + c2);
+            g = fmaf(dv[0], w[0], g);
+            g = fmaf(dv[1], w[1], g);
+            g = fmaf(dv[2], w[2], g);
+            g = fmaf(dv[3], w[3], g);
+        }
         p.dz1[o] = z1s[o] > 0.f ? g : 0.f;
     }
 }
