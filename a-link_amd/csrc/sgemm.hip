@@ -115,6 +115,16 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
         }
     }
 
+    // A_CONVT, 16-byte form: where this thread's walk over the pixels starts (see load_a); rows shorter than half a step (tiny
+    // images) and a gathered tensor in two buffers take the 4-byte form, which decodes every piece (vec_ok)
+    int t_ox = 0, t_oy = 0, t_off = 0;
+    const int t_drow = (p.W - p.Wo) * p.Ci, t_dimg = (p.H - p.Ho) * p.W * p.Ci;      // offset steps at a row's / an image's end
+    if (AMODE == A_CONVT && VEC) {
+        const int r = fdiv(kbeg + alkk0, p.Wo, rWo, t_ox);
+        const int n = fdiv(r, p.Ho, rHo, t_oy);
+        t_off = ((n * p.H + t_oy + tdy[0]) * p.W + t_ox + tdx[0]) * p.Ci + tci[0];
+    }
+
     // The loaders are BRANCH-FREE: every piece computes its address and whether it exists, loads from the address or from a
     // harmless one (the start of the operand), and keeps the value or zero.  With the `if (inside) load` form they had until
     // round 6 the compiler could not issue a stage's loads together — each sat in its own block behind a branch, followed by
@@ -180,17 +190,31 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
         } else {   // A_CONVT: reduction index = pixel, M index = (tap, ci) or the ones row
             const int pix = k0 + alkk0 + j * AKR;
             const bool live = pix < kend;
+            if (VEC) {                                          // (the launcher takes this form only where the walk holds: vec_ok)
+                // The pieces of a thread walk the pixels kbeg + alkk0, + AKR, + 2 AKR, ... in exactly the order the kernel asks
+                // for them (AQ pieces per stage, BK = AQ x AKR), and its four columns are ONE tap's consecutive channels: the
+                // element offset of (pixel + tap, channel) is carried from piece to piece — an add, and selects at a row's and
+                // an image's end — instead of rebuilt from two divisions and three multiplies per piece.  That arithmetic was
+                // the stage: ~100 vector instructions a piece, eight pieces, 8.5 k cycles around 2 k of MFMA
+                // (tools/experiments/gemm_probe.sh phases).
+                const bool ok = live && tkind[0] == 1 && (unsigned)(t_oy + tdy[0]) < (unsigned)p.H && (unsigned)(t_ox + tdx[0]) < (unsigned)p.W;
+                const int mk = ld4(p.A, t_off, ok, v) | ((live && tkind[0] == 2) ? 16 : 0);
+                t_ox += AKR; t_off += AKR * p.Ci;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {                    // (AKR <= 2 Wo: at most two row ends per step)
+                    const bool c = t_ox >= p.Wo;
+                    t_ox -= c ? p.Wo : 0; t_off += c ? t_drow : 0; t_oy += c ? 1 : 0;
+                    const bool c2 = t_oy >= p.Ho;
+                    t_oy = c2 ? 0 : t_oy; t_off += c2 ? t_dimg : 0;
+                }
+                return mk;
+            }
             int ox, oy;
             const int r = fdiv(live ? pix : 0, p.Wo, rWo, ox);
             const int n = fdiv(r, p.Ho, rHo, oy);
             const bool second = p.A2 && n >= p.a_split;
             const float* Ap = second ? p.A2 : p.A;
             const int nn = second ? n - p.a_split : n;
-            if (VEC) {                                          // Ci % 4 == 0: this thread's four columns are one tap's consecutive channels
-                const int iy = oy + tdy[0], ix = ox + tdx[0];
-                const bool ok = live && tkind[0] == 1 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                return ld4(Ap, ((nn * p.H + iy) * p.W + ix) * p.Ci + tci[0], ok, v) | ((live && tkind[0] == 2) ? 16 : 0);
-            }
             int mk = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -315,6 +339,11 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
                 for (int t = 0; t < PER; ++t)
                     if (kk < BK) { mfma_step(kk); kk += 2; }
                 __builtin_amdgcn_sched_barrier(0);               // keep the deal as written
+                // (Written straight instead — fetches, LDS operand reads, the chain — with the interleave handed to the scheduler
+                // as sched_group_barrier groups of one MFMA, two LDS reads, 6-12 vector instructions and a load: the same 4.3-5.1 k
+                // cycles a stage.  The skeleton WITHOUT MFMAs and loads already takes 2.0-2.5 k of them (gemm_probe.sh
+                // phases_skeleton) and the two do not overlap inside one wave: the phase is their sum, and a wave alone on its SIMD
+                // has no other wave to overlap with.  Two workgroups per CU run 2x the work in 1.47x the time.)
             }
 #pragma unroll
             for (; kk < BK; kk += 2) mfma_step(kk);
@@ -442,7 +471,7 @@ inline bool vec_ok(const GemmP& p) {
     if (p.amode == A_ROW) a = (p.K % 4) == 0 && (p.lda % 4) == 0;
     else if (p.amode == A_COL) a = (p.M % 4) == 0 && (p.lda % 4) == 0;
     else if (p.amode == A_CONV) a = (p.Ci % 4) == 0 && p.prescale == 0;      // (pre-scaled pixels are 3-channel images: the 4-byte form)
-    else if (p.amode == A_CONVT) a = (p.Ci % 4) == 0;
+    else if (p.amode == A_CONVT) a = (p.Ci % 4) == 0 && 2 * p.Wo >= (narrow(p) ? 8 : 16) && !p.A2;      // (the pixel walk: at most two row ends per step of 1024 / BM pixels)
     if (p.bmode == B_ROW) b = (p.N % 4) == 0 && (p.ldb % 4) == 0;
     else if (p.bmode == B_COLT) b = (p.K % 4) == 0 && (p.ldb % 4) == 0;
     return a && b && ((((uintptr_t)p.A) | ((uintptr_t)p.B) | ((uintptr_t)(p.A2 ? p.A2 : p.A))) & 15) == 0;

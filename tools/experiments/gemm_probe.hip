@@ -29,13 +29,18 @@ static float time_gemm(GemmP g, int max_split, float* ws, int reps) {
 int main() {
     const int nb = 32;
     float *in, *w, *out, *ws;
-    hipMalloc(&in, (size_t)nb * 32 * 32 * 64 * 4); hipMalloc(&w, 9 * 64 * 64 * 4 + (1 << 20)); hipMalloc(&out, (size_t)nb * 32 * 32 * 64 * 4);
+    hipMalloc(&in, (size_t)2 * nb * 32 * 32 * 64 * 4); hipMalloc(&w, 9 * 64 * 64 * 4 + (1 << 20)); hipMalloc(&out, (size_t)2 * nb * 32 * 32 * 64 * 4);
     hipMalloc(&ws, (size_t)64 << 20);
-    hipMemset(in, 0, (size_t)nb * 32 * 32 * 64 * 4); hipMemset(w, 0, 9 * 64 * 64 * 4);
+    hipMemset(in, 0, (size_t)2 * nb * 32 * 32 * 64 * 4); hipMemset(w, 0, 9 * 64 * 64 * 4);
     {   // conv2 forward: 32 images 32x32x32 -> 30x30x32 (valid)
         GemmP g{}; g.A = in; g.B = w; g.C = out; g.Ho = 30; g.Wo = 30; g.M = nb * 900; g.N = 32; g.K = 288; g.ldb = 32; g.ldc = 32;
         g.amode = A_CONV; g.bmode = B_ROW; g.H = 32; g.W = 32; g.Ci = 32; g.pad = 0; g.relu = 1; g.bias = w;
         printf("conv2 fwd  M=%d N=32 K=288: %.1f us\n", g.M, time_gemm(g, 1, ws, 50));
+    }
+    {   // the same on 64 images: 450 workgroups = two per CU (2 x 64 KB of LDS), i.e. two waves per SIMD — does the launch take twice as long?
+        GemmP g{}; g.A = in; g.B = w; g.C = out; g.Ho = 30; g.Wo = 30; g.M = 2 * nb * 900; g.N = 32; g.K = 288; g.ldb = 32; g.ldc = 32;
+        g.amode = A_CONV; g.bmode = B_ROW; g.H = 32; g.W = 32; g.Ci = 32; g.pad = 0; g.relu = 1; g.bias = w;
+        printf("conv2 fwd x2  M=%d N=32 K=288: %.1f us\n", g.M, time_gemm(g, 1, ws, 50));
     }
     {   // conv4 forward: 15x15x64 -> 13x13x64
         GemmP g{}; g.A = in; g.B = w; g.C = out; g.Ho = 13; g.Wo = 13; g.M = nb * 169; g.N = 64; g.K = 576; g.ldb = 64; g.ldc = 64;
