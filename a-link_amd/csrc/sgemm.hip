@@ -252,15 +252,35 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
     };
     // what a fetched piece becomes on its way into LDS: absent values 0, pixels pre-scaled (conv modes), the ones row 1
     const bool a_scaled = AMODE == A_CONV || AMODE == A_CONVT;
+    // (The 16-byte forms fetch all four values of a piece or none, and the im2col one is never pre-scaled (vec_ok): one test and
+    // four selects a piece instead of a scale, a bit test and a select per VALUE — this kernel's time is its vector instruction
+    // count, the exact-f32 MFMA shares the vector unit's issue: see the stage loop.)
     auto fix_a = [&](float v[4], int mk) {
+        if (VEC) {
+            if (AMODE == A_CONVT && p.prescale) {                // (uniform)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (v[i] - psub) * pmul;
+            }
+            const bool have = mk & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = have ? v[i] : 0.f;
+            if (AMODE == A_CONVT) v[0] += (mk & 16) ? 1.f : 0.f;                   // the ones row: the quad's first column
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float x = a_scaled ? (v[i] - psub) * pmul : v[i];
             v[i] = (mk >> i & 1) ? x : 0.f;
-            if (AMODE == A_CONVT) v[i] += (mk >> (4 + i) & 1) ? 1.f : 0.f;       // (VEC: bit 4 = element 0, the quad's first column)
+            if (AMODE == A_CONVT) v[i] += (mk >> (4 + i) & 1) ? 1.f : 0.f;
         }
     };
     auto fix_b = [&](float v[4], int mk) {
+        if (VEC) {
+            const bool have = mk & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = have ? v[i] : 0.f;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (mk >> i & 1) ? v[i] : 0.f;
     };
@@ -343,7 +363,13 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
                 // as sched_group_barrier groups of one MFMA, two LDS reads, 6-12 vector instructions and a load: the same 4.3-5.1 k
                 // cycles a stage.  The skeleton WITHOUT MFMAs and loads already takes 2.0-2.5 k of them (gemm_probe.sh
                 // phases_skeleton) and the two do not overlap inside one wave: the phase is their sum, and a wave alone on its SIMD
-                // has no other wave to overlap with.  Two workgroups per CU run 2x the work in 1.47x the time.)
+                // has no other wave to overlap with.  Two workgroups per CU run 2x the work in 1.47x the time.
+                // And another wave does not overlap with it either: a WAVE-SPECIALISED form — 4 waves that only multiply, 4 that
+                // only fetch into the other of two LDS buffers, one barrier a stage; bit-equal, tested — ran a stage in 4.6 k cycles,
+                // the multiplying waves' 1.9 k PLUS the fetching waves' instructions, and lost the gain to its longer prologue
+                // (conv2 forward 16.6 -> 17.7 us).  v_mfma_f32_32x32x2_f32 runs at the vector unit's own FP32 rate (157 TFLOP/s
+                // both): the exact-f32 MFMA and the vector instructions share the SIMD's issue, whatever wave they come from.
+                // What this kernel can still save is vector INSTRUCTIONS, not their placement.)
             }
 #pragma unroll
             for (; kk < BK; kk += 2) mfma_step(kk);
