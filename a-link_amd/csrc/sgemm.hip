@@ -29,6 +29,9 @@ namespace {
 
 constexpr int BK_SMALL = 16, BK_DEEP = 64;
 
+// what an absent 16-byte piece reads: zeros, so that it needs no fix-up on its way into LDS
+__device__ __attribute__((aligned(16))) const float g_gemm_zeros[4] = {0.f, 0.f, 0.f, 0.f};
+
 
 // a / d for 0 <= a < 2^23, d > 0 given rd = 1.f / d: one multiply and a correction instead of the ~40 instructions of an
 // integer division by a run-time divisor (the loaders below decode an im2col index per 16 bytes they fetch: with one
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
     // the piece is written to LDS a stage later (fix below): a load whose value is selected, scaled or masked right behind it
     // is waited for right behind it, and a stage then costs one trip to memory per piece.
     auto ld4 = [](const float* base, int off, bool ok, float v[4]) -> int {
-        const f32x4 t = *(const f32x4*)(base + (ok ? off : 0));
+        const f32x4 t = *(const f32x4*)(ok ? base + off : g_gemm_zeros);
         v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
         return ok ? 15 : 0;
     };
@@ -252,18 +255,16 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
     };
     // what a fetched piece becomes on its way into LDS: absent values 0, pixels pre-scaled (conv modes), the ones row 1
     const bool a_scaled = AMODE == A_CONV || AMODE == A_CONVT;
-    // (The 16-byte forms fetch all four values of a piece or none, and the im2col one is never pre-scaled (vec_ok): one test and
-    // four selects a piece instead of a scale, a bit test and a select per VALUE — this kernel's time is its vector instruction
-    // count, the exact-f32 MFMA shares the vector unit's issue: see the stage loop.)
+    // (The 16-byte forms fetch all four values of a piece or none — none = from a 16-byte block of zeros — and the im2col one is
+    // never pre-scaled (vec_ok): nothing to do to a piece on its way into LDS, where the 4-byte forms scale, test a bit and select per
+    // VALUE.  This kernel's time is its vector instruction count — the exact-f32 MFMA shares the vector unit's issue: see the stage loop.)
     auto fix_a = [&](float v[4], int mk) {
-        if (VEC) {
-            if (AMODE == A_CONVT && p.prescale) {                // (uniform)
+        if (VEC) {                                               // an absent piece was fetched from g_gemm_zeros: nothing to select
+            if (AMODE == A_CONVT && p.prescale) {                // (uniform; an absent value must stay 0)
+                const bool have = mk & 1;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (v[i] - psub) * pmul;
+                for (int i = 0; i < 4; ++i) v[i] = have ? (v[i] - psub) * pmul : 0.f;
             }
-            const bool have = mk & 1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = have ? v[i] : 0.f;
             if (AMODE == A_CONVT) v[0] += (mk & 16) ? 1.f : 0.f;                   // the ones row: the quad's first column
             return;
         }
@@ -275,12 +276,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
         }
     };
     auto fix_b = [&](float v[4], int mk) {
-        if (VEC) {
-            const bool have = mk & 1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = have ? v[i] : 0.f;
-            return;
-        }
+        if (VEC || BMODE == B_FLIP) return;                      // 16-byte pieces: absent ones are zeros already
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (mk >> i & 1) ? v[i] : 0.f;
     };
@@ -324,23 +320,31 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
     // [probe:2]
     float* const As = As0;
     float* const Bs = Bs0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    // (the last stage stands after the loop, not in a branch of it: with three ways through one loop body the accumulator was
+    // copied register to register at every join — 32 moves a stage)
+    int k0 = kbeg;
+    auto stash = [&]() {
 #pragma unroll
         for (int j = 0; j < AQ; ++j) { fix_a(ra[j], ma[j]); store_a(As, j, ra[j]); }
 #pragma unroll
         for (int j = 0; j < BQ; ++j) { fix_b(rb[j], mb[j]); store_b(Bs, j, rb[j]); }
-        // [probe:3]
-        __syncthreads();
-        // [probe:4]
-        // (read one step at a time, every MFMA waited ~130 cycles for its own ds_read)
-        float av[BK / 2], bv[BK / 2];
+    };
+    float av[BK / 2], bv[BK / 2];
+    auto operands = [&]() {                      // (read one step at a time, every MFMA waited ~130 cycles for its own ds_read)
 #pragma unroll
         for (int i = 0; i < BK / 2; ++i) {
             av[i] = As[(2 * i + hh) * LDA + wm * 32 + l31];
             bv[i] = Bs[(2 * i + hh) * LDB + wn * 32 + l31];
         }
-        auto mfma_step = [&](int kk) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk >> 1], bv[kk >> 1], acc, 0, 0, 0); };
-        if (BK == BK_SMALL && k0 + BK < kend) {
+    };
+    auto mfma_step = [&](int kk) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk >> 1], bv[kk >> 1], acc, 0, 0, 0); };
+    for (; k0 + BK < kend; k0 += BK) {
+        stash();
+        // [probe:3]
+        __syncthreads();
+        // [probe:4]
+        operands();
+        if (BK == BK_SMALL) {
             // many workgroups per CU: other waves fill this one's shadows, and the scheduler does better left alone
 #pragma unroll
             for (int j = 0; j < AQ; ++j) ma[j] = load_a(k0 + BK, j, ra[j]);
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
             for (int j = 0; j < BQ; ++j) mb[j] = load_b(k0 + BK, j, rb[j]);
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) mfma_step(kk);
-        } else if (k0 + BK < kend) {
+        } else {
             constexpr int NP = AQ + BQ, STEPS = BK / 2, PER = STEPS / NP > 0 ? STEPS / NP : 1;
             int kk = 0;
 #pragma unroll
@@ -373,22 +377,26 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmP p) {
             }
 #pragma unroll
             for (; kk < BK; kk += 2) mfma_step(kk);
-        } else {
-            // [probe:5]
-            // the last stage: the steps that exist (a reduction shorter than the stage — conv1's K = 27 — stops early: the
-            // rest of the stage is zeros; an odd tail is one more zero step)
-            const int steps = min(BK, (kend - k0 + 1) & ~1);
-            if (BK == BK_SMALL || steps == BK) {
-#pragma unroll
-                for (int kk = 0; kk < BK; kk += 2) mfma_step(kk);
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < BK; kk += 2)
-                    if (kk < steps) mfma_step(kk);               // (uniform; unrolled so that av / bv stay registers)
-            }
         }
         // [probe:6]
         __syncthreads();
+    }
+    {
+        // [probe:5]
+        // the last stage: the steps that exist (a reduction shorter than the stage — conv1's K = 27 — stops early: the rest of
+        // the stage is zeros; an odd tail is one more zero step)
+        stash();
+        __syncthreads();
+        operands();
+        const int steps = min(BK, (kend - k0 + 1) & ~1);
+        if (BK == BK_SMALL || steps == BK) {
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) mfma_step(kk);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2)
+                if (kk < steps) mfma_step(kk);                   // (uniform; unrolled so that av / bv stay registers)
+        }
     }
     // [probe:7]
 
