@@ -30,7 +30,7 @@ namespace {
 constexpr int BK_SMALL = 16, BK_DEEP = 64;
 
 // what an absent 16-byte piece reads: zeros, so that it needs no fix-up on its way into LDS
-__device__ __attribute__((aligned(16))) const float g_gemm_zeros[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) float g_gemm_zeros[4] = {0.f, 0.f, 0.f, 0.f};      // (not const: a constant-address-space pointer selected against a global one makes every load a FLAT one)
 
 
 // a / d for 0 <= a < 2^23, d > 0 given rd = 1.f / d: one multiply and a correction instead of the ~40 instructions of an
