@@ -330,6 +330,22 @@ class SmallResNet(KerasFitMixin):
         _abi.check(self.lib.alink_smallres_apply_update(self.h, _abi.current_stream(self.device)), "alink_smallres_apply_update")
 
     def test_on_batch(self, x, y):
+        n = len(y)
+        if n <= MAXN:
+            # one evaluation launch chain: operands through the step's staging (one upload), {loss, accuracy} written by the
+            # device into pinned host memory, one stream synchronisation (a .to() per operand and a .cpu() of the metrics were a
+            # third of the call)
+            torch = self.torch
+            staged = self._up_all((x[0], x[1], y, None))
+            if staged is not None:
+                L, R, yd, _ = staged
+            else:
+                L, R, yd = self._up("L", x[0]), self._up("R", x[1]), self._up("y", y)
+            st = torch.cuda.current_stream(self._tdev)
+            _abi.check(self.lib.alink_smallres_eval(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yd), n, self.prescale,
+                                                    C.c_void_p(self._metrics_host.data_ptr()), C.c_void_p(st.cuda_stream)), "alink_smallres_eval")
+            st.synchronize()
+            return self._metrics_host.tolist()[:2]
         L, R, yd = self._dev(x[0]), self._dev(x[1]), self._dev(y)
         tot, seen = np.zeros(2), 0
         for s in range(0, L.shape[0], MAXN):
