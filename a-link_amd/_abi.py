@@ -118,6 +118,7 @@ PROTOTYPES = {
     "alink_smallres_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "alink_smallres_train_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _f, _i, _vp, _vp]),
     "alink_smallres_train_step_drawn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, C.c_uint64, _f, _i, _vp, _vp]),
+    "alink_smallres_train_on_batch_host": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_uint64, _vp, _vp]),
     "alink_smallres_apply_update": (_i, [_vp, _vp]),
     "alink_smallres_set_graph": (_i, [_vp, _i]),
     "alink_smallres_eval": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),

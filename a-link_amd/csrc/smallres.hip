@@ -17,6 +17,7 @@
 #include "sgemm.h"
 #include "philox.h"
 
+#include <cstring>
 #include <vector>
 
 using namespace alink;
@@ -232,6 +233,10 @@ struct alink_smallres {
     std::vector<StepGraph> graphs;
     bool use_graph = false;
     uint8_t *arg1 = nullptr, *arg2 = nullptr;
+    // alink_smallres_train_on_batch_host: the step's operands staged through pinned memory owned by the handle
+    float *h_stage = nullptr, *d_stage = nullptr, *h_metrics = nullptr;
+    uint8_t* d_masks_own = nullptr;
+    int stage_rows = 0;                // pairs the staging is sized for
     float* d_all_grads = nullptr;      // [tower grads | head grads] contiguous copy for all-reduce
     float* ws = nullptr;               // split-K slabs of sgemm
     size_t ws_floats = 0;
@@ -242,6 +247,10 @@ struct alink_smallres {
         for (hipEvent_t e : ev_dz) if (e) (void)hipEventDestroy(e);
         if (ev_side) (void)hipEventDestroy(ev_side);
         for (void* p : allocs) (void)hipFree(p);
+        if (h_stage) (void)hipHostFree(h_stage);
+        if (h_metrics) (void)hipHostFree(h_metrics);
+        if (d_stage) (void)hipFree(d_stage);
+        if (d_masks_own) (void)hipFree(d_masks_own);
         if (head) alink_head_destroy(head);
     }
 };
@@ -636,6 +645,52 @@ int alink_smallres_train_step_drawn(alink_smallres_t* m, const float* dev_L, con
     }
     DeviceGuard dg(m->device);
     return train_step_launches(m, dev_L, dev_R, dev_y, dev_sw, n, prescale, dev_masks, grad_scale, apply, dev_metrics, stream, &mask_seed);
+}
+
+int alink_smallres_train_on_batch_host(alink_smallres_t* m, const float* host_L, const float* host_R, const float* host_y,
+                                       const float* host_sw, int n, int prescale, int dropout, uint64_t mask_seed,
+                                       float* host_metrics, void* stream) {
+    ALINK_REQUIRE(m && host_L && host_R && host_y && host_metrics, ALINK_EINVAL, "NULL argument");
+    ALINK_REQUIRE(n > 0 && n <= MAXN, ALINK_EINVAL, "n=%d outside 1..%d", n, MAXN);
+    DeviceGuard dg(m->device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t img = (size_t)m->H * m->W * 3;
+    const size_t e1 = (size_t)m->P1h * m->P1w * 32, e2 = (size_t)m->P2h * m->P2w * 64;
+    if (n > m->stage_rows) {               // (grown to the largest batch seen; a step is synchronous, so nothing is in flight here)
+        ALINK_HIP(hipStreamSynchronize(st));
+        if (m->h_stage) (void)hipHostFree(m->h_stage);
+        if (m->d_stage) (void)hipFree(m->d_stage);
+        if (m->d_masks_own) (void)hipFree(m->d_masks_own);
+        m->h_stage = m->d_stage = nullptr; m->d_masks_own = nullptr; m->stage_rows = 0;
+        const int rows = n < 16 ? 16 : n;
+        const size_t floats = (size_t)rows * (2 * img + 4);
+        ALINK_HIP(hipHostMalloc((void**)&m->h_stage, floats * sizeof(float), hipHostMallocDefault));
+        ALINK_HIP(hipMalloc((void**)&m->d_stage, floats * sizeof(float)));
+        ALINK_HIP(hipMalloc((void**)&m->d_masks_own, 2 * (size_t)rows * (e1 + e2)));
+        if (!m->h_metrics) ALINK_HIP(hipHostMalloc((void**)&m->h_metrics, 4 * sizeof(float), hipHostMallocDefault));
+        m->stage_rows = rows;
+    }
+    // [L | R | y | sw] in one pinned block, one upload
+    const size_t oL = 0, oR = (size_t)n * img, oy = 2 * (size_t)n * img, osw = oy + 2 * (size_t)n, total = osw + (host_sw ? (size_t)n : 0);
+    memcpy(m->h_stage + oL, host_L, (size_t)n * img * sizeof(float));
+    memcpy(m->h_stage + oR, host_R, (size_t)n * img * sizeof(float));
+    memcpy(m->h_stage + oy, host_y, 2 * (size_t)n * sizeof(float));
+    if (host_sw) memcpy(m->h_stage + osw, host_sw, (size_t)n * sizeof(float));
+    ALINK_HIP(hipMemcpyAsync(m->d_stage, m->h_stage, total * sizeof(float), hipMemcpyHostToDevice, st));
+    const float* dsw = host_sw ? m->d_stage + osw : nullptr;
+    int rc;
+    if (dropout && m->use_graph) {
+        rc = alink_smallres_train_step_drawn(m, m->d_stage + oL, m->d_stage + oR, m->d_stage + oy, dsw, n, prescale, m->d_masks_own, mask_seed,
+                                             0.f, 1, m->h_metrics, stream);
+    } else {
+        rc = train_step_launches(m, m->d_stage + oL, m->d_stage + oR, m->d_stage + oy, dsw, n, prescale, dropout ? m->d_masks_own : nullptr,
+                                 0.f, 1, m->h_metrics, stream, dropout ? &mask_seed : nullptr);
+    }
+    if (rc) return rc;
+    ALINK_HIP(hipStreamSynchronize(st));
+    host_metrics[0] = m->h_metrics[0];
+    host_metrics[1] = m->h_metrics[1];
+    return ALINK_OK;
 }
 
 int alink_smallres_apply_update(alink_smallres_t* m, void* stream) {

@@ -53,6 +53,7 @@ class SmallResNet(KerasFitMixin):
         # {loss, accuracy} of a step land in pinned host memory, written by the kernel itself (as DenseHead's do): a step ends with
         # one stream wait instead of a device-to-host copy
         self._metrics_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        self._metrics_np = np.zeros(2, dtype=np.float32)
         self._tdev = torch.device(self.device)
         self._tdev_index = self._tdev.index
         self._mask_buf = {}
@@ -227,6 +228,19 @@ class SmallResNet(KerasFitMixin):
         if sw is None and class_weight is not None:
             sw = np.asarray([class_weight[c] for c in np.asarray(y).argmax(axis=1)], np.float32)
         cur = torch.cuda.current_stream(self._tdev)
+        if masks is None and not self.use_graph and not isinstance(x[0], torch.Tensor) and not isinstance(x[1], torch.Tensor) \
+                and not isinstance(y, torch.Tensor) and not isinstance(sw, torch.Tensor):
+            # host operands, as the reference's Keras call hands them: ONE synchronous library call stages them (pinned memory of the
+            # handle, one upload), draws the masks, runs the step, synchronises and returns {loss, accuracy}
+            L, R = np.ascontiguousarray(x[0], np.float32), np.ascontiguousarray(x[1], np.float32)
+            yh = np.ascontiguousarray(y, np.float32)
+            swh = None if sw is None else np.ascontiguousarray(sw, np.float32)
+            drop = 1 if self.training_dropout else 0
+            seed = int(np.random.randint(0, 2 ** 31 - 1)) if drop else 0      # (one np.random draw per step, as in the device-operand form)
+            _abi.check(self.lib.alink_smallres_train_on_batch_host(self.h, _abi.ptr(L), _abi.ptr(R), _abi.ptr(yh), _abi.ptr(swh), n, self.prescale,
+                                                                   drop, seed, _abi.ptr(self._metrics_np), C.c_void_p(cur.cuda_stream)),
+                       "alink_smallres_train_on_batch_host")
+            return self._metrics_np.tolist()
         st = self._stream if self.use_graph else cur
         if st is not cur:
             st.wait_stream(cur)                       # inputs produced on the caller's stream

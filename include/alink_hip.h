@@ -393,6 +393,13 @@ int alink_smallres_train_step(alink_smallres_t* m, const float* dev_L, const flo
 int alink_smallres_train_step_drawn(alink_smallres_t* m, const float* dev_L, const float* dev_R, const float* dev_y,
                                     const float* dev_sw, int n, int prescale, uint8_t* dev_masks, uint64_t mask_seed,
                                     float grad_scale, int apply, float* dev_metrics, void* stream);
+/* Keras train_on_batch (code/siamese.py:172-184 hands NumPy arrays) as ONE synchronous call on HOST operands: host_L / host_R
+ * (n, H, W, 3) f32, host_y (n, 2), host_sw (n) or NULL.  The operands go through pinned staging owned by the handle (one
+ * upload), the step draws its Dropout masks from mask_seed (dropout = 0: no Dropout), applies its update, the stream is
+ * synchronised and {loss, accuracy} are returned in host_metrics[2]. */
+int alink_smallres_train_on_batch_host(alink_smallres_t* m, const float* host_L, const float* host_R, const float* host_y,
+                                       const float* host_sw, int n, int prescale, int dropout, uint64_t mask_seed,
+                                       float* host_metrics, void* stream);
 /* Optional (SmallResNet turns it on): on a non-default stream, the whole train step — ~40 short launches on two streams — is
  * captured per distinct (operand pointers, n, flags, lr) the second time it is seen and replayed from then on.  The caller keeps its
  * operands at stable addresses (staging buffers) for that to hit.  Same kernels, same order: the same results. */
